@@ -1,0 +1,154 @@
+/* rtmodt.h -- C ABI of librtmodt_hip.so, the MI355X (gfx950) detect + track hot path.
+ *
+ * Drop-in boundary for the reference's two hot-path classes:
+ *   src/detection/detector.py:54-135   class Detector          -> rtmodt_detector_*
+ *   src/tracking/tracker.py:43-194     class _ByteTrackCore    -> rtmodt_tracker_*
+ * The Python classes of the same names in the package call these entry points through
+ * ctypes; INTEGRATION.md shows the binding a maintainer of the reference would add.
+ *
+ * Conventions: plain C, opaque handles, host pointers unless a parameter says "device".
+ * Every function returns 0 on success or a negative RTMODT_E_* code; the message for the
+ * calling thread's last failure is rtmodt_last_error().  No exceptions cross the ABI.
+ * The library owns all device memory (one static arena per handle).  Handles are not
+ * thread-safe: one Detector + one tracker per stream group, used from one thread
+ * (as the reference's single main loop does, tools/run_pipeline.py:121-166).
+ */
+#ifndef RTMODT_H
+#define RTMODT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RTMODT_OK 0
+#define RTMODT_E_INVALID (-1)   /* bad argument / unsupported configuration            */
+#define RTMODT_E_IO (-2)        /* weight file missing or malformed                    */
+#define RTMODT_E_HIP (-3)       /* HIP runtime failure (message carries hipGetErrorString) */
+#define RTMODT_E_CAPACITY (-4)  /* more tracks / detections than the handle was sized for */
+#define RTMODT_E_UNSUPPORTED (-5)
+
+#define RTMODT_MEM_HOST 0
+#define RTMODT_MEM_DEVICE 1
+
+#define RTMODT_ASSIGN_GREEDY 0  /* tracker.py:182-194 (the branch taken when `lap` is absent) */
+#define RTMODT_ASSIGN_LAPJV 1   /* tracker.py:168-181 (lap.lapjv); not built yet -> RTMODT_E_UNSUPPORTED */
+
+typedef struct rtmodt_detector rtmodt_detector;
+typedef struct rtmodt_tracker rtmodt_tracker;
+
+/* ---- library / device ------------------------------------------------------------- */
+const char *rtmodt_last_error(void);
+const char *rtmodt_version(void);
+int rtmodt_device_count(int *count);
+int rtmodt_synchronize(int device);                 /* replaces torch.cuda.synchronize() (latency_profiler.py:63,69) */
+int rtmodt_device_alloc(int device, size_t bytes, void **out);
+int rtmodt_device_free(int device, void *ptr);
+int rtmodt_memcpy_h2d(int device, void *dst_device, const void *src_host, size_t bytes);
+int rtmodt_memcpy_d2h(int device, void *dst_host, const void *src_device, size_t bytes);
+
+/* ---- detector: replaces Detector.__init__/detect/_parse (detector.py:59-129) ------- */
+typedef struct rtmodt_det_cfg {
+    const char *weight_path;   /* RTMODTW1 file (package weights.py); model scale/nc come from its header */
+    int32_t in_w, in_h;        /* network input = letterbox target; multiples of 32 (detector.py:61, :102) */
+    float conf;                /* detector.py:62  confidence=0.35  (strict >, float32)                      */
+    float iou;                 /* detector.py:63  iou=0.45         (strict >)                               */
+    const int32_t *classes;    /* detector.py:64  class filter, NULL = all                                 */
+    int32_t n_classes;
+    int32_t half;              /* detector.py:65,76  must be 1: the engine stores activations in fp16       */
+    int32_t device;            /* detector.py:66  ordinal of "cuda:N"                                      */
+    int32_t max_det;           /* detector.py:67  max_det=100                                              */
+    int32_t agnostic;          /* detector.py:68  agnostic_nms                                             */
+    int32_t batch;             /* frames per detect_batch call (streams batched on this GPU), >= 1         */
+    int32_t max_src_w, max_src_h; /* largest source frame accepted (staging), 0 = in_w/in_h                */
+    int32_t use_graph;         /* 1: replay the forward pass as one captured hipGraph                      */
+} rtmodt_det_cfg;
+
+int rtmodt_detector_create(const rtmodt_det_cfg *cfg, rtmodt_detector **out);
+void rtmodt_detector_destroy(rtmodt_detector *det);
+
+/* One frame, synchronous: letterbox -> forward -> decode -> NMS -> rescale -> D2H.
+ * bgr: H x W x 3 uint8, row pitch stride_bytes (host).  Outputs caller-allocated:
+ * xyxy[max_det*4], conf[max_det], cls[max_det]; *n_out = number of detections. */
+int rtmodt_detector_detect(rtmodt_detector *det, const uint8_t *bgr, int h, int w, int stride_bytes,
+                           float *xyxy, float *conf, int32_t *cls, int32_t *n_out);
+
+/* n <= cfg.batch frames of identical size in one pass (BASELINE configs 4-5: streams
+ * batched per GPU).  frames[i] is a host or device pointer per mem_kind.  Outputs are
+ * [n][max_det] blocks; n_out[n]. */
+int rtmodt_detector_detect_batch(rtmodt_detector *det, const uint8_t *const *frames, int n, int h, int w,
+                                 int stride_bytes, int mem_kind, float *xyxy, float *conf, int32_t *cls,
+                                 int32_t *n_out);
+
+/* Asynchronous halves of detect_batch for the throughput path: enqueue leaves the
+ * detections on the device (consumable by rtmodt_tracker_update_from_detector on the same
+ * HIP stream, no host round trip); fetch synchronises and copies them out. */
+int rtmodt_detector_enqueue_batch(rtmodt_detector *det, const uint8_t *const *frames, int n, int h, int w,
+                                  int stride_bytes, int mem_kind);
+int rtmodt_detector_fetch(rtmodt_detector *det, float *xyxy, float *conf, int32_t *cls, int32_t *n_out);
+
+/* Introspection used by the parity tests and bench.py */
+int rtmodt_detector_info(rtmodt_detector *det, int32_t *scale_id, int32_t *nc, int32_t *n_anchors,
+                         int32_t *n_convs, int64_t *conv_flops_per_frame, int64_t *arena_bytes);
+/* Copies out, for frame `img` of the last batch: the letterboxed network input as fp16 NHWC(3)
+ * [in_h*in_w*3] (may be NULL), the three Detect maps as fp16 [A_i*(64+nc)] concatenated
+ * P3,P4,P5 (may be NULL) and the decoded pre-NMS tensor pred[(4+nc)*A] float32 (may be NULL). */
+int rtmodt_detector_debug_fetch(rtmodt_detector *det, int img, uint16_t *input_f16, uint16_t *heads_f16, float *pred);
+/* Output of fused conv `name` ("4.cv2", "22.cv3.0.1", ...) for frame img as fp16 NHWC [H*W*C];
+ * shape returned through hwc[3]; out may be NULL to query the shape. */
+int rtmodt_detector_debug_layer(rtmodt_detector *det, const char *name, int img, uint16_t *out, int32_t *hwc);
+/* Per-launch device time of the last `iters` eager (non-graph) forwards, measured with HIP
+ * events on the detector's stream: names[i] points into handle-owned storage. */
+int rtmodt_detector_profile(rtmodt_detector *det, int iters, int max_entries, const char **names, float *ms,
+                            int64_t *flops, int32_t *n_entries);
+/* Device time (ms, HIP events on the detector's stream) of the last enqueue_batch: whole
+ * pass, and the forward-graph part alone. */
+int rtmodt_detector_last_timing(rtmodt_detector *det, float *total_ms, float *forward_ms);
+
+/* decode-free NMS on a caller-supplied pre-NMS tensor pred[(4+nc)*A] float32 (the layout
+ * ultralytics' non_max_suppression receives): BASELINE config 2's
+ * "NMS correctness" case.  dets out: xyxy in the tensor's own coordinates (no rescale). */
+int rtmodt_nms_pred(int device, const float *pred, int nc, int n_anchors, float conf, float iou,
+                    const int32_t *classes, int n_classes, int agnostic, int max_det,
+                    float *xyxy, float *conf_out, int32_t *cls, int32_t *anchor_idx, int32_t *n_out);
+
+/* letterbox + BGR->RGB + /255 alone (ultralytics LetterBox + cv2.resize INTER_LINEAR restated):
+ * out fp16 NHWC [in_h*in_w*3]. */
+int rtmodt_preprocess(int device, const uint8_t *bgr, int h, int w, int stride_bytes, int in_w, int in_h,
+                      uint16_t *out_f16);
+
+/* ---- tracker: replaces _ByteTrackCore (tracker.py:43-194) ---------------------------- */
+/* n_streams independent tracker states updated by ONE launch (one workgroup per stream). */
+int rtmodt_tracker_create(int device, float track_thresh, int track_buffer, float match_thresh,
+                          int assign_mode, int max_tracks, int max_dets, int n_streams, rtmodt_tracker **out);
+void rtmodt_tracker_destroy(rtmodt_tracker *trk);
+
+/* One frame for one stream (tracker.py:58-141).  *n_active_out = tracks with
+ * time_since_update == 0 after the update -- always 0, as in the reference (SURVEY finding 4). */
+int rtmodt_tracker_update(rtmodt_tracker *trk, int stream, const float *xyxy, const float *conf,
+                          const int32_t *cls, int n, int32_t *n_active_out);
+/* One frame for every stream: xyxy[n_streams][max_dets][4], conf/cls[n_streams][max_dets], n[n_streams]. */
+int rtmodt_tracker_update_batch(rtmodt_tracker *trk, const float *xyxy, const float *conf, const int32_t *cls,
+                                const int32_t *n, int32_t *n_active_out);
+/* Consumes the device-resident detections of det's last enqueue_batch (stream i <- frame i),
+ * asynchronously on det's HIP stream. */
+int rtmodt_tracker_update_from_detector(rtmodt_tracker *trk, rtmodt_detector *det);
+/* List-order snapshot of a stream's state = the reference's _core._tracks + _core._next_id
+ * (the parity surface).  Arrays sized max_tracks; any may be NULL. */
+int rtmodt_tracker_state(rtmodt_tracker *trk, int stream, int64_t *ids, float *xyxy, float *conf,
+                         int32_t *cls, int32_t *age, int32_t *tsu, int32_t *n, int64_t *next_id);
+int rtmodt_tracker_reset(rtmodt_tracker *trk, int stream);   /* stream < 0: all */
+
+/* _ByteTrackCore._batch_iou (tracker.py:150-161) alone: out[m*n] float32, bit-exact. */
+int rtmodt_iou_matrix(int device, const float *a, int m, const float *b, int n, float *out);
+/* _linear_assignment greedy branch (tracker.py:182-194) alone on a caller-supplied matrix:
+ * row_to_col[m] (-1 = unmatched), col_used[n]. */
+int rtmodt_assign_greedy(int device, const float *iou, int m, int n, float thresh, int32_t *row_to_col,
+                         int32_t *col_used);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RTMODT_H */

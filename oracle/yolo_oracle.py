@@ -202,38 +202,52 @@ def upsample2(x):
 # ---------------------------------------------------------------------------
 # network forward
 # ---------------------------------------------------------------------------
-def forward(x, weights: dict, scale="s", nc=80, reg_max=16, taps: dict | None = None):
+def forward(x, weights: dict, scale="s", nc=80, reg_max=16, taps: dict | None = None, force: dict | None = None):
     """x: (H,W,3) float32 RGB in [0,1].  ``weights[name] = (w, b)``.  Returns the three
     Detect maps ``[(H_i, W_i, 4*reg_max + nc)]`` (box logits first, then class logits).
-    ``taps`` (optional dict) receives every module output by index for per-layer checks."""
-    mods, head = arch(scale, nc, reg_max)
 
-    def cv(name, t, k_s_act):
+    ``taps`` (optional dict) receives every fused conv's output by name (for a Bottleneck's
+    second conv: the value AFTER the residual add, which is what the engine stores) and
+    every module output by integer index.  ``force[name]`` (optional) replaces that conv's
+    output before it is used downstream -- "teacher forcing" with the engine's own
+    activations, so each layer can be checked in isolation with a tight tolerance."""
+    mods, head = arch(scale, nc, reg_max)
+    force = force or {}
+
+    def tap(name, y):
+        if taps is not None:
+            taps[name] = y
+        f = force.get(name)
+        return y if f is None else np.asarray(f, dtype=F32).reshape(y.shape)
+
+    def cv(name, t, stride, act, res=None):
         w, b = weights[name]
-        return conv2d_nhwc(t, w, b, stride=k_s_act[0], act=k_s_act[1])
+        y = conv2d_nhwc(t, w, b, stride=stride, act=act)
+        if res is not None:
+            y = (res + y).astype(F32)
+        return tap(name, y)
 
     saved = {}
     cur = x.astype(F32)
     for i, m in enumerate(mods):
         kind = m[0]
         if kind == "conv":
-            cur = cv(f"{i}", cur, (m[5], 1))
+            cur = cv(f"{i}", cur, m[5], 1)
         elif kind == "c2f":
             n, shortcut = m[4], m[5]
-            y = cv(f"{i}.cv1", cur, (1, 1))
+            y = cv(f"{i}.cv1", cur, 1, 1)
             c = y.shape[2] // 2
             ys = [y[..., :c], y[..., c:]]
             for j in range(n):
-                t = cv(f"{i}.m.{j}.cv1", ys[-1], (1, 1))
-                t = cv(f"{i}.m.{j}.cv2", t, (1, 1))
-                ys.append((ys[-1] + t).astype(F32) if shortcut else t)
-            cur = cv(f"{i}.cv2", np.concatenate(ys, axis=2), (1, 1))
+                t = cv(f"{i}.m.{j}.cv1", ys[-1], 1, 1)
+                ys.append(cv(f"{i}.m.{j}.cv2", t, 1, 1, res=ys[-1] if shortcut else None))
+            cur = cv(f"{i}.cv2", np.concatenate(ys, axis=2), 1, 1)
         elif kind == "sppf":
-            y = cv(f"{i}.cv1", cur, (1, 1))
+            y = cv(f"{i}.cv1", cur, 1, 1)
             p1 = maxpool5(y)
             p2 = maxpool5(p1)
             p3 = maxpool5(p2)
-            cur = cv(f"{i}.cv2", np.concatenate([y, p1, p2, p3], axis=2), (1, 1))
+            cur = cv(f"{i}.cv2", np.concatenate([y, p1, p2, p3], axis=2), 1, 1)
         elif kind == "up":
             cur = upsample2(cur)
         elif kind == "cat":
@@ -245,12 +259,12 @@ def forward(x, weights: dict, scale="s", nc=80, reg_max=16, taps: dict | None = 
     outs = []
     for lvl, src in enumerate((15, 18, 21)):
         f = saved[src]
-        bx = cv(f"22.cv2.{lvl}.0", f, (1, 1))
-        bx = cv(f"22.cv2.{lvl}.1", bx, (1, 1))
-        bx = cv(f"22.cv2.{lvl}.2", bx, (1, 0))
-        cl = cv(f"22.cv3.{lvl}.0", f, (1, 1))
-        cl = cv(f"22.cv3.{lvl}.1", cl, (1, 1))
-        cl = cv(f"22.cv3.{lvl}.2", cl, (1, 0))
+        bx = cv(f"22.cv2.{lvl}.0", f, 1, 1)
+        bx = cv(f"22.cv2.{lvl}.1", bx, 1, 1)
+        bx = cv(f"22.cv2.{lvl}.2", bx, 1, 0)
+        cl = cv(f"22.cv3.{lvl}.0", f, 1, 1)
+        cl = cv(f"22.cv3.{lvl}.1", cl, 1, 1)
+        cl = cv(f"22.cv3.{lvl}.2", cl, 1, 0)
         outs.append(np.concatenate([bx, cl], axis=2))
     return outs
 

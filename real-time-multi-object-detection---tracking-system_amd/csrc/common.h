@@ -1,0 +1,44 @@
+// common.h -- error plumbing and small helpers shared by every translation unit of
+// librtmodt_hip.so.  gfx950 only; no CUDA compatibility layer.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <string>
+
+#include "../../include/rtmodt.h"
+
+namespace rtmodt {
+
+// thread-local last-error string behind rtmodt_last_error()
+std::string &last_error();
+int fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
+
+#define RT_HIP(expr)                                                                                   \
+    do {                                                                                               \
+        hipError_t _e = (expr);                                                                        \
+        if (_e != hipSuccess)                                                                          \
+            return ::rtmodt::fail(RTMODT_E_HIP, "%s:%d %s -> %s", __FILE__, __LINE__, #expr,           \
+                                  hipGetErrorString(_e));                                              \
+    } while (0)
+
+#define RT_CHECK(cond, code, ...)                                  \
+    do {                                                           \
+        if (!(cond)) return ::rtmodt::fail((code), __VA_ARGS__);   \
+    } while (0)
+
+#define RT_TRY(expr)               \
+    do {                           \
+        int _r = (expr);           \
+        if (_r != RTMODT_OK) return _r; \
+    } while (0)
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+typedef _Float16 f16;
+
+}  // namespace rtmodt

@@ -1,0 +1,886 @@
+// engine.hip -- host runtime behind the detector half of include/rtmodt.h.
+//
+// Plays the part `ultralytics.YOLO(...)` + `model.predict(...)` play for the reference's
+// Detector (/root/reference/src/detection/detector.py:82-112): reads the fused-conv weight
+// file, builds the YOLOv8 graph natively for one (scale, input size, batch), lays every
+// activation out in ONE device arena (fp16 NHWC, zero borders, concat-free channel slices),
+// captures the forward pass into a hipGraph and drives
+//   letterbox -> [graph: stem, 60-odd MFMA convs, SPPF pools, upsamples, decode] -> NMS
+// on a private HIP stream.  No PyTorch, no BLAS/MIOpen: only the kernels in this directory.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <fstream>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "kernels.h"
+
+namespace rtmodt {
+
+std::string &last_error() {
+    static thread_local std::string e;
+    return e;
+}
+
+int fail(int code, const char *fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    last_error() = buf;
+    return code;
+}
+
+// ------------------------------------------------------------------ weight file (package weights.py)
+struct WeightRec {
+    std::string name;
+    int cin, cout, k, stride, act;
+    std::vector<f16> w;      // [cout][k][k][cin]
+    std::vector<float> b;    // [cout]
+};
+
+struct WeightFile {
+    int scale_id = 1, nc = 80, reg_max = 16;
+    std::map<std::string, WeightRec> recs;
+    std::vector<std::string> order;
+};
+
+static int read_weight_file(const char *path, WeightFile &wf) {
+    std::ifstream f(path, std::ios::binary);
+    RT_CHECK(f.good(), RTMODT_E_IO, "No model found at %s", path);
+    std::vector<char> raw((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+    RT_CHECK(raw.size() >= 40 && memcmp(raw.data(), "RTMODTW1", 8) == 0, RTMODT_E_IO, "%s: not an RTMODTW1 weight file", path);
+    const uint32_t *h = (const uint32_t *)(raw.data() + 8);
+    RT_CHECK(h[0] == 1, RTMODT_E_IO, "%s: unsupported version %u", path, h[0]);
+    wf.scale_id = (int)h[1]; wf.nc = (int)h[2]; wf.reg_max = (int)h[3];
+    uint32_t n = h[4];
+    RT_CHECK(raw.size() >= 40 + (size_t)n * 72, RTMODT_E_IO, "%s: truncated record table", path);
+    for (uint32_t i = 0; i < n; ++i) {
+        const char *r = raw.data() + 40 + (size_t)i * 72;
+        WeightRec w;
+        w.name = std::string(r, strnlen(r, 32));
+        const uint32_t *u = (const uint32_t *)(r + 32);
+        w.cin = u[0]; w.cout = u[1]; w.k = u[2]; w.stride = u[3]; w.act = u[4];
+        uint64_t woff, boff;
+        memcpy(&woff, r + 56, 8); memcpy(&boff, r + 64, 8);
+        size_t nw = (size_t)w.cout * w.k * w.k * w.cin;
+        RT_CHECK(woff + nw * 2 <= raw.size() && boff + (size_t)w.cout * 4 <= raw.size(), RTMODT_E_IO, "%s: record %s out of bounds", path,
+                 w.name.c_str());
+        w.w.resize(nw); w.b.resize(w.cout);
+        memcpy(w.w.data(), raw.data() + woff, nw * 2);
+        memcpy(w.b.data(), raw.data() + boff, (size_t)w.cout * 4);
+        wf.order.push_back(w.name);
+        wf.recs[w.name] = std::move(w);
+    }
+    return RTMODT_OK;
+}
+
+// ------------------------------------------------------------------ letterbox geometry (ultralytics LetterBox, App. B.1)
+static inline int round_half_even(double v) { return (int)std::nearbyint(v); }   // == Python round()
+
+struct LbHost { int new_w, new_h, top, left, resize; double gain; int pad_x, pad_y; };
+
+static LbHost letterbox_geometry(int h, int w, int in_h, int in_w) {
+    LbHost g;
+    double r = std::min((double)in_h / h, (double)in_w / w);
+    g.new_w = round_half_even(w * r); g.new_h = round_half_even(h * r);
+    double dw = (in_w - g.new_w) / 2.0, dh = (in_h - g.new_h) / 2.0;
+    g.top = round_half_even(dh - 0.1); g.left = round_half_even(dw - 0.1);
+    g.resize = (g.new_w != w) || (g.new_h != h);
+    // scale_boxes (App. B.4)
+    g.gain = std::min((double)in_h / h, (double)in_w / w);
+    g.pad_x = round_half_even((in_w - w * g.gain) / 2 - 0.1);
+    g.pad_y = round_half_even((in_h - h * g.gain) / 2 - 0.1);
+    return g;
+}
+
+// cv::resize INTER_LINEAR 8-bit tables (same arithmetic as oracle/yolo_oracle.py:_resize_coeffs)
+static void build_resize_tables(int dst, int src, std::vector<int32_t> &ofs, std::vector<int32_t> &c0, std::vector<int32_t> &c1) {
+    ofs.resize(dst); c0.resize(dst); c1.resize(dst);
+    double scale = 1.0 / ((double)dst / src);
+    for (int d = 0; d < dst; ++d) {
+        float f = (float)((d + 0.5) * scale - 0.5);
+        int s = (int)std::floor(f);
+        f = f - (float)s;
+        if (s < 0) { s = 0; f = 0.f; }
+        if (s >= src - 1) { s = src - 1; f = 0.f; }
+        ofs[d] = s;
+        c0[d] = (int)std::nearbyint((1.0f - f) * 2048.0f);
+        c1[d] = (int)std::nearbyint(f * 2048.0f);
+    }
+}
+
+// ------------------------------------------------------------------ graph description
+struct Tensor { f16 *ptr = nullptr; int H, W, C, pad; size_t per_image; };
+
+enum OpKind { OP_STEM, OP_CONV, OP_POOL, OP_UP };
+
+struct Op {
+    OpKind kind;
+    std::string name;
+    ConvLaunch conv;                 // OP_CONV
+    TensorView v[4];                 // STEM: in,out; POOL: y,p1,p2,p3; UP: in,out
+    const float *stem_w = nullptr, *stem_b = nullptr;
+    int64_t flops = 0;               // per frame
+};
+
+}  // namespace rtmodt
+
+using namespace rtmodt;
+
+struct rtmodt_detector {
+    rtmodt_det_cfg cfg{};
+    std::string weight_path;
+    std::vector<int32_t> classes;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int scale_id = 1, nc = 80, reg_max = 16;
+    int B = 1, in_h = 640, in_w = 640, n_anchors = 0;
+    // arena
+    char *arena = nullptr;
+    size_t arena_bytes = 0;
+    std::vector<Tensor> tensors;
+    std::vector<Op> ops;
+    std::map<std::string, TensorView> layer_out;     // fused conv name -> output view
+    std::vector<void *> dev_allocs;                   // weights etc.
+    int img_t = -1;
+    int head_t[3] = {-1, -1, -1};
+    int64_t flops_per_frame = 0;
+    // frames
+    uint8_t *stage = nullptr; size_t stage_per = 0;
+    FramePtrs fptrs{};
+    int tab_h = -1, tab_w = -1;
+    int32_t *d_tab = nullptr; size_t tab_cap = 0;
+    ResizeTables tabs{};
+    // postprocess
+    float4 *d_box = nullptr; float *d_score = nullptr; int32_t *d_cls = nullptr; float *d_pred = nullptr;
+    uint64_t *d_keys = nullptr; float4 *d_sbox = nullptr; int32_t *d_sidx = nullptr;
+    float *o_xyxy = nullptr, *o_conf = nullptr; int32_t *o_cls = nullptr, *o_anchor = nullptr, *o_n = nullptr;
+    float *h_xyxy = nullptr, *h_conf = nullptr; int32_t *h_cls = nullptr, *h_n = nullptr;   // pinned
+    uint64_t class_mask[2] = {~0ull, ~0ull};
+    // graph
+    hipGraph_t graph = nullptr; hipGraphExec_t graph_exec = nullptr;
+    bool want_pred = false;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
+    int last_n = 0, last_h = 0, last_w = 0;
+    bool pending = false;
+    // profile storage
+    std::vector<std::string> prof_names;
+};
+
+namespace rtmodt {
+
+struct Builder {
+    rtmodt_detector *d;
+    WeightFile *wf;
+    size_t arena_used = 0;
+
+    int T(int H, int W, int C, int pad) {
+        Tensor t;
+        t.H = H; t.W = W; t.C = C; t.pad = pad;
+        t.per_image = (size_t)(H + 2 * pad) * (W + 2 * pad) * C;
+        size_t bytes = align_up(t.per_image * d->B * sizeof(f16), 256);
+        t.ptr = (f16 *)(uintptr_t)arena_used;            // offset for now; rebased after allocation
+        arena_used += bytes + 256;                         // slack: tail tiles of the conv re-read within the tensor only, keep tensors apart
+        d->tensors.push_back(t);
+        return (int)d->tensors.size() - 1;
+    }
+    TensorView V(int t, int coff = 0, int c = -1) {
+        const Tensor &x = d->tensors[t];
+        TensorView v;
+        v.base = x.ptr; v.H = x.H; v.W = x.W; v.C = x.C; v.pad = x.pad; v.coff = coff; v.c = c < 0 ? x.C : c;
+        return v;
+    }
+};
+
+static int upload(rtmodt_detector *d, const void *src, size_t bytes, void **out) {
+    void *p = nullptr;
+    RT_HIP(hipMalloc(&p, bytes));
+    RT_HIP(hipMemcpy(p, src, bytes, hipMemcpyHostToDevice));
+    d->dev_allocs.push_back(p);
+    *out = p;
+    return RTMODT_OK;
+}
+
+static int pick_tile(int M, int cout) {
+    if (const char *e = getenv("RTMODT_TILE")) {
+        int t = atoi(e);
+        if (t >= 0 && t < TILE_COUNT) return t;
+    }
+    static const float eff[TILE_COUNT] = {1.0f, 0.85f, 0.62f, 0.75f, 0.85f};
+    static const int occ[TILE_COUNT] = {3, 5, 8, 4, 5};
+    int best = 0;
+    double best_cost = 1e30;
+    for (int t = 0; t < TILE_COUNT; ++t) {
+        TileShape ts = tile_shape(t);
+        long nblk = (long)cdiv(M, ts.bm) * cdiv(cout, ts.bn);
+        long slots = 256L * occ[t];
+        double waves = std::ceil((double)nblk / slots);
+        // partial last wave costs less than a full one when blocks are few
+        double fill = (double)nblk / (waves * slots);
+        double cost = waves * ts.bm * ts.bn / eff[t] * (0.5 + 0.5 * std::max(fill, 1.0 / occ[t]));
+        if (cost < best_cost) { best_cost = cost; best = t; }
+    }
+    return best;
+}
+
+// upload a fused conv (one or more records concatenated along cout) in the MFMA layout
+static int make_conv(rtmodt_detector *d, WeightFile &wf, const std::vector<std::string> &names, const std::string &op_name,
+                     const TensorView &in, const TensorView &out, const TensorView *res, int cout_pad4) {
+    std::vector<const WeightRec *> rs;
+    for (auto &n : names) {
+        auto it = wf.recs.find(n);
+        RT_CHECK(it != wf.recs.end(), RTMODT_E_IO, "weight file lacks conv %s", n.c_str());
+        rs.push_back(&it->second);
+    }
+    const WeightRec &r0 = *rs[0];
+    int cout = 0;
+    for (auto *r : rs) {
+        RT_CHECK(r->cin == r0.cin && r->k == r0.k && r->stride == r0.stride && r->act == r0.act, RTMODT_E_IO, "cannot fuse %s", r->name.c_str());
+        cout += r->cout;
+    }
+    int cout_eff = cout_pad4 ? (int)align_up(cout, 4) : cout;
+    RT_CHECK(in.c == r0.cin, RTMODT_E_IO, "conv %s: graph expects cin %d, file has %d", op_name.c_str(), in.c, r0.cin);
+    RT_CHECK(out.c == cout_eff, RTMODT_E_IO, "conv %s: graph expects cout %d, file has %d", op_name.c_str(), out.c, cout_eff);
+    int K = r0.k * r0.k * r0.cin, kp = (int)align_up(K, 32), cp = (int)align_up(cout_eff, 128);
+    std::vector<f16> w((size_t)cp * kp, (f16)0.0f);
+    std::vector<float> b(cp, 0.f);
+    int row = 0;
+    for (auto *r : rs) {
+        for (int o = 0; o < r->cout; ++o, ++row) {
+            memcpy(&w[(size_t)row * kp], &r->w[(size_t)o * K], (size_t)K * sizeof(f16));
+            b[row] = r->b[o];
+        }
+    }
+    Op op;
+    op.kind = OP_CONV; op.name = op_name;
+    void *dw, *db;
+    RT_TRY(upload(d, w.data(), w.size() * sizeof(f16), &dw));
+    RT_TRY(upload(d, b.data(), b.size() * sizeof(float), &db));
+    ConvLaunch &c = op.conv;
+    c.in = in; c.out = out; if (res) c.res = *res;
+    c.wt = (const f16 *)dw; c.bias = (const float *)db;
+    c.B = d->B; c.cin = r0.cin; c.cout = cout_eff; c.ks = r0.k; c.stride = r0.stride; c.act = r0.act; c.kp = kp;
+    int M = d->B * out.H * out.W;
+    c.tile = pick_tile(M, cout_eff);
+    op.flops = 2LL * out.H * out.W * cout * K;
+    d->ops.push_back(op);
+    int off = 0;
+    for (auto *r : rs) {
+        TensorView lv = out; lv.coff = out.coff + off; lv.c = r->cout;
+        d->layer_out[r->name] = lv;
+        off += r->cout;
+    }
+    return RTMODT_OK;
+}
+
+static int build_graph(rtmodt_detector *d, WeightFile &wf) {
+    static const double SC[5][3] = {{0.33, 0.25, 1024}, {0.33, 0.50, 1024}, {0.67, 0.75, 768}, {1.00, 1.00, 512}, {1.00, 1.25, 512}};
+    RT_CHECK(d->scale_id >= 0 && d->scale_id < 5, RTMODT_E_IO, "bad model scale id %d", d->scale_id);
+    RT_CHECK(wf.reg_max == 16, RTMODT_E_UNSUPPORTED, "reg_max %d (only 16 built)", wf.reg_max);
+    const double dep = SC[d->scale_id][0], wid = SC[d->scale_id][1], mx = SC[d->scale_id][2];
+    auto ch = [&](int c) { return (int)(std::ceil(std::min((double)c, mx) * wid / 8.0) * 8); };
+    auto rep = [&](int n) { return std::max((int)std::nearbyint(n * dep), 1); };   // Python round(): half-even
+    Builder bld{d, &wf};
+    auto T = [&](int H, int W, int C, int pad) { return bld.T(H, W, C, pad); };
+    auto V = [&](int t, int coff = 0, int c = -1) { return bld.V(t, coff, c); };
+    int rc = RTMODT_OK;
+    auto conv = [&](const std::string &name, const TensorView &in, const TensorView &out, const TensorView *res = nullptr) {
+        if (rc == RTMODT_OK) rc = make_conv(d, wf, {name}, name, in, out, res, 0);
+    };
+    auto c2f = [&](const std::string &i, const TensorView &in, int cout, int n, bool shortcut, const TensorView &out) {
+        int c = cout / 2;
+        int cat = T(in.H, in.W, (2 + n) * c, 1);
+        conv(i + ".cv1", in, V(cat, 0, 2 * c));
+        for (int j = 0; j < n; ++j) {
+            int tmp = T(in.H, in.W, c, 1);
+            std::string m = i + ".m." + std::to_string(j);
+            conv(m + ".cv1", V(cat, (1 + j) * c, c), V(tmp));
+            TensorView r = V(cat, (1 + j) * c, c);
+            conv(m + ".cv2", V(tmp), V(cat, (2 + j) * c, c), shortcut ? &r : nullptr);
+        }
+        conv(i + ".cv2", V(cat, 0, (2 + n) * c), out);
+    };
+
+    const int H = d->in_h, W = d->in_w;
+    const int c1 = ch(64), c2 = ch(128), c3 = ch(256), c4 = ch(512), c5 = ch(1024);
+    d->img_t = T(H, W, 4, 1);
+    int t0 = T(H / 2, W / 2, c1, 1);
+    {   // stem
+        auto it = wf.recs.find("0");
+        RT_CHECK(it != wf.recs.end(), RTMODT_E_IO, "weight file lacks conv 0");
+        const WeightRec &r = it->second;
+        RT_CHECK(r.cin == 3 && r.k == 3 && r.stride == 2 && r.cout == c1, RTMODT_E_IO, "stem conv shape mismatch");
+        std::vector<float> w(27 * (size_t)c1);
+        for (int o = 0; o < c1; ++o)
+            for (int k = 0; k < 27; ++k) w[(size_t)k * c1 + o] = (float)r.w[(size_t)o * 27 + k];
+        void *dw, *db;
+        RT_TRY(upload(d, w.data(), w.size() * 4, &dw));
+        RT_TRY(upload(d, r.b.data(), r.b.size() * 4, &db));
+        Op op; op.kind = OP_STEM; op.name = "0";
+        op.v[0] = V(d->img_t); op.v[1] = V(t0); op.stem_w = (const float *)dw; op.stem_b = (const float *)db;
+        op.flops = 2LL * (H / 2) * (W / 2) * c1 * 27;
+        d->ops.push_back(op);
+        d->layer_out["0"] = V(t0);
+    }
+    int t1 = T(H / 4, W / 4, c2, 1);
+    conv("1", V(t0), V(t1));
+    int t2 = T(H / 4, W / 4, c2, 1);
+    c2f("2", V(t1), c2, rep(3), true, V(t2));
+    int t3 = T(H / 8, W / 8, c3, 1);
+    conv("3", V(t2), V(t3));
+    // neck concat tensors; producers write straight into their slices
+    int cat11 = T(H / 16, W / 16, c5 + c4, 1);
+    int cat14 = T(H / 8, W / 8, c4 + c3, 1);
+    int cat17 = T(H / 16, W / 16, c3 + c4, 1);
+    int cat20 = T(H / 32, W / 32, c4 + c5, 1);
+    TensorView out4 = V(cat14, c4, c3);
+    c2f("4", V(t3), c3, rep(6), true, out4);
+    int t5 = T(H / 16, W / 16, c4, 1);
+    conv("5", out4, V(t5));
+    TensorView out6 = V(cat11, c5, c4);
+    c2f("6", V(t5), c4, rep(6), true, out6);
+    int t7 = T(H / 32, W / 32, c5, 1);
+    conv("7", out6, V(t7));
+    int t8 = T(H / 32, W / 32, c5, 1);
+    c2f("8", V(t7), c5, rep(3), true, V(t8));
+    // SPPF
+    int ch9 = c5 / 2;
+    int cat9 = T(H / 32, W / 32, 4 * ch9, 1);
+    conv("9.cv1", V(t8), V(cat9, 0, ch9));
+    {
+        Op op; op.kind = OP_POOL; op.name = "9.pool";
+        op.v[0] = V(cat9, 0, ch9); op.v[1] = V(cat9, ch9, ch9); op.v[2] = V(cat9, 2 * ch9, ch9); op.v[3] = V(cat9, 3 * ch9, ch9);
+        d->ops.push_back(op);
+    }
+    TensorView out9 = V(cat20, c4, c5);
+    conv("9.cv2", V(cat9), out9);
+    { Op op; op.kind = OP_UP; op.name = "10.up"; op.v[0] = out9; op.v[1] = V(cat11, 0, c5); d->ops.push_back(op); }
+    TensorView out12 = V(cat17, c3, c4);
+    c2f("12", V(cat11), c4, rep(3), false, out12);
+    { Op op; op.kind = OP_UP; op.name = "13.up"; op.v[0] = out12; op.v[1] = V(cat14, 0, c4); d->ops.push_back(op); }
+    int t15 = T(H / 8, W / 8, c3, 1);
+    c2f("15", V(cat14), c3, rep(3), false, V(t15));
+    conv("16", V(t15), V(cat17, 0, c3));
+    int t18 = T(H / 16, W / 16, c4, 1);
+    c2f("18", V(cat17), c4, rep(3), false, V(t18));
+    conv("19", V(t18), V(cat20, 0, c4));
+    int t21 = T(H / 32, W / 32, c5, 1);
+    c2f("21", V(cat20), c5, rep(3), false, V(t21));
+    RT_TRY(rc);
+    // Detect head: the two first 3x3 convs of a level share their input -> one conv, cout = cbox + ccls
+    const int cbox = std::max(16, std::max(c3 / 4, 64)), ccls = std::max(c3, std::min(d->nc, 100));
+    const int nc4 = (int)align_up(d->nc, 4), no = 64 + (int)align_up(d->nc, 8);
+    const int src[3] = {t15, t18, t21};
+    for (int l = 0; l < 3; ++l) {
+        const Tensor &s = d->tensors[src[l]];
+        std::string L = std::to_string(l);
+        int hA = T(s.H, s.W, cbox + ccls, 1);
+        RT_TRY(make_conv(d, wf, {"22.cv2." + L + ".0", "22.cv3." + L + ".0"}, "22.cv2+cv3." + L + ".0", V(src[l]), V(hA), nullptr, 0));
+        int hB2 = T(s.H, s.W, cbox, 0), hB3 = T(s.H, s.W, ccls, 0);
+        RT_TRY(make_conv(d, wf, {"22.cv2." + L + ".1"}, "22.cv2." + L + ".1", V(hA, 0, cbox), V(hB2), nullptr, 0));
+        RT_TRY(make_conv(d, wf, {"22.cv3." + L + ".1"}, "22.cv3." + L + ".1", V(hA, cbox, ccls), V(hB3), nullptr, 0));
+        d->head_t[l] = T(s.H, s.W, no, 0);
+        RT_TRY(make_conv(d, wf, {"22.cv2." + L + ".2"}, "22.cv2." + L + ".2", V(hB2), V(d->head_t[l], 0, 64), nullptr, 0));
+        RT_TRY(make_conv(d, wf, {"22.cv3." + L + ".2"}, "22.cv3." + L + ".2", V(hB3), V(d->head_t[l], 64, nc4), nullptr, 1));
+    }
+    d->n_anchors = 0;
+    for (int l = 0; l < 3; ++l) d->n_anchors += d->tensors[d->head_t[l]].H * d->tensors[d->head_t[l]].W;
+    d->flops_per_frame = 0;
+    for (auto &op : d->ops) d->flops_per_frame += op.flops;
+
+    // one arena for every activation; zeroed once (the zero borders are never written again)
+    d->arena_bytes = bld.arena_used + 4096;
+    RT_HIP(hipMalloc((void **)&d->arena, d->arena_bytes));
+    RT_HIP(hipMemset(d->arena, 0, d->arena_bytes));
+    auto rebase = [&](TensorView &v) { if (v.base || v.c) v.base = (f16 *)(d->arena + (uintptr_t)v.base); };
+    for (auto &t : d->tensors) t.ptr = (f16 *)(d->arena + (uintptr_t)t.ptr);
+    for (auto &op : d->ops) {
+        if (op.kind == OP_CONV) {
+            rebase(op.conv.in); rebase(op.conv.out);
+            if (op.conv.res.c) rebase(op.conv.res);
+        } else {
+            for (auto &v : op.v) if (v.c) rebase(v);
+        }
+    }
+    for (auto &kv : d->layer_out) rebase(kv.second);
+    return RTMODT_OK;
+}
+
+static int run_op(rtmodt_detector *d, const Op &op) {
+    switch (op.kind) {
+        case OP_STEM: return launch_stem(op.v[0], op.v[1], op.stem_w, op.stem_b, d->B, op.v[1].c, d->stream);
+        case OP_CONV: return launch_conv(op.conv, d->stream);
+        case OP_POOL: return launch_sppf_pool(op.v[0], op.v[1], op.v[2], op.v[3], d->B, d->stream);
+        case OP_UP: return launch_upsample2(op.v[0], op.v[1], d->B, d->stream);
+    }
+    return RTMODT_OK;
+}
+
+static int run_decode(rtmodt_detector *d) {
+    DecodeArgs a{};
+    const int strides[3] = {8, 16, 32};
+    for (int l = 0; l < 3; ++l) {
+        const Tensor &t = d->tensors[d->head_t[l]];
+        a.lvl[l] = HeadLevel{t.ptr, t.H, t.W, strides[l]};
+    }
+    a.B = d->B; a.nc = d->nc; a.n_anchors = d->n_anchors; a.conf = d->cfg.conf;
+    a.class_mask[0] = d->class_mask[0]; a.class_mask[1] = d->class_mask[1];
+    a.box = d->d_box; a.score = d->d_score; a.cls = d->d_cls;
+    a.pred = d->want_pred ? d->d_pred : nullptr;
+    return launch_decode(a, d->stream);
+}
+
+static int forward_eager(rtmodt_detector *d) {
+    for (auto &op : d->ops) RT_TRY(run_op(d, op));
+    return run_decode(d);
+}
+
+static int capture_graph(rtmodt_detector *d) {
+    if (d->graph_exec) { hipGraphExecDestroy(d->graph_exec); d->graph_exec = nullptr; }
+    if (d->graph) { hipGraphDestroy(d->graph); d->graph = nullptr; }
+    RT_HIP(hipStreamBeginCapture(d->stream, hipStreamCaptureModeRelaxed));
+    int rc = forward_eager(d);
+    hipError_t e = hipStreamEndCapture(d->stream, &d->graph);
+    RT_TRY(rc);
+    RT_HIP(e);
+    RT_HIP(hipGraphInstantiate(&d->graph_exec, d->graph, nullptr, nullptr, 0));
+    return RTMODT_OK;
+}
+
+static int run_nms(rtmodt_detector *d, const LbHost &g, int h, int w) {
+    NmsArgs a{};
+    a.B = d->B; a.n_anchors = d->n_anchors; a.max_det = d->cfg.max_det; a.agnostic = d->cfg.agnostic; a.iou = d->cfg.iou;
+    a.box = d->d_box; a.score = d->d_score; a.cls = d->d_cls;
+    a.keys = d->d_keys; a.sbox = d->d_sbox; a.sidx = d->d_sidx;
+    a.gain = (float)g.gain; a.pad_x = (float)g.pad_x; a.pad_y = (float)g.pad_y; a.src_w = (float)w; a.src_h = (float)h; a.rescale = 1;
+    a.out_xyxy = d->o_xyxy; a.out_conf = d->o_conf; a.out_cls = d->o_cls; a.out_anchor = d->o_anchor; a.out_n = d->o_n;
+    return launch_nms(a, d->stream);
+}
+
+int detector_outputs(rtmodt_detector *d, DetOutputs *o) {
+    RT_CHECK(d && o, RTMODT_E_INVALID, "null argument");
+    RT_CHECK(d->last_n > 0, RTMODT_E_INVALID, "detector has no enqueued batch");
+    o->box = (const float4 *)d->o_xyxy; o->conf = d->o_conf; o->cls = d->o_cls; o->n = d->o_n;
+    o->stride = d->cfg.max_det; o->count = d->last_n; o->device = d->device; o->stream = d->stream;
+    return RTMODT_OK;
+}
+
+}  // namespace rtmodt
+
+// =====================================================================================
+// C ABI
+// =====================================================================================
+extern "C" {
+
+const char *rtmodt_last_error(void) { return last_error().c_str(); }
+const char *rtmodt_version(void) { return "rtmodt-hip 0.1 (gfx950)"; }
+
+int rtmodt_device_count(int *count) {
+    RT_CHECK(count, RTMODT_E_INVALID, "null argument");
+    RT_HIP(hipGetDeviceCount(count));
+    return RTMODT_OK;
+}
+int rtmodt_synchronize(int device) {
+    RT_HIP(hipSetDevice(device));
+    RT_HIP(hipDeviceSynchronize());
+    return RTMODT_OK;
+}
+int rtmodt_device_alloc(int device, size_t bytes, void **out) {
+    RT_CHECK(out, RTMODT_E_INVALID, "null argument");
+    RT_HIP(hipSetDevice(device));
+    RT_HIP(hipMalloc(out, bytes));
+    return RTMODT_OK;
+}
+int rtmodt_device_free(int device, void *ptr) {
+    RT_HIP(hipSetDevice(device));
+    RT_HIP(hipFree(ptr));
+    return RTMODT_OK;
+}
+int rtmodt_memcpy_h2d(int device, void *dst, const void *src, size_t bytes) {
+    RT_HIP(hipSetDevice(device));
+    RT_HIP(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+    return RTMODT_OK;
+}
+int rtmodt_memcpy_d2h(int device, void *dst, const void *src, size_t bytes) {
+    RT_HIP(hipSetDevice(device));
+    RT_HIP(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+    return RTMODT_OK;
+}
+
+void rtmodt_detector_destroy(rtmodt_detector *d) {
+    if (!d) return;
+    hipSetDevice(d->device);
+    if (d->stream) hipStreamSynchronize(d->stream);
+    if (d->graph_exec) hipGraphExecDestroy(d->graph_exec);
+    if (d->graph) hipGraphDestroy(d->graph);
+    for (void *p : d->dev_allocs) hipFree(p);
+    hipFree(d->arena); hipFree(d->stage); hipFree(d->d_tab);
+    hipFree(d->d_box); hipFree(d->d_score); hipFree(d->d_cls); hipFree(d->d_pred);
+    hipFree(d->d_keys); hipFree(d->d_sbox); hipFree(d->d_sidx);
+    hipFree(d->o_xyxy); hipFree(d->o_conf); hipFree(d->o_cls); hipFree(d->o_anchor); hipFree(d->o_n);
+    hipHostFree(d->h_xyxy); hipHostFree(d->h_conf); hipHostFree(d->h_cls); hipHostFree(d->h_n);
+    if (d->ev0) hipEventDestroy(d->ev0);
+    if (d->ev1) hipEventDestroy(d->ev1);
+    if (d->ev2) hipEventDestroy(d->ev2);
+    if (d->stream) hipStreamDestroy(d->stream);
+    delete d;
+}
+
+static int detector_create_impl(const rtmodt_det_cfg *cfg, rtmodt_detector *d) {
+    d->cfg = *cfg;
+    d->weight_path = cfg->weight_path;
+    d->cfg.weight_path = d->weight_path.c_str();
+    if (cfg->classes && cfg->n_classes > 0) {
+        d->classes.assign(cfg->classes, cfg->classes + cfg->n_classes);
+        d->class_mask[0] = d->class_mask[1] = 0;
+        for (int c : d->classes)
+            if (c >= 0 && c < 128) d->class_mask[c >> 6] |= 1ull << (c & 63);
+    }
+    d->cfg.classes = nullptr;
+    d->device = cfg->device;
+    d->B = cfg->batch; d->in_h = cfg->in_h; d->in_w = cfg->in_w;
+    RT_CHECK(cfg->half == 1, RTMODT_E_UNSUPPORTED, "half=0: this engine stores activations in fp16 only");
+    RT_CHECK(d->B >= 1 && d->B <= 64, RTMODT_E_INVALID, "batch %d out of range [1,64]", d->B);
+    RT_CHECK(d->in_h % 32 == 0 && d->in_w % 32 == 0 && d->in_h >= 32 && d->in_w >= 32 && d->in_h <= 1280 && d->in_w <= 1280,
+             RTMODT_E_INVALID, "input size %dx%d must be a multiple of 32 in [32,1280]", d->in_w, d->in_h);
+    RT_CHECK(cfg->max_det >= 1 && cfg->max_det <= 4096, RTMODT_E_INVALID, "max_det %d out of range [1,4096]", cfg->max_det);
+    WeightFile wf;
+    RT_TRY(read_weight_file(d->weight_path.c_str(), wf));
+    d->scale_id = wf.scale_id; d->nc = wf.nc; d->reg_max = wf.reg_max;
+    RT_CHECK(d->nc >= 1 && d->nc <= 128, RTMODT_E_UNSUPPORTED, "nc %d (1..128 supported)", d->nc);
+    RT_HIP(hipSetDevice(d->device));
+    RT_HIP(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking));
+    RT_HIP(hipEventCreate(&d->ev0)); RT_HIP(hipEventCreate(&d->ev1)); RT_HIP(hipEventCreate(&d->ev2));
+    RT_TRY(build_graph(d, wf));
+
+    int msw = cfg->max_src_w > 0 ? cfg->max_src_w : d->in_w, msh = cfg->max_src_h > 0 ? cfg->max_src_h : d->in_h;
+    d->cfg.max_src_w = msw; d->cfg.max_src_h = msh;
+    d->stage_per = align_up((size_t)msw * msh * 3 + 64, 256);
+    RT_HIP(hipMalloc((void **)&d->stage, d->stage_per * d->B));
+    d->tab_cap = (size_t)(d->in_w + d->in_h) * 3;
+    RT_HIP(hipMalloc((void **)&d->d_tab, d->tab_cap * sizeof(int32_t)));
+
+    size_t BA = (size_t)d->B * d->n_anchors, BD = (size_t)d->B * cfg->max_det;
+    RT_HIP(hipMalloc((void **)&d->d_box, BA * sizeof(float4)));
+    RT_HIP(hipMalloc((void **)&d->d_score, BA * sizeof(float)));
+    RT_HIP(hipMalloc((void **)&d->d_cls, BA * sizeof(int32_t)));
+    RT_HIP(hipMalloc((void **)&d->d_pred, BA * (4 + d->nc) * sizeof(float)));
+    RT_HIP(hipMalloc((void **)&d->d_keys, BA * sizeof(uint64_t)));
+    RT_HIP(hipMalloc((void **)&d->d_sbox, BA * sizeof(float4)));
+    RT_HIP(hipMalloc((void **)&d->d_sidx, BA * sizeof(int32_t)));
+    RT_HIP(hipMalloc((void **)&d->o_xyxy, BD * 4 * sizeof(float)));
+    RT_HIP(hipMalloc((void **)&d->o_conf, BD * sizeof(float)));
+    RT_HIP(hipMalloc((void **)&d->o_cls, BD * sizeof(int32_t)));
+    RT_HIP(hipMalloc((void **)&d->o_anchor, BD * sizeof(int32_t)));
+    RT_HIP(hipMalloc((void **)&d->o_n, d->B * sizeof(int32_t)));
+    RT_HIP(hipMemset(d->o_n, 0, d->B * sizeof(int32_t)));
+    RT_HIP(hipHostMalloc((void **)&d->h_xyxy, BD * 4 * sizeof(float), hipHostMallocDefault));
+    RT_HIP(hipHostMalloc((void **)&d->h_conf, BD * sizeof(float), hipHostMallocDefault));
+    RT_HIP(hipHostMalloc((void **)&d->h_cls, BD * sizeof(int32_t), hipHostMallocDefault));
+    RT_HIP(hipHostMalloc((void **)&d->h_n, d->B * sizeof(int32_t), hipHostMallocDefault));
+
+    // one eager pass (also sets kernel attributes) before capturing the graph
+    RT_TRY(forward_eager(d));
+    RT_HIP(hipStreamSynchronize(d->stream));
+    if (cfg->use_graph) RT_TRY(capture_graph(d));
+    return RTMODT_OK;
+}
+
+int rtmodt_detector_create(const rtmodt_det_cfg *cfg, rtmodt_detector **out) {
+    RT_CHECK(cfg && out && cfg->weight_path, RTMODT_E_INVALID, "null argument");
+    rtmodt_detector *d = new rtmodt_detector();
+    int rc = detector_create_impl(cfg, d);
+    if (rc != RTMODT_OK) {
+        std::string keep = last_error();
+        rtmodt_detector_destroy(d);
+        last_error() = keep;
+        return rc;
+    }
+    *out = d;
+    return RTMODT_OK;
+}
+
+int rtmodt_detector_enqueue_batch(rtmodt_detector *d, const uint8_t *const *frames, int n, int h, int w, int stride_bytes,
+                                  int mem_kind) {
+    RT_CHECK(d && frames, RTMODT_E_INVALID, "null argument");
+    RT_CHECK(n >= 1 && n <= d->B, RTMODT_E_INVALID, "n %d outside [1, batch %d]", n, d->B);
+    RT_CHECK(h >= 1 && w >= 1 && stride_bytes >= w * 3, RTMODT_E_INVALID, "bad frame geometry %dx%d pitch %d", w, h, stride_bytes);
+    RT_HIP(hipSetDevice(d->device));
+    if (mem_kind == RTMODT_MEM_HOST) {
+        RT_CHECK((size_t)h * stride_bytes <= d->stage_per, RTMODT_E_CAPACITY, "frame %dx%d exceeds max_src %dx%d", w, h, d->cfg.max_src_w,
+                 d->cfg.max_src_h);
+        for (int i = 0; i < n; ++i) {
+            RT_HIP(hipMemcpyAsync(d->stage + d->stage_per * i, frames[i], (size_t)h * stride_bytes, hipMemcpyHostToDevice, d->stream));
+            d->fptrs.p[i] = d->stage + d->stage_per * i;
+        }
+    } else {
+        for (int i = 0; i < n; ++i) d->fptrs.p[i] = frames[i];
+    }
+    for (int i = n; i < d->B; ++i) d->fptrs.p[i] = d->fptrs.p[0];
+    LbHost g = letterbox_geometry(h, w, d->in_h, d->in_w);
+    if (g.resize && (h != d->tab_h || w != d->tab_w)) {
+        std::vector<int32_t> xo, x0, x1, yo, y0, y1;
+        build_resize_tables(g.new_w, w, xo, x0, x1);
+        build_resize_tables(g.new_h, h, yo, y0, y1);
+        RT_CHECK((size_t)(g.new_w + g.new_h) * 3 <= d->tab_cap, RTMODT_E_INVALID, "resize table overflow");
+        RT_HIP(hipStreamSynchronize(d->stream));
+        int32_t *p = d->d_tab;
+        const std::vector<int32_t> *src[6] = {&xo, &x0, &x1, &yo, &y0, &y1};
+        const int32_t *dst[6];
+        for (int k = 0; k < 6; ++k) {
+            RT_HIP(hipMemcpy(p, src[k]->data(), src[k]->size() * 4, hipMemcpyHostToDevice));
+            dst[k] = p; p += src[k]->size();
+        }
+        d->tabs = ResizeTables{dst[0], dst[1], dst[2], dst[3], dst[4], dst[5]};
+        d->tab_h = h; d->tab_w = w;
+    }
+    LetterboxGeom lg{h, w, g.new_w, g.new_h, g.top, g.left, g.resize};
+    TensorView img; img.base = d->tensors[d->img_t].ptr; img.H = d->in_h; img.W = d->in_w; img.C = 4; img.pad = 1; img.c = 4;
+    RT_HIP(hipEventRecord(d->ev0, d->stream));
+    RT_TRY(launch_letterbox(d->fptrs, stride_bytes, lg, d->tabs, img, d->B, d->stream));
+    if (d->graph_exec && !d->want_pred) RT_HIP(hipGraphLaunch(d->graph_exec, d->stream));
+    else RT_TRY(forward_eager(d));
+    RT_HIP(hipEventRecord(d->ev1, d->stream));
+    RT_TRY(run_nms(d, g, h, w));
+    RT_HIP(hipEventRecord(d->ev2, d->stream));
+    d->last_n = n; d->last_h = h; d->last_w = w; d->pending = true;
+    return RTMODT_OK;
+}
+
+int rtmodt_detector_fetch(rtmodt_detector *d, float *xyxy, float *conf, int32_t *cls, int32_t *n_out) {
+    RT_CHECK(d && n_out, RTMODT_E_INVALID, "null argument");
+    RT_CHECK(d->last_n > 0, RTMODT_E_INVALID, "fetch before any enqueue_batch");
+    RT_HIP(hipSetDevice(d->device));
+    const int n = d->last_n, md = d->cfg.max_det;
+    RT_HIP(hipMemcpyAsync(d->h_n, d->o_n, n * sizeof(int32_t), hipMemcpyDeviceToHost, d->stream));
+    if (xyxy) RT_HIP(hipMemcpyAsync(d->h_xyxy, d->o_xyxy, (size_t)n * md * 4 * sizeof(float), hipMemcpyDeviceToHost, d->stream));
+    if (conf) RT_HIP(hipMemcpyAsync(d->h_conf, d->o_conf, (size_t)n * md * sizeof(float), hipMemcpyDeviceToHost, d->stream));
+    if (cls) RT_HIP(hipMemcpyAsync(d->h_cls, d->o_cls, (size_t)n * md * sizeof(int32_t), hipMemcpyDeviceToHost, d->stream));
+    RT_HIP(hipStreamSynchronize(d->stream));
+    d->pending = false;
+    memcpy(n_out, d->h_n, n * sizeof(int32_t));
+    if (xyxy) memcpy(xyxy, d->h_xyxy, (size_t)n * md * 4 * sizeof(float));
+    if (conf) memcpy(conf, d->h_conf, (size_t)n * md * sizeof(float));
+    if (cls) memcpy(cls, d->h_cls, (size_t)n * md * sizeof(int32_t));
+    return RTMODT_OK;
+}
+
+int rtmodt_detector_detect_batch(rtmodt_detector *d, const uint8_t *const *frames, int n, int h, int w, int stride_bytes, int mem_kind,
+                                 float *xyxy, float *conf, int32_t *cls, int32_t *n_out) {
+    RT_TRY(rtmodt_detector_enqueue_batch(d, frames, n, h, w, stride_bytes, mem_kind));
+    return rtmodt_detector_fetch(d, xyxy, conf, cls, n_out);
+}
+
+int rtmodt_detector_detect(rtmodt_detector *d, const uint8_t *bgr, int h, int w, int stride_bytes, float *xyxy, float *conf,
+                           int32_t *cls, int32_t *n_out) {
+    const uint8_t *f[1] = {bgr};
+    return rtmodt_detector_detect_batch(d, f, 1, h, w, stride_bytes, RTMODT_MEM_HOST, xyxy, conf, cls, n_out);
+}
+
+int rtmodt_detector_info(rtmodt_detector *d, int32_t *scale_id, int32_t *nc, int32_t *n_anchors, int32_t *n_convs,
+                         int64_t *conv_flops_per_frame, int64_t *arena_bytes) {
+    RT_CHECK(d, RTMODT_E_INVALID, "null argument");
+    if (scale_id) *scale_id = d->scale_id;
+    if (nc) *nc = d->nc;
+    if (n_anchors) *n_anchors = d->n_anchors;
+    if (n_convs) {
+        int c = 0;
+        for (auto &op : d->ops) c += (op.kind == OP_CONV || op.kind == OP_STEM);
+        *n_convs = c;
+    }
+    if (conv_flops_per_frame) *conv_flops_per_frame = d->flops_per_frame;
+    if (arena_bytes) *arena_bytes = (int64_t)d->arena_bytes;
+    return RTMODT_OK;
+}
+
+// dense copy of a channel-slice view of image `img`
+static int fetch_view(rtmodt_detector *d, const TensorView &v, int img, uint16_t *out) {
+    size_t per = (size_t)(v.H + 2 * v.pad) * (v.W + 2 * v.pad) * v.C;
+    std::vector<uint16_t> tmp(per);
+    RT_HIP(hipMemcpy(tmp.data(), v.base + per * img, per * 2, hipMemcpyDeviceToHost));
+    for (int y = 0; y < v.H; ++y)
+        for (int x = 0; x < v.W; ++x)
+            memcpy(out + ((size_t)y * v.W + x) * v.c, &tmp[((size_t)(y + v.pad) * (v.W + 2 * v.pad) + x + v.pad) * v.C + v.coff], (size_t)v.c * 2);
+    return RTMODT_OK;
+}
+
+int rtmodt_detector_debug_fetch(rtmodt_detector *d, int img, uint16_t *input_f16, uint16_t *heads_f16, float *pred) {
+    RT_CHECK(d && img >= 0 && img < d->B, RTMODT_E_INVALID, "bad argument");
+    RT_HIP(hipSetDevice(d->device));
+    RT_HIP(hipStreamSynchronize(d->stream));
+    if (input_f16) {
+        TensorView v; const Tensor &t = d->tensors[d->img_t];
+        v.base = t.ptr; v.H = t.H; v.W = t.W; v.C = 4; v.pad = 1; v.coff = 0; v.c = 3;
+        RT_TRY(fetch_view(d, v, img, input_f16));
+    }
+    if (heads_f16) {
+        uint16_t *o = heads_f16;
+        for (int l = 0; l < 3; ++l) {
+            const Tensor &t = d->tensors[d->head_t[l]];
+            TensorView v; v.base = t.ptr; v.H = t.H; v.W = t.W; v.C = t.C; v.pad = 0; v.coff = 0; v.c = 64 + d->nc;
+            RT_TRY(fetch_view(d, v, img, o));
+            o += (size_t)t.H * t.W * (64 + d->nc);
+        }
+    }
+    if (pred) {
+        // re-run decode with the pred dump enabled (inputs are still resident)
+        d->want_pred = true;
+        int rc = run_decode(d);
+        d->want_pred = false;
+        RT_TRY(rc);
+        RT_HIP(hipStreamSynchronize(d->stream));
+        size_t per = (size_t)(4 + d->nc) * d->n_anchors;
+        RT_HIP(hipMemcpy(pred, d->d_pred + per * img, per * sizeof(float), hipMemcpyDeviceToHost));
+    }
+    return RTMODT_OK;
+}
+
+int rtmodt_detector_debug_layer(rtmodt_detector *d, const char *name, int img, uint16_t *out, int32_t *hwc) {
+    RT_CHECK(d && name && img >= 0 && img < d->B, RTMODT_E_INVALID, "bad argument");
+    auto it = d->layer_out.find(name);
+    RT_CHECK(it != d->layer_out.end(), RTMODT_E_INVALID, "no fused conv named %s", name);
+    const TensorView &v = it->second;
+    if (hwc) { hwc[0] = v.H; hwc[1] = v.W; hwc[2] = v.c; }
+    if (!out) return RTMODT_OK;
+    RT_HIP(hipSetDevice(d->device));
+    RT_HIP(hipStreamSynchronize(d->stream));
+    return fetch_view(d, v, img, out);
+}
+
+int rtmodt_detector_profile(rtmodt_detector *d, int iters, int max_entries, const char **names, float *ms, int64_t *flops,
+                            int32_t *n_entries) {
+    RT_CHECK(d && iters >= 1 && n_entries, RTMODT_E_INVALID, "bad argument");
+    RT_HIP(hipSetDevice(d->device));
+    const int n = (int)d->ops.size() + 1;
+    std::vector<hipEvent_t> ev((size_t)n + 1);
+    for (auto &e : ev) RT_HIP(hipEventCreate(&e));
+    std::vector<double> acc(n, 0.0);
+    for (int it = 0; it < iters; ++it) {
+        RT_HIP(hipEventRecord(ev[0], d->stream));
+        for (int i = 0; i < n - 1; ++i) {
+            RT_TRY(run_op(d, d->ops[i]));
+            RT_HIP(hipEventRecord(ev[i + 1], d->stream));
+        }
+        RT_TRY(run_decode(d));
+        RT_HIP(hipEventRecord(ev[n], d->stream));
+        RT_HIP(hipStreamSynchronize(d->stream));
+        for (int i = 0; i < n; ++i) {
+            float t = 0;
+            RT_HIP(hipEventElapsedTime(&t, ev[i], ev[i + 1]));
+            acc[i] += t;
+        }
+    }
+    for (auto &e : ev) hipEventDestroy(e);
+    d->prof_names.clear();
+    for (auto &op : d->ops) d->prof_names.push_back(op.name);
+    d->prof_names.push_back("decode");
+    *n_entries = n;
+    for (int i = 0; i < n && i < max_entries; ++i) {
+        if (names) names[i] = d->prof_names[i].c_str();
+        if (ms) ms[i] = (float)(acc[i] / iters);
+        if (flops) flops[i] = i < n - 1 ? d->ops[i].flops * d->B : 0;
+    }
+    return RTMODT_OK;
+}
+
+int rtmodt_detector_last_timing(rtmodt_detector *d, float *total_ms, float *forward_ms) {
+    RT_CHECK(d && d->last_n > 0, RTMODT_E_INVALID, "no batch has been enqueued");
+    RT_HIP(hipSetDevice(d->device));
+    RT_HIP(hipEventSynchronize(d->ev2));
+    if (total_ms) RT_HIP(hipEventElapsedTime(total_ms, d->ev0, d->ev2));
+    if (forward_ms) RT_HIP(hipEventElapsedTime(forward_ms, d->ev0, d->ev1));
+    return RTMODT_OK;
+}
+
+// ---- standalone pieces ----------------------------------------------------------------
+int rtmodt_nms_pred(int device, const float *pred, int nc, int A, float conf, float iou, const int32_t *classes, int n_classes,
+                    int agnostic, int max_det, float *xyxy, float *conf_out, int32_t *cls, int32_t *anchor_idx, int32_t *n_out) {
+    RT_CHECK(pred && n_out && nc >= 1 && nc <= 128 && A >= 1 && max_det >= 1 && max_det <= 4096, RTMODT_E_INVALID, "bad argument");
+    RT_HIP(hipSetDevice(device));
+    uint64_t mask[2] = {~0ull, ~0ull};
+    if (classes && n_classes > 0) {
+        mask[0] = mask[1] = 0;
+        for (int i = 0; i < n_classes; ++i)
+            if (classes[i] >= 0 && classes[i] < 128) mask[classes[i] >> 6] |= 1ull << (classes[i] & 63);
+    }
+    struct Bufs {
+        std::vector<void *> p;
+        ~Bufs() { for (void *q : p) hipFree(q); }
+        int get(size_t bytes, void **o) { RT_HIP(hipMalloc(o, bytes)); p.push_back(*o); return RTMODT_OK; }
+    } bufs;
+    float *dpred; float4 *box, *sbox; float *score; int32_t *dcls, *sidx; uint64_t *keys;
+    float *oxy, *ocf; int32_t *ocl, *oan, *on;
+    RT_TRY(bufs.get((size_t)(4 + nc) * A * 4, (void **)&dpred));
+    RT_TRY(bufs.get((size_t)A * 16, (void **)&box)); RT_TRY(bufs.get((size_t)A * 16, (void **)&sbox));
+    RT_TRY(bufs.get((size_t)A * 4, (void **)&score)); RT_TRY(bufs.get((size_t)A * 4, (void **)&dcls));
+    RT_TRY(bufs.get((size_t)A * 4, (void **)&sidx)); RT_TRY(bufs.get((size_t)A * 8, (void **)&keys));
+    RT_TRY(bufs.get((size_t)max_det * 16, (void **)&oxy)); RT_TRY(bufs.get((size_t)max_det * 4, (void **)&ocf));
+    RT_TRY(bufs.get((size_t)max_det * 4, (void **)&ocl)); RT_TRY(bufs.get((size_t)max_det * 4, (void **)&oan));
+    RT_TRY(bufs.get(4, (void **)&on));
+    RT_HIP(hipMemcpy(dpred, pred, (size_t)(4 + nc) * A * 4, hipMemcpyHostToDevice));
+    RT_TRY(launch_pred_candidates(dpred, nc, A, conf, mask, box, score, dcls, nullptr));
+    NmsArgs a{};
+    a.B = 1; a.n_anchors = A; a.max_det = max_det; a.agnostic = agnostic; a.iou = iou;
+    a.box = box; a.score = score; a.cls = dcls; a.keys = keys; a.sbox = sbox; a.sidx = sidx;
+    a.rescale = 0; a.gain = 1.f;
+    a.out_xyxy = oxy; a.out_conf = ocf; a.out_cls = ocl; a.out_anchor = oan; a.out_n = on;
+    RT_TRY(launch_nms(a, nullptr));
+    RT_HIP(hipDeviceSynchronize());
+    int n = 0;
+    RT_HIP(hipMemcpy(&n, on, 4, hipMemcpyDeviceToHost));
+    *n_out = n;
+    if (xyxy) RT_HIP(hipMemcpy(xyxy, oxy, (size_t)n * 16, hipMemcpyDeviceToHost));
+    if (conf_out) RT_HIP(hipMemcpy(conf_out, ocf, (size_t)n * 4, hipMemcpyDeviceToHost));
+    if (cls) RT_HIP(hipMemcpy(cls, ocl, (size_t)n * 4, hipMemcpyDeviceToHost));
+    if (anchor_idx) RT_HIP(hipMemcpy(anchor_idx, oan, (size_t)n * 4, hipMemcpyDeviceToHost));
+    return RTMODT_OK;
+}
+
+int rtmodt_preprocess(int device, const uint8_t *bgr, int h, int w, int stride_bytes, int in_w, int in_h, uint16_t *out_f16) {
+    RT_CHECK(bgr && out_f16 && h >= 1 && w >= 1 && stride_bytes >= 3 * w && in_w >= 1 && in_h >= 1, RTMODT_E_INVALID, "bad argument");
+    RT_HIP(hipSetDevice(device));
+    struct Bufs {
+        std::vector<void *> p;
+        ~Bufs() { for (void *q : p) hipFree(q); }
+        int get(size_t bytes, void **o) { RT_HIP(hipMalloc(o, bytes)); p.push_back(*o); return RTMODT_OK; }
+    } bufs;
+    uint8_t *dimg; f16 *dout; int32_t *dtab;
+    size_t per = (size_t)(in_h + 2) * (in_w + 2) * 4;
+    RT_TRY(bufs.get((size_t)h * stride_bytes, (void **)&dimg));
+    RT_TRY(bufs.get(per * 2, (void **)&dout));
+    RT_HIP(hipMemset(dout, 0, per * 2));
+    RT_HIP(hipMemcpy(dimg, bgr, (size_t)h * stride_bytes, hipMemcpyHostToDevice));
+    FramePtrs fp{};
+    fp.p[0] = dimg;
+    LbHost g = letterbox_geometry(h, w, in_h, in_w);
+    ResizeTables tabs{};
+    if (g.resize) {
+        std::vector<int32_t> t[6];
+        build_resize_tables(g.new_w, w, t[0], t[1], t[2]);
+        build_resize_tables(g.new_h, h, t[3], t[4], t[5]);
+        RT_TRY(bufs.get((size_t)(g.new_w + g.new_h) * 3 * 4, (void **)&dtab));
+        const int32_t *dst[6]; int32_t *p = dtab;
+        for (int k = 0; k < 6; ++k) {
+            RT_HIP(hipMemcpy(p, t[k].data(), t[k].size() * 4, hipMemcpyHostToDevice));
+            dst[k] = p; p += t[k].size();
+        }
+        tabs = ResizeTables{dst[0], dst[1], dst[2], dst[3], dst[4], dst[5]};
+    }
+    LetterboxGeom lg{h, w, g.new_w, g.new_h, g.top, g.left, g.resize};
+    TensorView img; img.base = dout; img.H = in_h; img.W = in_w; img.C = 4; img.pad = 1; img.c = 4;
+    RT_TRY(launch_letterbox(fp, stride_bytes, lg, tabs, img, 1, nullptr));
+    RT_HIP(hipDeviceSynchronize());
+    std::vector<uint16_t> tmp(per);
+    RT_HIP(hipMemcpy(tmp.data(), dout, per * 2, hipMemcpyDeviceToHost));
+    for (int y = 0; y < in_h; ++y)
+        for (int x = 0; x < in_w; ++x)
+            memcpy(out_f16 + ((size_t)y * in_w + x) * 3, &tmp[((size_t)(y + 1) * (in_w + 2) + x + 1) * 4], 6);
+    return RTMODT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,118 @@
+// kernels.h -- host-side launch interface of the hand-written gfx950 kernels.
+#pragma once
+
+#include "common.h"
+
+namespace rtmodt {
+
+// ---------------------------------------------------------------------------------------
+// Activation tensors: fp16 NHWC with an optional 1-pixel zero border,
+//   element (b, y, x, c) at ((b*(H+2*pad) + y + pad)*(W+2*pad) + x + pad)*C + c.
+// The border is zeroed once at arena creation and never written, so a 3x3 conv reads its
+// halo without bounds checks.  A "view" is a channel slice [coff, coff+c) of a tensor --
+// that is how C2f split/concat and the neck concats exist without any copy kernel.
+// ---------------------------------------------------------------------------------------
+struct TensorView {
+    f16 *base = nullptr;   // tensor base (border included), channel offset NOT applied
+    int H = 0, W = 0;      // interior size
+    int C = 0;             // channels of the underlying tensor (pixel stride)
+    int pad = 0;           // border width (0 or 1)
+    int coff = 0, c = 0;   // the slice
+};
+
+// Tile configurations of the implicit-GEMM kernel (conv.hip)
+enum ConvTile { TILE_128x128 = 0, TILE_128x64 = 1, TILE_64x64 = 2, TILE_256x32 = 3, TILE_64x128 = 4, TILE_COUNT = 5 };
+struct TileShape { int bm, bn; };
+TileShape tile_shape(int tile);
+
+struct ConvLaunch {
+    TensorView in, out, res;      // res.base == nullptr -> no residual
+    const f16 *wt = nullptr;      // [cout_pad][kp] fp16, K order (kh, kw, cin), zero padded
+    const float *bias = nullptr;  // [cout_pad]
+    int B = 1;
+    int cin = 0, cout = 0, ks = 1, stride = 1, act = 1;
+    int kp = 0;                   // weight row stride (K rounded up to 32)
+    int tile = TILE_128x128;
+};
+
+int launch_conv(const ConvLaunch &c, hipStream_t s);
+
+// stem: 3x3 stride-2 conv on the 4-channel (RGB0) padded fp16 image, cout in {16,32,48,64,80}
+int launch_stem(const TensorView &img4, const TensorView &out, const float *w27xc, const float *bias, int B,
+                int cout, hipStream_t s);
+// SPPF: y -> (max5(y), max5(max5(y)), max5^3(y)) written to three channel slices of the same tensor
+int launch_sppf_pool(const TensorView &y, const TensorView &p1, const TensorView &p2, const TensorView &p3, int B,
+                     hipStream_t s);
+// nearest 2x upsample of a view into a channel slice of a tensor twice the size
+int launch_upsample2(const TensorView &in, const TensorView &out, int B, hipStream_t s);
+
+// ---------------------------------------------------------------------------------------
+// preprocess (preprocess.hip)
+// ---------------------------------------------------------------------------------------
+struct ResizeTables {          // device arrays, cv::resize INTER_LINEAR fixed-point tables
+    const int32_t *xofs, *xa0, *xa1, *yofs, *yb0, *yb1;
+};
+struct LetterboxGeom { int src_h, src_w, new_w, new_h, top, left, resize; };
+// frames: up to 64 device pointers to BGR uint8 images with row pitch `pitch`, passed by value in
+// the kernel arguments (no pointer table to upload, nothing to race with launch-ahead)
+struct FramePtrs { const uint8_t *p[64]; };
+int launch_letterbox(const FramePtrs &frames, int pitch, const LetterboxGeom &g, const ResizeTables &t,
+                     const TensorView &img4, int B, hipStream_t s);
+
+// ---------------------------------------------------------------------------------------
+// postprocess (postprocess.hip)
+// ---------------------------------------------------------------------------------------
+struct HeadLevel { const f16 *ptr; int H, W, stride; };   // [B][H][W][64+nc] fp16, no border
+struct DecodeArgs {
+    HeadLevel lvl[3];
+    int B, nc, n_anchors;
+    float conf;
+    uint64_t class_mask[2];    // allowed classes (bit per class id < 128)
+    // per-anchor dense outputs [B][A]
+    float4 *box;               // xyxy in network-input pixels
+    float *score;              // best class score, or -1 when not a candidate
+    int32_t *cls;
+    float *pred;               // optional full (4+nc) x A tensor per image (debug / parity), or nullptr
+};
+int launch_decode(const DecodeArgs &a, hipStream_t s);
+
+struct NmsArgs {
+    int B, n_anchors, max_det, agnostic;
+    float iou;
+    const float4 *box; const float *score; const int32_t *cls;     // dense per-anchor, [B][A]
+    // scratch [B][A]
+    uint64_t *keys; float4 *sbox; int32_t *sidx;
+    // rescale to the source frame (scale_boxes): x = (x - pad_x)/gain clipped to [0, src]
+    float gain, pad_x, pad_y, src_w, src_h; int rescale;
+    // outputs [B][max_det]
+    float *out_xyxy; float *out_conf; int32_t *out_cls; int32_t *out_anchor; int32_t *out_n;
+};
+int launch_nms(const NmsArgs &a, hipStream_t s);
+// pred[(4+nc)][A] float32 -> dense per-anchor candidates (what decode emits), for rtmodt_nms_pred
+int launch_pred_candidates(const float *pred, int nc, int n_anchors, float conf, const uint64_t class_mask[2],
+                           float4 *box, float *score, int32_t *cls, hipStream_t s);
+
+// ---------------------------------------------------------------------------------------
+// tracker (tracker.hip)
+// ---------------------------------------------------------------------------------------
+struct TrackerState {          // one stream; device pointers; double-buffered (cur = buffer index)
+    int64_t *ids[2]; float4 *box[2]; float *conf[2]; int32_t *cls[2]; int32_t *age[2]; int32_t *tsu[2];
+};
+struct TrackerArgs {
+    int n_streams, stream_base, max_tracks, max_dets;   // grid = n_streams workgroups, stream index = stream_base + blockIdx.x
+    float track_thresh, match_thresh; int track_buffer;
+    TrackerState *states;      // device array [n_streams]
+    int64_t *meta;             // device [n_streams][8]: {cur, n_tracks, err, n_active, next_id, 0, 0, 0}
+    // detections: [n_streams][det_stride] boxes / conf / cls ; counts [n_streams]
+    const float4 *det_box; const float *det_conf; const int32_t *det_cls; const int32_t *det_n; int det_stride;
+};
+int launch_tracker_update(const TrackerArgs &a, hipStream_t s);
+int launch_iou_matrix(const float4 *a, int m, const float4 *b, int n, float *out, hipStream_t s);
+int launch_assign_greedy(const float *iou, int m, int n, float thresh, int32_t *row_to_col, int32_t *col_used,
+                         hipStream_t s);
+
+// device-resident results of a detector's last enqueue_batch (engine.hip), consumed by the tracker
+struct DetOutputs { const float4 *box; const float *conf; const int32_t *cls; const int32_t *n; int stride, count, device; hipStream_t stream; };
+int detector_outputs(rtmodt_detector *det, DetOutputs *out);
+
+}  // namespace rtmodt

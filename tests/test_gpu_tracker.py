@@ -1,0 +1,126 @@
+"""GPU: the single-launch HIP tracker against the golden fixtures (produced by the
+reference's tracker.py) and the pinned oracle.  Everything goes through the C ABI."""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+from oracle import tracker_oracle as T
+from conftest import GOLDEN, unpack_frames
+
+pytestmark = pytest.mark.gpu
+KEYS = ("ids", "xyxy", "conf", "cls", "age", "tsu")
+
+
+def bits(a):
+    a = np.ascontiguousarray(a)
+    return a.view(np.int32) if a.dtype == np.float32 else a
+
+
+def test_iou_matrix_bit_exact_g1(pkg):
+    z = np.load(os.path.join(GOLDEN, "tracker_g1_iou.npz"))
+    got = pkg._ffi.iou_matrix(z["a"], z["b"])
+    assert np.array_equal(got.view(np.int32), z["iou"].view(np.int32))
+
+
+def test_greedy_assignment_g2(pkg):
+    z = np.load(os.path.join(GOLDEN, "tracker_g2_assign.npz"))
+    for name in z["names"]:
+        mr, mc, ur, uc = pkg._ffi.assign_greedy(z[f"{name}_cost"], 0.8)
+        assert mr == z[f"{name}_mr"].tolist(), name
+        assert mc == z[f"{name}_mc"].tolist(), name
+        assert ur == z[f"{name}_ur"].tolist(), name
+        assert uc == z[f"{name}_uc"].tolist(), name
+
+
+def run_sequence(pkg, z, frames, **params):
+    trk = pkg.MultiObjectTracker("bytetrack", **params)
+    for f, (b, c, k) in enumerate(frames):
+        out = trk.update(pkg.Detections(b, c, k))
+        assert out == []                                     # reference facade returns [] every frame
+        s = trk._core.snapshot()
+        assert len(s["ids"]) == z["n_tracks"][f], f"frame {f}"
+        assert s["next_id"] == z["next_id"][f], f"frame {f}"
+        assert np.array_equal(T.state_digest(s), z["digest"][f]), f"frame {f}"
+        if f"f{f:04d}_ids" in z:
+            for key in KEYS:
+                assert np.array_equal(bits(s[key]), bits(z[f"f{f:04d}_{key}"])), (f, key)
+    return trk
+
+
+@pytest.mark.parametrize("name,params", [
+    ("tracker_g3_lifecycle.npz", {}),
+    ("tracker_g3c_expiry.npz", {}),
+    ("tracker_g3b_params.npz", {"bytetrack": {"track_thresh": 0.6, "track_buffer": 5, "match_thresh": 0.7, "mot20": False}}),
+    ("tracker_g7_ragged.npz", {}),
+])
+def test_fixture_sequences(pkg, name, params):
+    z = np.load(os.path.join(GOLDEN, name))
+    trk = run_sequence(pkg, z, unpack_frames(z), **params)
+    # reference attribute names work
+    assert trk._core._next_id == z["next_id"][-1]
+    assert [t["track_id"] for t in trk._core._tracks] == z["f%04d_ids" % (len(z["n_tracks"]) - 1)].tolist()
+
+
+@pytest.mark.parametrize("name", ["tracker_g5_seq200.npz", "tracker_g6_seq500.npz"])
+def test_baseline_sequences(pkg, name):
+    """BASELINE configs 3 and 5: 200 boxes @640^2 x120 frames, 500 boxes @1280^2 x60 frames."""
+    z = np.load(os.path.join(GOLDEN, name))
+    xy, cf, cl = pkg.synth.box_sequence(int(z["seq_n"]), int(z["seq_canvas"]), int(z["seq_frames"]), int(z["seq_seed"]))
+    sha = hashlib.sha256(xy.tobytes() + cf.tobytes() + cl.tobytes()).digest()
+    assert np.array_equal(np.frombuffer(sha, dtype=np.uint8), z["in_sha"])
+    run_sequence(pkg, z, [(xy[f], cf, cl) for f in range(xy.shape[0])])
+
+
+def test_multi_stream_batch_equals_oracle(pkg):
+    """8 independent streams advanced by ONE launch each frame (BASELINE config 4 shape)."""
+    from importlib import import_module
+    core_cls = import_module(pkg.__name__ + ".tracking.tracker")._ByteTrackCore
+    S, N = 8, 256
+    core = core_cls(n_streams=S, max_dets=N, max_tracks=1024)
+    oracles = [T.TrackerOracle() for _ in range(S)]
+    seqs = [pkg.synth.box_sequence(40 + 25 * s, 640, 30, seed=100 + s) for s in range(S)]
+    for f in range(30):
+        xy = np.zeros((S, N, 4), np.float32); cf = np.zeros((S, N), np.float32); cl = np.zeros((S, N), np.int32)
+        cnt = np.zeros(S, np.int32)
+        for s, (b, c, k) in enumerate(seqs):
+            n = 0 if (f + s) % 11 == 0 else b.shape[1]        # some empty frames
+            cnt[s] = n
+            xy[s, :n], cf[s, :n], cl[s, :n] = b[f][:n], c[:n], k[:n]
+            oracles[s].update(b[f][:n], c[:n], k[:n])
+        act = core.update_batch(xy, cf, cl, cnt)
+        assert act.tolist() == [0] * S
+        for s in range(S):
+            assert np.array_equal(T.state_digest(core.snapshot(s)), T.state_digest(oracles[s].snapshot())), (f, s)
+
+
+def test_matched_report_and_trails(pkg):
+    trk = pkg.MultiObjectTracker("bytetrack")
+    trk.report = "matched"
+    xy, cf, cl = pkg.synth.box_sequence(10, 320, 40, seed=2)
+    cf[:] = 0.9
+    for f in range(40):
+        out = trk.update(pkg.Detections(xy[f], cf, cl))
+    assert len(out) > 0 and all(t.time_since_update == 1 for t in out)
+    assert max(len(t.trail) for t in out) == 30                # trail capped at 30 points (tracker.py:219,247)
+    t = out[0]
+    assert t.trail[-1] == (int((t.xyxy[0] + t.xyxy[2]) / 2), int((t.xyxy[1] + t.xyxy[3]) / 2))
+
+
+def test_capacity_errors(pkg):
+    from importlib import import_module
+    core_cls = import_module(pkg.__name__ + ".tracking.tracker")._ByteTrackCore
+    core = core_cls(max_tracks=8, max_dets=16)
+    xy, cf, cl = pkg.synth.box_sequence(12, 320, 1, seed=1)
+    cf[:] = 0.9
+    with pytest.raises(pkg._ffi.RtmodtError) as e:
+        core.update(xy[0], cf, cl)
+    assert e.value.code == pkg._ffi.E_CAPACITY
+    core2 = core_cls(max_tracks=64, max_dets=4)
+    with pytest.raises(pkg._ffi.RtmodtError) as e:
+        core2.update(xy[0], cf, cl)
+    assert e.value.code == pkg._ffi.E_CAPACITY
+    with pytest.raises(pkg._ffi.RtmodtError) as e:
+        core_cls(assign_mode=pkg._ffi.ASSIGN_LAPJV)
+    assert e.value.code == pkg._ffi.E_UNSUPPORTED
