@@ -64,6 +64,7 @@ typedef struct rtmodt_det_cfg {
     int32_t batch;             /* frames per detect_batch call (streams batched on this GPU), >= 1         */
     int32_t max_src_w, max_src_h; /* largest source frame accepted (staging), 0 = in_w/in_h                */
     int32_t use_graph;         /* 1: replay the forward pass as one captured hipGraph                      */
+    int32_t autotune;          /* 1: time every conv tile configuration at create and keep the fastest      */
 } rtmodt_det_cfg;
 
 int rtmodt_detector_create(const rtmodt_det_cfg *cfg, rtmodt_detector **out);
@@ -84,7 +85,9 @@ int rtmodt_detector_detect_batch(rtmodt_detector *det, const uint8_t *const *fra
 
 /* Asynchronous halves of detect_batch for the throughput path: enqueue leaves the
  * detections on the device (consumable by rtmodt_tracker_update_from_detector on the same
- * HIP stream, no host round trip); fetch synchronises and copies them out. */
+ * HIP stream, no host round trip) and starts their copy to pinned host memory; fetch waits
+ * for the OLDEST batch in flight and hands it out.  Up to two batches may be in flight
+ * (enqueue t+1, then fetch t), which hides the host's per-step work behind the GPU. */
 int rtmodt_detector_enqueue_batch(rtmodt_detector *det, const uint8_t *const *frames, int n, int h, int w,
                                   int stride_bytes, int mem_kind);
 int rtmodt_detector_fetch(rtmodt_detector *det, float *xyxy, float *conf, int32_t *cls, int32_t *n_out);
@@ -103,8 +106,8 @@ int rtmodt_detector_debug_layer(rtmodt_detector *det, const char *name, int img,
  * events on the detector's stream: names[i] points into handle-owned storage. */
 int rtmodt_detector_profile(rtmodt_detector *det, int iters, int max_entries, const char **names, float *ms,
                             int64_t *flops, int32_t *n_entries);
-/* Device time (ms, HIP events on the detector's stream) of the last enqueue_batch: whole
- * pass, and the forward-graph part alone. */
+/* Device time (ms, HIP events on the detector's stream) of the batch the last fetch returned:
+ * whole pass, and the letterbox + forward-graph part alone. */
 int rtmodt_detector_last_timing(rtmodt_detector *det, float *total_ms, float *forward_ms);
 
 /* decode-free NMS on a caller-supplied pre-NMS tensor pred[(4+nc)*A] float32 (the layout

@@ -159,15 +159,22 @@ struct rtmodt_detector {
     // postprocess
     float4 *d_box = nullptr; float *d_score = nullptr; int32_t *d_cls = nullptr; float *d_pred = nullptr;
     uint64_t *d_keys = nullptr; float4 *d_sbox = nullptr; int32_t *d_sidx = nullptr;
-    float *o_xyxy = nullptr, *o_conf = nullptr; int32_t *o_cls = nullptr, *o_anchor = nullptr, *o_n = nullptr;
-    float *h_xyxy = nullptr, *h_conf = nullptr; int32_t *h_cls = nullptr, *h_n = nullptr;   // pinned
+    // results: a ring of RING_SLOTS batches may be in flight (enqueue t+1 before fetching t)
+    struct Slot {
+        float *o_xyxy = nullptr, *o_conf = nullptr; int32_t *o_cls = nullptr, *o_anchor = nullptr, *o_n = nullptr;   // device
+        float *h_xyxy = nullptr, *h_conf = nullptr; int32_t *h_cls = nullptr, *h_n = nullptr;                        // pinned host
+        hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, done = nullptr;
+        int n = 0;
+    };
+    static constexpr int RING_SLOTS = 2;
+    Slot slots[RING_SLOTS];
+    int head = 0, n_pending = 0;          // next slot to fill; batches enqueued but not fetched
+    int newest = -1, last_fetched = -1;
     uint64_t class_mask[2] = {~0ull, ~0ull};
     // graph
     hipGraph_t graph = nullptr; hipGraphExec_t graph_exec = nullptr;
     bool want_pred = false;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
-    int last_n = 0, last_h = 0, last_w = 0;
-    bool pending = false;
+    int last_h = 0, last_w = 0;
     // profile storage
     std::vector<std::string> prof_names;
 };
@@ -440,6 +447,40 @@ static int forward_eager(rtmodt_detector *d) {
     return run_decode(d);
 }
 
+// Times every tile configuration of every MFMA conv on the device it will run on (HIP events,
+// best of a few launches) and keeps the fastest: the GEMM shapes of this net are small and
+// skinny, so the best tile depends on how M x N fills 256 CUs, not on a rule.
+static int autotune_tiles(rtmodt_detector *d) {
+    hipEvent_t e0, e1;
+    RT_HIP(hipEventCreate(&e0)); RT_HIP(hipEventCreate(&e1));
+    for (auto &op : d->ops) {
+        if (op.kind != OP_CONV) continue;
+        float best = 1e30f;
+        int best_tile = op.conv.tile;
+        for (int t = 0; t < TILE_COUNT; ++t) {
+            op.conv.tile = t;
+            for (int w = 0; w < 2; ++w) RT_TRY(launch_conv(op.conv, d->stream));
+            float ms_min = 1e30f;
+            for (int rep = 0; rep < 3; ++rep) {
+                RT_HIP(hipEventRecord(e0, d->stream));
+                for (int k = 0; k < 4; ++k) RT_TRY(launch_conv(op.conv, d->stream));
+                RT_HIP(hipEventRecord(e1, d->stream));
+                RT_HIP(hipEventSynchronize(e1));
+                float ms = 0;
+                RT_HIP(hipEventElapsedTime(&ms, e0, e1));
+                ms_min = std::min(ms_min, ms);
+            }
+            if (ms_min < best) { best = ms_min; best_tile = t; }
+        }
+        op.conv.tile = best_tile;
+    }
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    // the tuning launches left garbage-free but stale activations; run one clean pass
+    RT_TRY(forward_eager(d));
+    RT_HIP(hipStreamSynchronize(d->stream));
+    return RTMODT_OK;
+}
+
 static int capture_graph(rtmodt_detector *d) {
     if (d->graph_exec) { hipGraphExecDestroy(d->graph_exec); d->graph_exec = nullptr; }
     if (d->graph) { hipGraphDestroy(d->graph); d->graph = nullptr; }
@@ -452,21 +493,22 @@ static int capture_graph(rtmodt_detector *d) {
     return RTMODT_OK;
 }
 
-static int run_nms(rtmodt_detector *d, const LbHost &g, int h, int w) {
+static int run_nms(rtmodt_detector *d, const LbHost &g, int h, int w, rtmodt_detector::Slot &sl) {
     NmsArgs a{};
     a.B = d->B; a.n_anchors = d->n_anchors; a.max_det = d->cfg.max_det; a.agnostic = d->cfg.agnostic; a.iou = d->cfg.iou;
     a.box = d->d_box; a.score = d->d_score; a.cls = d->d_cls;
     a.keys = d->d_keys; a.sbox = d->d_sbox; a.sidx = d->d_sidx;
     a.gain = (float)g.gain; a.pad_x = (float)g.pad_x; a.pad_y = (float)g.pad_y; a.src_w = (float)w; a.src_h = (float)h; a.rescale = 1;
-    a.out_xyxy = d->o_xyxy; a.out_conf = d->o_conf; a.out_cls = d->o_cls; a.out_anchor = d->o_anchor; a.out_n = d->o_n;
+    a.out_xyxy = sl.o_xyxy; a.out_conf = sl.o_conf; a.out_cls = sl.o_cls; a.out_anchor = sl.o_anchor; a.out_n = sl.o_n;
     return launch_nms(a, d->stream);
 }
 
 int detector_outputs(rtmodt_detector *d, DetOutputs *o) {
     RT_CHECK(d && o, RTMODT_E_INVALID, "null argument");
-    RT_CHECK(d->last_n > 0, RTMODT_E_INVALID, "detector has no enqueued batch");
-    o->box = (const float4 *)d->o_xyxy; o->conf = d->o_conf; o->cls = d->o_cls; o->n = d->o_n;
-    o->stride = d->cfg.max_det; o->count = d->last_n; o->device = d->device; o->stream = d->stream;
+    RT_CHECK(d->newest >= 0, RTMODT_E_INVALID, "detector has no enqueued batch");
+    const rtmodt_detector::Slot &sl = d->slots[d->newest];
+    o->box = (const float4 *)sl.o_xyxy; o->conf = sl.o_conf; o->cls = sl.o_cls; o->n = sl.o_n;
+    o->stride = d->cfg.max_det; o->count = sl.n; o->device = d->device; o->stream = d->stream;
     return RTMODT_OK;
 }
 
@@ -522,11 +564,11 @@ void rtmodt_detector_destroy(rtmodt_detector *d) {
     hipFree(d->arena); hipFree(d->stage); hipFree(d->d_tab);
     hipFree(d->d_box); hipFree(d->d_score); hipFree(d->d_cls); hipFree(d->d_pred);
     hipFree(d->d_keys); hipFree(d->d_sbox); hipFree(d->d_sidx);
-    hipFree(d->o_xyxy); hipFree(d->o_conf); hipFree(d->o_cls); hipFree(d->o_anchor); hipFree(d->o_n);
-    hipHostFree(d->h_xyxy); hipHostFree(d->h_conf); hipHostFree(d->h_cls); hipHostFree(d->h_n);
-    if (d->ev0) hipEventDestroy(d->ev0);
-    if (d->ev1) hipEventDestroy(d->ev1);
-    if (d->ev2) hipEventDestroy(d->ev2);
+    for (auto &sl : d->slots) {
+        hipFree(sl.o_xyxy); hipFree(sl.o_conf); hipFree(sl.o_cls); hipFree(sl.o_anchor); hipFree(sl.o_n);
+        hipHostFree(sl.h_xyxy); hipHostFree(sl.h_conf); hipHostFree(sl.h_cls); hipHostFree(sl.h_n);
+        for (hipEvent_t e : {sl.ev0, sl.ev1, sl.ev2, sl.done}) if (e) hipEventDestroy(e);
+    }
     if (d->stream) hipStreamDestroy(d->stream);
     delete d;
 }
@@ -555,7 +597,6 @@ static int detector_create_impl(const rtmodt_det_cfg *cfg, rtmodt_detector *d) {
     RT_CHECK(d->nc >= 1 && d->nc <= 128, RTMODT_E_UNSUPPORTED, "nc %d (1..128 supported)", d->nc);
     RT_HIP(hipSetDevice(d->device));
     RT_HIP(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking));
-    RT_HIP(hipEventCreate(&d->ev0)); RT_HIP(hipEventCreate(&d->ev1)); RT_HIP(hipEventCreate(&d->ev2));
     RT_TRY(build_graph(d, wf));
 
     int msw = cfg->max_src_w > 0 ? cfg->max_src_w : d->in_w, msh = cfg->max_src_h > 0 ? cfg->max_src_h : d->in_h;
@@ -573,20 +614,25 @@ static int detector_create_impl(const rtmodt_det_cfg *cfg, rtmodt_detector *d) {
     RT_HIP(hipMalloc((void **)&d->d_keys, BA * sizeof(uint64_t)));
     RT_HIP(hipMalloc((void **)&d->d_sbox, BA * sizeof(float4)));
     RT_HIP(hipMalloc((void **)&d->d_sidx, BA * sizeof(int32_t)));
-    RT_HIP(hipMalloc((void **)&d->o_xyxy, BD * 4 * sizeof(float)));
-    RT_HIP(hipMalloc((void **)&d->o_conf, BD * sizeof(float)));
-    RT_HIP(hipMalloc((void **)&d->o_cls, BD * sizeof(int32_t)));
-    RT_HIP(hipMalloc((void **)&d->o_anchor, BD * sizeof(int32_t)));
-    RT_HIP(hipMalloc((void **)&d->o_n, d->B * sizeof(int32_t)));
-    RT_HIP(hipMemset(d->o_n, 0, d->B * sizeof(int32_t)));
-    RT_HIP(hipHostMalloc((void **)&d->h_xyxy, BD * 4 * sizeof(float), hipHostMallocDefault));
-    RT_HIP(hipHostMalloc((void **)&d->h_conf, BD * sizeof(float), hipHostMallocDefault));
-    RT_HIP(hipHostMalloc((void **)&d->h_cls, BD * sizeof(int32_t), hipHostMallocDefault));
-    RT_HIP(hipHostMalloc((void **)&d->h_n, d->B * sizeof(int32_t), hipHostMallocDefault));
+    for (auto &sl : d->slots) {
+        RT_HIP(hipMalloc((void **)&sl.o_xyxy, BD * 4 * sizeof(float)));
+        RT_HIP(hipMalloc((void **)&sl.o_conf, BD * sizeof(float)));
+        RT_HIP(hipMalloc((void **)&sl.o_cls, BD * sizeof(int32_t)));
+        RT_HIP(hipMalloc((void **)&sl.o_anchor, BD * sizeof(int32_t)));
+        RT_HIP(hipMalloc((void **)&sl.o_n, d->B * sizeof(int32_t)));
+        RT_HIP(hipMemset(sl.o_n, 0, d->B * sizeof(int32_t)));
+        RT_HIP(hipHostMalloc((void **)&sl.h_xyxy, BD * 4 * sizeof(float), hipHostMallocDefault));
+        RT_HIP(hipHostMalloc((void **)&sl.h_conf, BD * sizeof(float), hipHostMallocDefault));
+        RT_HIP(hipHostMalloc((void **)&sl.h_cls, BD * sizeof(int32_t), hipHostMallocDefault));
+        RT_HIP(hipHostMalloc((void **)&sl.h_n, d->B * sizeof(int32_t), hipHostMallocDefault));
+        RT_HIP(hipEventCreate(&sl.ev0)); RT_HIP(hipEventCreate(&sl.ev1)); RT_HIP(hipEventCreate(&sl.ev2));
+        RT_HIP(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+    }
 
     // one eager pass (also sets kernel attributes) before capturing the graph
     RT_TRY(forward_eager(d));
     RT_HIP(hipStreamSynchronize(d->stream));
+    if (cfg->autotune) RT_TRY(autotune_tiles(d));
     if (cfg->use_graph) RT_TRY(capture_graph(d));
     return RTMODT_OK;
 }
@@ -610,7 +656,10 @@ int rtmodt_detector_enqueue_batch(rtmodt_detector *d, const uint8_t *const *fram
     RT_CHECK(d && frames, RTMODT_E_INVALID, "null argument");
     RT_CHECK(n >= 1 && n <= d->B, RTMODT_E_INVALID, "n %d outside [1, batch %d]", n, d->B);
     RT_CHECK(h >= 1 && w >= 1 && stride_bytes >= w * 3, RTMODT_E_INVALID, "bad frame geometry %dx%d pitch %d", w, h, stride_bytes);
+    RT_CHECK(d->n_pending < rtmodt_detector::RING_SLOTS, RTMODT_E_CAPACITY, "%d batches already in flight: fetch before enqueueing more",
+             d->n_pending);
     RT_HIP(hipSetDevice(d->device));
+    rtmodt_detector::Slot &sl = d->slots[d->head];
     if (mem_kind == RTMODT_MEM_HOST) {
         RT_CHECK((size_t)h * stride_bytes <= d->stage_per, RTMODT_E_CAPACITY, "frame %dx%d exceeds max_src %dx%d", w, h, d->cfg.max_src_w,
                  d->cfg.max_src_h);
@@ -641,37 +690,48 @@ int rtmodt_detector_enqueue_batch(rtmodt_detector *d, const uint8_t *const *fram
     }
     LetterboxGeom lg{h, w, g.new_w, g.new_h, g.top, g.left, g.resize};
     TensorView img; img.base = d->tensors[d->img_t].ptr; img.H = d->in_h; img.W = d->in_w; img.C = 4; img.pad = 1; img.c = 4;
-    RT_HIP(hipEventRecord(d->ev0, d->stream));
+    RT_HIP(hipEventRecord(sl.ev0, d->stream));
     RT_TRY(launch_letterbox(d->fptrs, stride_bytes, lg, d->tabs, img, d->B, d->stream));
     if (d->graph_exec && !d->want_pred) RT_HIP(hipGraphLaunch(d->graph_exec, d->stream));
     else RT_TRY(forward_eager(d));
-    RT_HIP(hipEventRecord(d->ev1, d->stream));
-    RT_TRY(run_nms(d, g, h, w));
-    RT_HIP(hipEventRecord(d->ev2, d->stream));
-    d->last_n = n; d->last_h = h; d->last_w = w; d->pending = true;
+    RT_HIP(hipEventRecord(sl.ev1, d->stream));
+    RT_TRY(run_nms(d, g, h, w, sl));
+    RT_HIP(hipEventRecord(sl.ev2, d->stream));
+    // results travel to pinned host memory right behind the kernels; fetch() only waits for `done`
+    const int md = d->cfg.max_det;
+    RT_HIP(hipMemcpyAsync(sl.h_n, sl.o_n, n * sizeof(int32_t), hipMemcpyDeviceToHost, d->stream));
+    RT_HIP(hipMemcpyAsync(sl.h_xyxy, sl.o_xyxy, (size_t)n * md * 4 * sizeof(float), hipMemcpyDeviceToHost, d->stream));
+    RT_HIP(hipMemcpyAsync(sl.h_conf, sl.o_conf, (size_t)n * md * sizeof(float), hipMemcpyDeviceToHost, d->stream));
+    RT_HIP(hipMemcpyAsync(sl.h_cls, sl.o_cls, (size_t)n * md * sizeof(int32_t), hipMemcpyDeviceToHost, d->stream));
+    RT_HIP(hipEventRecord(sl.done, d->stream));
+    sl.n = n;
+    d->newest = d->head;
+    d->head = (d->head + 1) % rtmodt_detector::RING_SLOTS;
+    d->n_pending += 1;
+    d->last_h = h; d->last_w = w;
     return RTMODT_OK;
 }
 
 int rtmodt_detector_fetch(rtmodt_detector *d, float *xyxy, float *conf, int32_t *cls, int32_t *n_out) {
     RT_CHECK(d && n_out, RTMODT_E_INVALID, "null argument");
-    RT_CHECK(d->last_n > 0, RTMODT_E_INVALID, "fetch before any enqueue_batch");
+    RT_CHECK(d->n_pending > 0, RTMODT_E_INVALID, "fetch without a pending enqueue_batch");
     RT_HIP(hipSetDevice(d->device));
-    const int n = d->last_n, md = d->cfg.max_det;
-    RT_HIP(hipMemcpyAsync(d->h_n, d->o_n, n * sizeof(int32_t), hipMemcpyDeviceToHost, d->stream));
-    if (xyxy) RT_HIP(hipMemcpyAsync(d->h_xyxy, d->o_xyxy, (size_t)n * md * 4 * sizeof(float), hipMemcpyDeviceToHost, d->stream));
-    if (conf) RT_HIP(hipMemcpyAsync(d->h_conf, d->o_conf, (size_t)n * md * sizeof(float), hipMemcpyDeviceToHost, d->stream));
-    if (cls) RT_HIP(hipMemcpyAsync(d->h_cls, d->o_cls, (size_t)n * md * sizeof(int32_t), hipMemcpyDeviceToHost, d->stream));
-    RT_HIP(hipStreamSynchronize(d->stream));
-    d->pending = false;
-    memcpy(n_out, d->h_n, n * sizeof(int32_t));
-    if (xyxy) memcpy(xyxy, d->h_xyxy, (size_t)n * md * 4 * sizeof(float));
-    if (conf) memcpy(conf, d->h_conf, (size_t)n * md * sizeof(float));
-    if (cls) memcpy(cls, d->h_cls, (size_t)n * md * sizeof(int32_t));
+    const int idx = (d->head + rtmodt_detector::RING_SLOTS - d->n_pending) % rtmodt_detector::RING_SLOTS;   // oldest in flight
+    rtmodt_detector::Slot &sl = d->slots[idx];
+    RT_HIP(hipEventSynchronize(sl.done));
+    d->n_pending -= 1;
+    d->last_fetched = idx;
+    const int n = sl.n, md = d->cfg.max_det;
+    memcpy(n_out, sl.h_n, n * sizeof(int32_t));
+    if (xyxy) memcpy(xyxy, sl.h_xyxy, (size_t)n * md * 4 * sizeof(float));
+    if (conf) memcpy(conf, sl.h_conf, (size_t)n * md * sizeof(float));
+    if (cls) memcpy(cls, sl.h_cls, (size_t)n * md * sizeof(int32_t));
     return RTMODT_OK;
 }
 
 int rtmodt_detector_detect_batch(rtmodt_detector *d, const uint8_t *const *frames, int n, int h, int w, int stride_bytes, int mem_kind,
                                  float *xyxy, float *conf, int32_t *cls, int32_t *n_out) {
+    RT_CHECK(d && d->n_pending == 0, RTMODT_E_INVALID, "detect_batch with batches still in flight: fetch them first");
     RT_TRY(rtmodt_detector_enqueue_batch(d, frames, n, h, w, stride_bytes, mem_kind));
     return rtmodt_detector_fetch(d, xyxy, conf, cls, n_out);
 }
@@ -777,7 +837,17 @@ int rtmodt_detector_profile(rtmodt_detector *d, int iters, int max_entries, cons
     }
     for (auto &e : ev) hipEventDestroy(e);
     d->prof_names.clear();
-    for (auto &op : d->ops) d->prof_names.push_back(op.name);
+    for (auto &op : d->ops) {
+        char buf[160];
+        if (op.kind == OP_CONV) {
+            TileShape ts = tile_shape(op.conv.tile);
+            snprintf(buf, sizeof(buf), "%s [M=%d N=%d K=%d k%d s%d tile %dx%d]", op.name.c_str(), d->B * op.conv.out.H * op.conv.out.W,
+                     op.conv.cout, op.conv.ks * op.conv.ks * op.conv.cin, op.conv.ks, op.conv.stride, ts.bm, ts.bn);
+        } else {
+            snprintf(buf, sizeof(buf), "%s", op.name.c_str());
+        }
+        d->prof_names.push_back(buf);
+    }
     d->prof_names.push_back("decode");
     *n_entries = n;
     for (int i = 0; i < n && i < max_entries; ++i) {
@@ -789,11 +859,12 @@ int rtmodt_detector_profile(rtmodt_detector *d, int iters, int max_entries, cons
 }
 
 int rtmodt_detector_last_timing(rtmodt_detector *d, float *total_ms, float *forward_ms) {
-    RT_CHECK(d && d->last_n > 0, RTMODT_E_INVALID, "no batch has been enqueued");
+    RT_CHECK(d && d->last_fetched >= 0, RTMODT_E_INVALID, "no batch has been fetched");
     RT_HIP(hipSetDevice(d->device));
-    RT_HIP(hipEventSynchronize(d->ev2));
-    if (total_ms) RT_HIP(hipEventElapsedTime(total_ms, d->ev0, d->ev2));
-    if (forward_ms) RT_HIP(hipEventElapsedTime(forward_ms, d->ev0, d->ev1));
+    const rtmodt_detector::Slot &sl = d->slots[d->last_fetched];          // the batch fetch() returned last
+    RT_HIP(hipEventSynchronize(sl.ev2));
+    if (total_ms) RT_HIP(hipEventElapsedTime(total_ms, sl.ev0, sl.ev2));
+    if (forward_ms) RT_HIP(hipEventElapsedTime(forward_ms, sl.ev0, sl.ev1));
     return RTMODT_OK;
 }
 

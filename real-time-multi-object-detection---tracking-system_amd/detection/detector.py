@@ -91,6 +91,7 @@ class Detector:
         batch: int = 1,
         max_source_size: Optional[tuple] = None,
         use_graph: bool = True,
+        autotune: bool = True,
         warmup: bool = True,
     ) -> None:
         self.input_size = input_size
@@ -125,7 +126,7 @@ class Detector:
         cfg = _ffi.DetCfg(chosen.encode(), side, side, float(confidence), float(iou),
                           None if cls_arr is None else cls_arr.ctypes.data_as(C.POINTER(C.c_int32)),
                           0 if cls_arr is None else len(cls_arr), 1, self._ordinal, int(max_det), int(bool(agnostic_nms)),
-                          self.batch, int(msw), int(msh), int(bool(use_graph)))
+                          self.batch, int(msw), int(msh), int(bool(use_graph)), int(bool(autotune)))
         h = C.c_void_p()
         _ffi.check(L.rtmodt_detector_create(C.byref(cfg), C.byref(h)))
         sid, nc, na, ncv = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
@@ -136,6 +137,7 @@ class Detector:
         self._conf = np.empty((self.batch, max_det), np.float32)
         self._cls = np.empty((self.batch, max_det), np.int32)
         self._n = np.zeros(self.batch, np.int32)
+        self._in_flight = []                              # frame counts of batches enqueued, not yet fetched
         if warmup:
             self._warmup()
 
@@ -146,6 +148,8 @@ class Detector:
 
     def detect_batch(self, frames: Sequence[np.ndarray]) -> list:
         """Up to ``batch`` same-sized frames in one pass (streams batched per GPU)."""
+        while self._in_flight:                            # drain anything enqueued earlier
+            self.fetch()
         self.enqueue(frames)
         return self.fetch()
 
@@ -171,10 +175,13 @@ class Detector:
                 arr[i] = a.ctypes.data
             self._frames_keepalive = keep
         _ffi.check(_ffi.lib().rtmodt_detector_enqueue_batch(self.model.handle, arr, n, int(h), int(w), int(p), kind))
-        self._last_n = n
+        self._in_flight.append(n)
 
     def fetch(self) -> list:
-        n = self._last_n
+        """Results of the OLDEST batch in flight (up to two may be: enqueue t+1, fetch t)."""
+        if not self._in_flight:
+            raise RuntimeError("fetch() without a pending enqueue()")
+        n = self._in_flight.pop(0)
         _ffi.check(_ffi.lib().rtmodt_detector_fetch(self.model.handle, _ffi.ptr(self._xyxy), _ffi.ptr(self._conf),
                                                     _ffi.ptr(self._cls), _ffi.ptr(self._n)))
         return [self._parse(i) for i in range(n)]
