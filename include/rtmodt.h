@@ -65,6 +65,7 @@ typedef struct rtmodt_det_cfg {
     int32_t max_src_w, max_src_h; /* largest source frame accepted (staging), 0 = in_w/in_h                */
     int32_t use_graph;         /* 1: replay the forward pass as one captured hipGraph                      */
     int32_t autotune;          /* 1: time every conv tile configuration at create and keep the fastest      */
+    int32_t chains;            /* sub-batches run as separate graphs on separate streams; 0 = 1 (more measured slower) */
 } rtmodt_det_cfg;
 
 int rtmodt_detector_create(const rtmodt_det_cfg *cfg, rtmodt_detector **out);

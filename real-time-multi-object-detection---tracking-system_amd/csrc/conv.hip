@@ -46,39 +46,137 @@ __device__ __forceinline__ float silu_f(float x) {
     return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x));
 }
 
-template <int BM, int BN, int WM, int WN, bool GENERAL>
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// position of a 32-deep k-step inside K = (kh, kw, cin): wave-uniform when cin % 32 == 0
+struct KPos {
+    int kh = 0, kw = 0, c0 = 0;
+    __device__ __forceinline__ void advance(int steps, int cin, int ks) {
+        c0 += 32 * steps;
+        while (c0 >= cin) {
+            c0 -= cin;
+            if (++kw == ks) { kw = 0; ++kh; }
+        }
+    }
+};
+// per-lane position of this lane's 8-channel chunk (general path: cin % 32 != 0, cin % 8 == 0)
+struct KLane {
+    int tap = 0, c = 0;
+    __device__ __forceinline__ void advance(int halves, int cin) {
+        c += halves;
+        while (c >= cin) { c -= cin; ++tap; }
+    }
+    __device__ __forceinline__ int offset(int ks, int in_Wp, int in_cs) const {
+        const bool in = tap < ks * ks;                   // K tail (zero weights): any valid address
+        int t = in ? tap : 0;
+        int th = ks == 3 ? (t * 11) >> 5 : 0;            // t / 3 for t < 9
+        int tw = t - th * ks;
+        return (th * in_Wp + tw) * in_cs + (in ? c : 0);
+    }
+};
+
+// LDS-DMA piece = 16 rows x 32 k (64 B per row), stored ROW-MAJOR: DMA lane l fills bytes
+// [16 l, 16 l + 16) = row l>>2, slot l&3, so every 16-lane quarter of the wave instruction
+// touches 4 rows x 64 contiguous bytes (4 cache-line lookups, not 16).  The MFMA fragment of
+// lane (r = lane&15, q = lane>>4) is k-chunk q of row r; a plain row-major image would make
+// that ds_read_b128 2-way bank conflicted, so chunk q of row r is stored in slot
+// q ^ swz(r), swz(r) = {0,0,3,3}[r>>2] (an involution applied on the SOURCE address, the LDS
+// image itself stays lane-linear as the DMA requires) -- conflict-free for all four
+// 16-lane groups of ds_read_b128.
+__device__ __forceinline__ int swz16(int row) { return ((row >> 3) & 1) * 3; }
+struct LaneMap {
+    int ld_row, ld_chunk;    // DMA: which row / which 8-half k-chunk this lane fetches
+    int rd_off;              // byte offset of this lane's fragment inside a piece
+    __device__ __forceinline__ LaneMap(int lane) {
+        ld_row = lane >> 2;
+        ld_chunk = (lane & 3) ^ swz16(ld_row);
+        int r = lane & 15, q = lane >> 4;
+        rd_off = r * 64 + ((q ^ swz16(r)) << 4);
+    }
+};
+
+__device__ __forceinline__ void glds16(const f16 *src, unsigned char *dst) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                     (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+}
+
+// fused epilogue for one 16(pixel) x 16(cout) accumulator tile: lane holds pixel (lane&15),
+// channels n .. n+3
+__device__ __forceinline__ void store_tile(const ConvArgs &p, const floatx4 &acc, long opix, long rpix, int n) {
+    floatx4 v = acc + *(const floatx4 *)(p.bias + n);
+    if (p.act) { v[0] = silu_f(v[0]); v[1] = silu_f(v[1]); v[2] = silu_f(v[2]); v[3] = silu_f(v[3]); }
+    if (p.res) {
+        half4 rv = *(const half4 *)(p.res + rpix + n);
+        v[0] += (float)rv[0]; v[1] += (float)rv[1]; v[2] += (float)rv[2]; v[3] += (float)rv[3];
+    }
+    half4 o = {(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
+    *(half4 *)(p.out + opix + n) = o;
+}
+
+__device__ __forceinline__ bool pixel_offsets(const ConvArgs &p, int m, long &opix, long &rpix) {
+    if (m >= p.M) return false;
+    const int HoWo = p.Ho * p.Wo;
+    int b = m / HoWo, rem = m - b * HoWo;
+    int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+    opix = ((long)(b * p.out_Hp + oy + p.out_pad) * p.out_Wp + ox + p.out_pad) * p.out_cs;
+    rpix = p.res ? ((long)(b * p.res_Hp + oy + p.res_pad) * p.res_Wp + ox + p.res_pad) * p.res_cs : 0;
+    return true;
+}
+
+__device__ __forceinline__ int input_offset(const ConvArgs &p, int m) {
+    m = m < p.M ? m : p.M - 1;                           // tail rows re-read the last pixel (masked at store)
+    const int HoWo = p.Ho * p.Wo;
+    int b = m / HoWo, rem = m - b * HoWo;
+    int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+    return ((b * p.in_Hp + oy * p.stride + p.in_org) * p.in_Wp + ox * p.stride + p.in_org) * p.in_cs;
+}
+
+// ---------------------------------------------------------------------------------------
+// conv_mfma: block tile BM x BN shared by 4 waves (WM x WN), THREE LDS stages.  The DMA of
+// k-steps kt+1 and kt+2 is in flight while kt is multiplied: each step waits with a COUNTED
+// s_waitcnt vmcnt (never 0 inside the loop) and a raw s_barrier.
+// ---------------------------------------------------------------------------------------
+// wait until at most `steps` k-steps' worth of this wave's DMA pieces are still in flight
+template <int L, int MAXSTEPS>
+__device__ __forceinline__ void wait_steps(int steps) {
+    if constexpr (MAXSTEPS == 0) {
+        wait_vmcnt<0>();
+    } else {
+        if (steps >= MAXSTEPS) wait_vmcnt<L * MAXSTEPS>();
+        else wait_steps<L, MAXSTEPS - 1>(steps);
+    }
+}
+
+template <int BM, int BN, int WM, int WN, int NSTAGE, bool GENERAL>
 __global__ __launch_bounds__(256) void conv_mfma(ConvArgs p) {
     static_assert(WM * WN == 4, "4 waves per workgroup");
     static_assert(BM % 64 == 0 && BN % 16 == 0, "tile shape");
     constexpr int NA = BM / 16, NB = BN / 16, NRB = NA + NB;
     constexpr int LA = NA / 4;                 // A pieces per wave per k-step
     constexpr int LB = (NB + 3) / 4;           // B pieces per wave per k-step (last may be absent)
+    constexpr int LBF = NB / 4, LBR = NB % 4;  // every wave issues LBF, waves < LBR one more
+    constexpr int DEPTH = NSTAGE - 1;          // k-steps of DMA kept in flight ahead of the MFMAs
     constexpr int STAGE = NRB * 1024;
+    static_assert(NSTAGE >= 2 && (LA + LBF + 1) * (DEPTH - 1) <= 63, "vmcnt is a 6-bit counter");
     constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
-    __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * STAGE];
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[NSTAGE * STAGE];
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r = lane & 15, q = lane >> 4;
+    const LaneMap lm(lane);
     const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
-    const int HoWo = p.Ho * p.Wo;
 
     // ---- loader set-up: element offsets of this lane's 16-byte chunk in each piece ----
     int a_off[LA];
 #pragma unroll
-    for (int i = 0; i < LA; ++i) {
-        int m = m0 + (wave + 4 * i) * 16 + r;
-        m = m < p.M ? m : p.M - 1;                       // tail rows re-read the last pixel (masked at store)
-        int b = m / HoWo, rem = m - b * HoWo;
-        int oy = rem / p.Wo, ox = rem - oy * p.Wo;
-        a_off[i] = ((b * p.in_Hp + oy * p.stride + p.in_org) * p.in_Wp + ox * p.stride + p.in_org) * p.in_cs;
-    }
+    for (int i = 0; i < LA; ++i) a_off[i] = input_offset(p, m0 + (wave + 4 * i) * 16 + lm.ld_row);
     int b_off[LB];
 #pragma unroll
-    for (int i = 0; i < LB; ++i) {
-        int n = n0 + (wave + 4 * i) * 16 + r;            // weights are zero-padded to a multiple of 128 rows
-        b_off[i] = n * p.kp + q * 8;
-    }
+    for (int i = 0; i < LB; ++i) b_off[i] = (n0 + (wave + 4 * i) * 16 + lm.ld_row) * p.kp + lm.ld_chunk * 8;   // weights zero-padded to 128 rows
 
     floatx4 acc[TM][TN];
 #pragma unroll
@@ -87,67 +185,41 @@ __global__ __launch_bounds__(256) void conv_mfma(ConvArgs p) {
         for (int u = 0; u < TN; ++u) acc[t][u] = floatx4{0.f, 0.f, 0.f, 0.f};
 
     const int nk = p.kp / 32;
-    // uniform path: (kh, kw, c0) of the current k-step are wave-uniform scalars
-    int kh = 0, kw = 0, c0 = 0;
-    // general path: per-lane position of chunk q inside K
-    int g_tap = 0, g_c = q * 8;
-    if (GENERAL) {
-        while (g_c >= p.cin) { g_c -= p.cin; ++g_tap; }
-    }
+    KPos kp;
+    KLane kl;
+    if (GENERAL) kl.advance(lm.ld_chunk * 8, p.cin);
 
     auto issue = [&](int kt, int stage) {
         unsigned char *sbase = lds + stage * STAGE;
-        int tap_off;
-        if (!GENERAL) {
-            tap_off = (kh * p.in_Wp + kw) * p.in_cs + c0 + q * 8;
-        } else {
-            int t = g_tap < p.ks * p.ks ? g_tap : 0;     // K tail (zero weights): any valid address
-            int th = p.ks == 3 ? (t * 11) >> 5 : 0;      // t / 3 for t < 9
-            int tw = t - th * p.ks;
-            tap_off = (th * p.in_Wp + tw) * p.in_cs + (g_tap < p.ks * p.ks ? g_c : 0);
-        }
+        const int tap_off = GENERAL ? kl.offset(p.ks, p.in_Wp, p.in_cs) : (kp.kh * p.in_Wp + kp.kw) * p.in_cs + kp.c0 + lm.ld_chunk * 8;
 #pragma unroll
-        for (int i = 0; i < LA; ++i) {
-            const f16 *src = p.in + (a_off[i] + tap_off);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                             (__attribute__((address_space(3))) void *)(sbase + (wave + 4 * i) * 1024),
-                                             16, 0, 0);
-        }
+        for (int i = 0; i < LA; ++i) glds16(p.in + (a_off[i] + tap_off), sbase + (wave + 4 * i) * 1024);
 #pragma unroll
-        for (int i = 0; i < LB; ++i) {
-            if (wave + 4 * i < NB) {
-                const f16 *src = p.wt + (b_off[i] + kt * 32);
-                __builtin_amdgcn_global_load_lds(
-                    (const __attribute__((address_space(1))) void *)src,
-                    (__attribute__((address_space(3))) void *)(sbase + (NA + wave + 4 * i) * 1024), 16, 0, 0);
-            }
-        }
-        // advance to the next k-step
-        if (!GENERAL) {
-            c0 += 32;
-            if (c0 >= p.cin) {
-                c0 = 0;
-                if (++kw == p.ks) { kw = 0; ++kh; }
-            }
-        } else {
-            g_c += 32;
-            if (g_c >= p.cin) { g_c -= p.cin; ++g_tap; }
-            if (g_c >= p.cin) { g_c -= p.cin; ++g_tap; }
-            if (g_c >= p.cin) { g_c -= p.cin; ++g_tap; }   // cin >= 16 (multiple of 8): at most 2, 3rd for safety
-        }
+        for (int i = 0; i < LB; ++i)
+            if (i < LBF || wave < LBR) glds16(p.wt + (b_off[i] + kt * 32), sbase + (NA + wave + 4 * i) * 1024);
+        if (GENERAL) kl.advance(32, p.cin); else kp.advance(1, p.cin, p.ks);
     };
 
     const int wm = wave / WN, wn = wave % WN;
-    issue(0, 0);
+#pragma unroll
+    for (int i = 0; i < DEPTH; ++i)
+        if (i < nk) issue(i, i);
+    int rstage = 0, wstage = DEPTH % NSTAGE;              // stage read this step / stage refilled this step
     for (int kt = 0; kt < nk; ++kt) {
-        __syncthreads();                                  // stage kt landed (vmcnt(0)) and stage kt-1 fully read
-        if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
-        const unsigned char *sbase = lds + (kt & 1) * STAGE;
+        // stage kt has landed once only the pieces of the (up to DEPTH-1) later steps are outstanding
+        const int ahead = min(DEPTH - 1, nk - 1 - kt);
+        if (LBR != 0 && wave < LBR) wait_steps<LA + LBF + 1, DEPTH - 1>(ahead); else wait_steps<LA + LBF, DEPTH - 1>(ahead);
+        __builtin_amdgcn_s_barrier();                     // everyone's stage kt landed; everyone is done reading stage kt-1
+        asm volatile("" ::: "memory");
+        if (kt + DEPTH < nk) issue(kt + DEPTH, wstage);   // refills the stage read in step kt-1
+        const unsigned char *sbase = lds + rstage * STAGE;
+        rstage = rstage + 1 == NSTAGE ? 0 : rstage + 1;
+        wstage = wstage + 1 == NSTAGE ? 0 : wstage + 1;
         half8 fa[TM], fb[TN];
 #pragma unroll
-        for (int t = 0; t < TM; ++t) fa[t] = *(const half8 *)(sbase + (wm * TM + t) * 1024 + lane * 16);
+        for (int t = 0; t < TM; ++t) fa[t] = *(const half8 *)(sbase + (wm * TM + t) * 1024 + lm.rd_off);
 #pragma unroll
-        for (int u = 0; u < TN; ++u) fb[u] = *(const half8 *)(sbase + (NA + wn * TN + u) * 1024 + lane * 16);
+        for (int u = 0; u < TN; ++u) fb[u] = *(const half8 *)(sbase + (NA + wn * TN + u) * 1024 + lm.rd_off);
 #pragma unroll
         for (int t = 0; t < TM; ++t)
 #pragma unroll
@@ -158,30 +230,112 @@ __global__ __launch_bounds__(256) void conv_mfma(ConvArgs p) {
     // ---- epilogue: D[row = cout (lane>>4)*4+j][col = pixel lane&15] ----
 #pragma unroll
     for (int t = 0; t < TM; ++t) {
-        int m = m0 + (wm * TM + t) * 16 + r;
-        if (m >= p.M) continue;
-        int b = m / HoWo, rem = m - b * HoWo;
-        int oy = rem / p.Wo, ox = rem - oy * p.Wo;
-        long opix = ((long)(b * p.out_Hp + oy + p.out_pad) * p.out_Wp + ox + p.out_pad) * p.out_cs;
-        long rpix = 0;
-        if (p.res) rpix = ((long)(b * p.res_Hp + oy + p.res_pad) * p.res_Wp + ox + p.res_pad) * p.res_cs;
+        long opix, rpix;
+        if (!pixel_offsets(p, m0 + (wm * TM + t) * 16 + r, opix, rpix)) continue;
 #pragma unroll
         for (int u = 0; u < TN; ++u) {
             int n = n0 + (wn * TN + u) * 16 + q * 4;
-            if (n >= p.cout) continue;
-            floatx4 bv = *(const floatx4 *)(p.bias + n);
-            floatx4 v = acc[t][u] + bv;
-            if (p.act) {
-                v[0] = silu_f(v[0]); v[1] = silu_f(v[1]); v[2] = silu_f(v[2]); v[3] = silu_f(v[3]);
-            }
-            if (p.res) {
-                half4 rv = *(const half4 *)(p.res + rpix + n);
-                v[0] += (float)rv[0]; v[1] += (float)rv[1]; v[2] += (float)rv[2]; v[3] += (float)rv[3];
-            }
-            half4 o = {(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
-            *(half4 *)(p.out + opix + n) = o;
+            if (n < p.cout) store_tile(p, acc[t][u], opix, rpix, n);
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------
+// conv_mfma_wsk: "wave-split-K" for the deep, small-M layers (P5: M = 400 per frame,
+// K up to 4608).  The 4 waves of a workgroup all own the SAME BM x BN output tile but take
+// every 4th k-step each, stage their operands in wave-private LDS (two stages per wave) and
+// therefore never meet at a barrier inside the k-loop; the four partial accumulators are
+// summed through LDS at the end and each wave finishes a quarter of the tile.  Four times
+// the k-parallelism per CU exactly where a 64-wide tile leaves most CUs waiting on memory.
+// ---------------------------------------------------------------------------------------
+template <int BM, int BN, bool GENERAL>
+__global__ __launch_bounds__(256) void conv_mfma_wsk(ConvArgs p) {
+    constexpr int NA = BM / 16, NB = BN / 16, NP = NA + NB;
+    constexpr int WSTAGE = NP * 1024;
+    constexpr int TM = NA, TN = NB;
+    constexpr int STAGING = 4 * 2 * WSTAGE, REDUCE = 4 * TM * TN * 1024;
+    constexpr int LDS_BYTES = STAGING > REDUCE ? STAGING : REDUCE;
+    static_assert((TM * TN) % 4 == 0, "tile count must split over 4 waves");
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[LDS_BYTES];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r = lane & 15, q = lane >> 4;
+    const LaneMap lm(lane);
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    unsigned char *wbase = lds + wave * 2 * WSTAGE;
+
+    int a_off[NA], b_off[NB];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) a_off[i] = input_offset(p, m0 + i * 16 + lm.ld_row);
+#pragma unroll
+    for (int i = 0; i < NB; ++i) b_off[i] = (n0 + i * 16 + lm.ld_row) * p.kp + lm.ld_chunk * 8;
+
+    floatx4 acc[TM][TN];
+#pragma unroll
+    for (int t = 0; t < TM; ++t)
+#pragma unroll
+        for (int u = 0; u < TN; ++u) acc[t][u] = floatx4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = p.kp / 32;
+    const int my_nk = (nk - wave + 3) / 4;               // k-steps wave, wave+4, ...
+    KPos kp;
+    KLane kl;
+    if (GENERAL) kl.advance(lm.ld_chunk * 8 + 32 * wave, p.cin); else kp.advance(wave, p.cin, p.ks);
+
+    auto issue = [&](int kt, int stage) {
+        unsigned char *sbase = wbase + stage * WSTAGE;
+        const int tap_off = GENERAL ? kl.offset(p.ks, p.in_Wp, p.in_cs) : (kp.kh * p.in_Wp + kp.kw) * p.in_cs + kp.c0 + lm.ld_chunk * 8;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) glds16(p.in + (a_off[i] + tap_off), sbase + i * 1024);
+#pragma unroll
+        for (int i = 0; i < NB; ++i) glds16(p.wt + (b_off[i] + kt * 32), sbase + (NA + i) * 1024);
+        if (GENERAL) kl.advance(128, p.cin); else kp.advance(4, p.cin, p.ks);
+    };
+
+    if (my_nk > 0) issue(wave, 0);
+    for (int it = 0; it < my_nk; ++it) {
+        if (it + 1 < my_nk) { issue(wave + 4 * (it + 1), (it + 1) & 1); wait_vmcnt<NP>(); } else { wait_vmcnt<0>(); }
+        const unsigned char *sbase = wbase + (it & 1) * WSTAGE;
+        half8 fa[TM], fb[TN];
+#pragma unroll
+        for (int t = 0; t < TM; ++t) fa[t] = *(const half8 *)(sbase + t * 1024 + lm.rd_off);
+#pragma unroll
+        for (int u = 0; u < TN; ++u) fb[u] = *(const half8 *)(sbase + (NA + u) * 1024 + lm.rd_off);
+#pragma unroll
+        for (int t = 0; t < TM; ++t)
+#pragma unroll
+            for (int u = 0; u < TN; ++u)
+                acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[u], fa[t], acc[t][u], 0, 0, 0);
+        // the next issue() overwrites the stage just read: its LDS reads must have retired
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+
+    // ---- cross-wave reduction through LDS: partial[wave][tile][lane] (16 B per lane, lane-linear) ----
+    __syncthreads();                                       // all staging reads done before the region is reused
+    floatx4 *part = (floatx4 *)lds;
+#pragma unroll
+    for (int t = 0; t < TM; ++t)
+#pragma unroll
+        for (int u = 0; u < TN; ++u) part[(wave * TM * TN + t * TN + u) * 64 + lane] = acc[t][u];
+    __syncthreads();
+    constexpr int PER = TM * TN / 4;                       // tiles finished by each wave
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const int tile = wave * PER + k, t = tile / TN, u = tile % TN;
+        floatx4 v = part[(0 * TM * TN + tile) * 64 + lane] + part[(1 * TM * TN + tile) * 64 + lane] +
+                    part[(2 * TM * TN + tile) * 64 + lane] + part[(3 * TM * TN + tile) * 64 + lane];
+        long opix, rpix;
+        if (!pixel_offsets(p, m0 + t * 16 + r, opix, rpix)) continue;
+        int n = n0 + u * 16 + q * 4;
+        if (n < p.cout) store_tile(p, v, opix, rpix, n);
+    }
+}
+
+const char *tile_name(int tile) {
+    static const char *names[TILE_COUNT] = {"128x128s3", "128x64s3", "64x64s3", "256x32s3", "64x128s3", "wsk64x64", "wsk32x64", "wsk64x32",
+                                            "128x128s4", "128x64s5", "64x64s6", "64x128s5", "128x128s6"};
+    return tile >= 0 && tile < TILE_COUNT ? names[tile] : "?";
 }
 
 TileShape tile_shape(int tile) {
@@ -191,17 +345,33 @@ TileShape tile_shape(int tile) {
         case TILE_64x64: return {64, 64};
         case TILE_256x32: return {256, 32};
         case TILE_64x128: return {64, 128};
+        case TILE_WSK_64x64: return {64, 64};
+        case TILE_WSK_32x64: return {32, 64};
+        case TILE_WSK_64x32: return {64, 32};
+        case TILE_128x128_S4: case TILE_128x128_S6: return {128, 128};
+        case TILE_128x64_S5: return {128, 64};
+        case TILE_64x64_S6: return {64, 64};
+        case TILE_64x128_S5: return {64, 128};
     }
     return {0, 0};
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int NSTAGE>
 static void launch_tile(const ConvArgs &a, bool general, hipStream_t s) {
     dim3 grid(cdiv(a.M, BM), cdiv(a.cout, BN));
     if (general)
-        hipLaunchKernelGGL((conv_mfma<BM, BN, WM, WN, true>), grid, dim3(256), 0, s, a);
+        hipLaunchKernelGGL((conv_mfma<BM, BN, WM, WN, NSTAGE, true>), grid, dim3(256), 0, s, a);
     else
-        hipLaunchKernelGGL((conv_mfma<BM, BN, WM, WN, false>), grid, dim3(256), 0, s, a);
+        hipLaunchKernelGGL((conv_mfma<BM, BN, WM, WN, NSTAGE, false>), grid, dim3(256), 0, s, a);
+}
+
+template <int BM, int BN>
+static void launch_wsk(const ConvArgs &a, bool general, hipStream_t s) {
+    dim3 grid(cdiv(a.M, BM), cdiv(a.cout, BN));
+    if (general)
+        hipLaunchKernelGGL((conv_mfma_wsk<BM, BN, true>), grid, dim3(256), 0, s, a);
+    else
+        hipLaunchKernelGGL((conv_mfma_wsk<BM, BN, false>), grid, dim3(256), 0, s, a);
 }
 
 int launch_conv(const ConvLaunch &c, hipStream_t s) {
@@ -238,11 +408,19 @@ int launch_conv(const ConvLaunch &c, hipStream_t s) {
              RTMODT_E_INVALID, "launch_conv: tensor exceeds 2^31 elements");
     const bool general = (c.cin % 32) != 0;
     switch (c.tile) {
-        case TILE_128x128: launch_tile<128, 128, 2, 2>(a, general, s); break;
-        case TILE_128x64: launch_tile<128, 64, 2, 2>(a, general, s); break;
-        case TILE_64x64: launch_tile<64, 64, 2, 2>(a, general, s); break;
-        case TILE_256x32: launch_tile<256, 32, 4, 1>(a, general, s); break;
-        case TILE_64x128: launch_tile<64, 128, 1, 4>(a, general, s); break;
+        case TILE_128x128: launch_tile<128, 128, 2, 2, 3>(a, general, s); break;
+        case TILE_128x64: launch_tile<128, 64, 2, 2, 3>(a, general, s); break;
+        case TILE_64x64: launch_tile<64, 64, 2, 2, 3>(a, general, s); break;
+        case TILE_256x32: launch_tile<256, 32, 4, 1, 3>(a, general, s); break;
+        case TILE_64x128: launch_tile<64, 128, 1, 4, 3>(a, general, s); break;
+        case TILE_128x128_S4: launch_tile<128, 128, 2, 2, 4>(a, general, s); break;
+        case TILE_128x64_S5: launch_tile<128, 64, 2, 2, 5>(a, general, s); break;
+        case TILE_64x64_S6: launch_tile<64, 64, 2, 2, 6>(a, general, s); break;
+        case TILE_64x128_S5: launch_tile<64, 128, 1, 4, 5>(a, general, s); break;
+        case TILE_128x128_S6: launch_tile<128, 128, 2, 2, 6>(a, general, s); break;
+        case TILE_WSK_64x64: launch_wsk<64, 64>(a, general, s); break;
+        case TILE_WSK_32x64: launch_wsk<32, 64>(a, general, s); break;
+        case TILE_WSK_64x32: launch_wsk<64, 32>(a, general, s); break;
         default: return fail(RTMODT_E_INVALID, "launch_conv: tile %d", c.tile);
     }
     RT_HIP(hipGetLastError());

@@ -16,9 +16,29 @@
 #include <string>
 #include <vector>
 
+#include <execinfo.h>
+#include <signal.h>
+#include <unistd.h>
+
 #include "kernels.h"
 
 namespace rtmodt {
+
+static void segv_trace(int sig) {
+    void *bt[64];
+    int n = backtrace(bt, 64);
+    const char msg[] = "[rtmodt] fatal signal, backtrace:\n";
+    (void)!write(2, msg, sizeof(msg) - 1);
+    backtrace_symbols_fd(bt, n, 2);
+    _exit(128 + sig);
+}
+static void install_debug_handlers() {
+    static bool done = false;
+    if (done || !getenv("RTMODT_DEBUG")) return;
+    done = true;
+    signal(SIGSEGV, segv_trace);
+    signal(SIGABRT, segv_trace);
+}
 
 std::string &last_error() {
     static thread_local std::string e;
@@ -126,6 +146,8 @@ struct Op {
     TensorView v[4];                 // STEM: in,out; POOL: y,p1,p2,p3; UP: in,out
     const float *stem_w = nullptr, *stem_b = nullptr;
     int64_t flops = 0;               // per frame
+    int B = 1;                       // images this launch covers
+    int head_level = -1;             // >= 0: belongs to the Detect branch of that level (independent of the other levels)
 };
 
 }  // namespace rtmodt
@@ -144,7 +166,15 @@ struct rtmodt_detector {
     char *arena = nullptr;
     size_t arena_bytes = 0;
     std::vector<Tensor> tensors;
-    std::vector<Op> ops;
+    std::vector<Op> ops;                              // whole batch, one op per launch (eager path, profiler)
+    // The batch is also cut into `n_chains` sub-batches whose op lists are captured as PARALLEL
+    // branches of the forward graph (plus one branch per Detect level): the layers of this net
+    // are small and latency-bound, so independent chains in flight hide each other's launch
+    // gaps, first-load latency and epilogue tails.
+    int n_chains = 1;
+    std::vector<std::vector<Op>> chain_ops;
+    std::vector<hipStream_t> aux_streams;             // fork targets during capture
+    std::vector<hipEvent_t> aux_events;
     std::map<std::string, TensorView> layer_out;     // fused conv name -> output view
     std::vector<void *> dev_allocs;                   // weights etc.
     int img_t = -1;
@@ -157,13 +187,19 @@ struct rtmodt_detector {
     int32_t *d_tab = nullptr; size_t tab_cap = 0;
     ResizeTables tabs{};
     // postprocess
-    float4 *d_box = nullptr; float *d_score = nullptr; int32_t *d_cls = nullptr; float *d_pred = nullptr;
+    // decode's dense per-anchor outputs, one set per ring slot: NMS of batch t (post stream) reads
+    // set t%2 while the forward pass of batch t+1 (main stream) fills the other one
+    struct Dense { float4 *box = nullptr; float *score = nullptr; int32_t *cls = nullptr; };
+    Dense dense[2];
+    int cur_dense = 0;
+    float *d_pred = nullptr;
+    hipStream_t post_stream = nullptr;                // NMS + D2H + tracker run here, overlapped with the next forward
     uint64_t *d_keys = nullptr; float4 *d_sbox = nullptr; int32_t *d_sidx = nullptr;
     // results: a ring of RING_SLOTS batches may be in flight (enqueue t+1 before fetching t)
     struct Slot {
         float *o_xyxy = nullptr, *o_conf = nullptr; int32_t *o_cls = nullptr, *o_anchor = nullptr, *o_n = nullptr;   // device
         float *h_xyxy = nullptr, *h_conf = nullptr; int32_t *h_cls = nullptr, *h_n = nullptr;                        // pinned host
-        hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, done = nullptr;
+        hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, done = nullptr, decoded = nullptr;
         int n = 0;
     };
     static constexpr int RING_SLOTS = 2;
@@ -172,7 +208,9 @@ struct rtmodt_detector {
     int newest = -1, last_fetched = -1;
     uint64_t class_mask[2] = {~0ull, ~0ull};
     // graph
-    hipGraph_t graph = nullptr; hipGraphExec_t graph_exec = nullptr;
+    std::vector<hipGraph_t> graphs; std::vector<hipGraphExec_t> graph_execs;   // one captured graph per sub-batch chain
+    std::vector<hipStream_t> chain_streams;           // [n_chains], chain 0 runs on `stream`
+    std::vector<hipEvent_t> chain_fork, chain_join;
     bool want_pred = false;
     int last_h = 0, last_w = 0;
     // profile storage
@@ -213,13 +251,25 @@ static int upload(rtmodt_detector *d, const void *src, size_t bytes, void **out)
     return RTMODT_OK;
 }
 
+// the same launch restricted to images [b0, b0 + nb) of the batch
+static Op sub_batch(const Op &op, int b0, int nb) {
+    Op o = op;
+    auto shift = [&](TensorView &v) {
+        if (v.c) v.base += (size_t)b0 * (v.H + 2 * v.pad) * (v.W + 2 * v.pad) * v.C;
+    };
+    o.B = nb;
+    if (o.kind == OP_CONV) { shift(o.conv.in); shift(o.conv.out); shift(o.conv.res); o.conv.B = nb; }
+    else for (auto &v : o.v) shift(v);
+    return o;
+}
+
 static int pick_tile(int M, int cout) {
     if (const char *e = getenv("RTMODT_TILE")) {
         int t = atoi(e);
         if (t >= 0 && t < TILE_COUNT) return t;
     }
-    static const float eff[TILE_COUNT] = {1.0f, 0.85f, 0.62f, 0.75f, 0.85f};
-    static const int occ[TILE_COUNT] = {3, 5, 8, 4, 5};
+    static const float eff[TILE_COUNT] = {1.0f, 0.85f, 0.62f, 0.75f, 0.85f, 0.5f, 0.4f, 0.4f, 1.05f, 0.9f, 0.65f, 0.9f, 1.0f};
+    static const int occ[TILE_COUNT] = {3, 5, 8, 4, 5, 2, 3, 3, 2, 2, 3, 2, 1};
     int best = 0;
     double best_cost = 1e30;
     for (int t = 0; t < TILE_COUNT; ++t) {
@@ -395,6 +445,13 @@ static int build_graph(rtmodt_detector *d, WeightFile &wf) {
         RT_TRY(make_conv(d, wf, {"22.cv2." + L + ".2"}, "22.cv2." + L + ".2", V(hB2), V(d->head_t[l], 0, 64), nullptr, 0));
         RT_TRY(make_conv(d, wf, {"22.cv3." + L + ".2"}, "22.cv3." + L + ".2", V(hB3), V(d->head_t[l], 64, nc4), nullptr, 1));
     }
+    for (auto &op : d->ops) {
+        op.B = d->B;
+        if (op.name.rfind("22.", 0) == 0) {                // "22.cv2+cv3.<l>.0", "22.cv3.<l>.2": level = next-to-last field
+            size_t last = op.name.rfind('.'), prev = op.name.rfind('.', last - 1);
+            op.head_level = atoi(op.name.substr(prev + 1, last - prev - 1).c_str());
+        }
+    }
     d->n_anchors = 0;
     for (int l = 0; l < 3; ++l) d->n_anchors += d->tensors[d->head_t[l]].H * d->tensors[d->head_t[l]].W;
     d->flops_per_frame = 0;
@@ -415,18 +472,30 @@ static int build_graph(rtmodt_detector *d, WeightFile &wf) {
         }
     }
     for (auto &kv : d->layer_out) rebase(kv.second);
+
+    // sub-batch chains (parallel graph branches)
+    int chains = d->cfg.chains > 0 ? d->cfg.chains : 1;   // measured on MI355X: chains > 1 run slower (kernels of separate streams do not overlap here)
+    if (const char *e = getenv("RTMODT_CHAINS")) chains = atoi(e);
+    chains = std::max(1, std::min(chains, d->B));
+    while (d->B % chains) --chains;
+    d->n_chains = chains;
+    d->chain_ops.assign(chains, {});
+    const int nb = d->B / chains;
+    for (int c = 0; c < chains; ++c)
+        for (auto &op : d->ops) d->chain_ops[c].push_back(sub_batch(op, c * nb, nb));
     return RTMODT_OK;
 }
 
-static int run_op(rtmodt_detector *d, const Op &op) {
+static int run_op_on(const Op &op, hipStream_t s) {
     switch (op.kind) {
-        case OP_STEM: return launch_stem(op.v[0], op.v[1], op.stem_w, op.stem_b, d->B, op.v[1].c, d->stream);
-        case OP_CONV: return launch_conv(op.conv, d->stream);
-        case OP_POOL: return launch_sppf_pool(op.v[0], op.v[1], op.v[2], op.v[3], d->B, d->stream);
-        case OP_UP: return launch_upsample2(op.v[0], op.v[1], d->B, d->stream);
+        case OP_STEM: return launch_stem(op.v[0], op.v[1], op.stem_w, op.stem_b, op.B, op.v[1].c, s);
+        case OP_CONV: return launch_conv(op.conv, s);
+        case OP_POOL: return launch_sppf_pool(op.v[0], op.v[1], op.v[2], op.v[3], op.B, s);
+        case OP_UP: return launch_upsample2(op.v[0], op.v[1], op.B, s);
     }
     return RTMODT_OK;
 }
+static int run_op(rtmodt_detector *d, const Op &op) { return run_op_on(op, d->stream); }
 
 static int run_decode(rtmodt_detector *d) {
     DecodeArgs a{};
@@ -437,7 +506,8 @@ static int run_decode(rtmodt_detector *d) {
     }
     a.B = d->B; a.nc = d->nc; a.n_anchors = d->n_anchors; a.conf = d->cfg.conf;
     a.class_mask[0] = d->class_mask[0]; a.class_mask[1] = d->class_mask[1];
-    a.box = d->d_box; a.score = d->d_score; a.cls = d->d_cls;
+    const rtmodt_detector::Dense &dn = d->dense[d->cur_dense];
+    a.box = dn.box; a.score = dn.score; a.cls = dn.cls;
     a.pred = d->want_pred ? d->d_pred : nullptr;
     return launch_decode(a, d->stream);
 }
@@ -450,10 +520,10 @@ static int forward_eager(rtmodt_detector *d) {
 // Times every tile configuration of every MFMA conv on the device it will run on (HIP events,
 // best of a few launches) and keeps the fastest: the GEMM shapes of this net are small and
 // skinny, so the best tile depends on how M x N fills 256 CUs, not on a rule.
-static int autotune_tiles(rtmodt_detector *d) {
+static int autotune_ops(rtmodt_detector *d, std::vector<Op> &ops) {
     hipEvent_t e0, e1;
     RT_HIP(hipEventCreate(&e0)); RT_HIP(hipEventCreate(&e1));
-    for (auto &op : d->ops) {
+    for (auto &op : ops) {
         if (op.kind != OP_CONV) continue;
         float best = 1e30f;
         int best_tile = op.conv.tile;
@@ -475,32 +545,117 @@ static int autotune_tiles(rtmodt_detector *d) {
         op.conv.tile = best_tile;
     }
     hipEventDestroy(e0); hipEventDestroy(e1);
-    // the tuning launches left garbage-free but stale activations; run one clean pass
+    return RTMODT_OK;
+}
+
+static int autotune_tiles(rtmodt_detector *d) {
+    RT_TRY(autotune_ops(d, d->ops));
+    if (d->n_chains > 1) {
+        RT_TRY(autotune_ops(d, d->chain_ops[0]));          // the sub-batch GEMMs have their own best tiles
+        for (int c = 1; c < d->n_chains; ++c)
+            for (size_t i = 0; i < d->ops.size(); ++i) d->chain_ops[c][i].conv.tile = d->chain_ops[0][i].conv.tile;
+    } else {
+        for (size_t i = 0; i < d->ops.size(); ++i) d->chain_ops[0][i].conv.tile = d->ops[i].conv.tile;
+    }
+    // the tuning launches left stale activations; run one clean pass
     RT_TRY(forward_eager(d));
     RT_HIP(hipStreamSynchronize(d->stream));
     return RTMODT_OK;
 }
 
-static int capture_graph(rtmodt_detector *d) {
-    if (d->graph_exec) { hipGraphExecDestroy(d->graph_exec); d->graph_exec = nullptr; }
-    if (d->graph) { hipGraphDestroy(d->graph); d->graph = nullptr; }
-    RT_HIP(hipStreamBeginCapture(d->stream, hipStreamCaptureModeRelaxed));
-    int rc = forward_eager(d);
-    hipError_t e = hipStreamEndCapture(d->stream, &d->graph);
+// One hipGraph per sub-batch chain.  Inside a chain's graph the Detect branch of level 0 forks
+// off as soon as layer 15 is done and that of level 1 after layer 18, so they run beside the
+// (small, latency-bound) P4/P5 neck.  Forks/joins are only ever made against the capture's
+// ORIGIN stream: HIP 7.0's EndCapture recurses forever when two non-origin streams wait on
+// each other, which is why the chains are separate graphs launched on separate streams
+// instead of branches of one capture.
+static int capture_chain(rtmodt_detector *d, int c) {
+    hipStream_t main = d->chain_streams[c];
+    hipStream_t h0 = d->aux_streams[2 * c], h1 = d->aux_streams[2 * c + 1];
+    const auto &ops = d->chain_ops[c];
+    size_t ev = (size_t)c * 4;
+    auto fork = [&](hipStream_t from, hipStream_t to) -> int {
+        hipEvent_t e = d->aux_events[ev++];
+        RT_HIP(hipEventRecord(e, from));
+        RT_HIP(hipStreamWaitEvent(to, e, 0));
+        return RTMODT_OK;
+    };
+    auto run_head = [&](int level, hipStream_t st) -> int {
+        for (auto &op : ops) if (op.head_level == level) RT_TRY(run_op_on(op, st));
+        return RTMODT_OK;
+    };
+    auto body = [&]() -> int {
+        for (auto &op : ops) {
+            if (op.head_level >= 0) continue;
+            RT_TRY(run_op_on(op, main));
+            if (op.name == "15.cv2") { RT_TRY(fork(main, h0)); RT_TRY(run_head(0, h0)); }
+            if (op.name == "18.cv2") { RT_TRY(fork(main, h1)); RT_TRY(run_head(1, h1)); }
+        }
+        RT_TRY(run_head(2, main));
+        RT_TRY(fork(h0, main));                            // joins
+        RT_TRY(fork(h1, main));
+        return RTMODT_OK;
+    };
+    RT_HIP(hipStreamBeginCapture(main, hipStreamCaptureModeRelaxed));
+    int rc = body();
+    hipError_t e = hipStreamEndCapture(main, &d->graphs[c]);
     RT_TRY(rc);
     RT_HIP(e);
-    RT_HIP(hipGraphInstantiate(&d->graph_exec, d->graph, nullptr, nullptr, 0));
+    RT_HIP(hipGraphInstantiate(&d->graph_execs[c], d->graphs[c], nullptr, nullptr, 0));
     return RTMODT_OK;
+}
+
+static int capture_graph(rtmodt_detector *d) {
+    const int C = d->n_chains;
+    for (auto g : d->graph_execs) if (g) hipGraphExecDestroy(g);
+    for (auto g : d->graphs) if (g) hipGraphDestroy(g);
+    d->graphs.assign(C, nullptr); d->graph_execs.assign(C, nullptr);
+    while ((int)d->chain_streams.size() < C) {
+        hipStream_t st = d->stream;
+        if (!d->chain_streams.empty()) RT_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        d->chain_streams.push_back(st);
+        hipEvent_t a, b;
+        RT_HIP(hipEventCreateWithFlags(&a, hipEventDisableTiming)); RT_HIP(hipEventCreateWithFlags(&b, hipEventDisableTiming));
+        d->chain_fork.push_back(a); d->chain_join.push_back(b);
+    }
+    while ((int)d->aux_streams.size() < 2 * C) {
+        hipStream_t st;
+        RT_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        d->aux_streams.push_back(st);
+    }
+    while ((int)d->aux_events.size() < 4 * C) {
+        hipEvent_t e;
+        RT_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        d->aux_events.push_back(e);
+    }
+    for (int c = 0; c < C; ++c) RT_TRY(capture_chain(d, c));
+    return RTMODT_OK;
+}
+
+// letterboxed input -> dense per-anchor candidates, on the main stream (+ chain streams)
+static int forward_graphs(rtmodt_detector *d) {
+    const int C = d->n_chains;
+    for (int c = 1; c < C; ++c) {
+        RT_HIP(hipEventRecord(d->chain_fork[c], d->stream));
+        RT_HIP(hipStreamWaitEvent(d->chain_streams[c], d->chain_fork[c], 0));
+    }
+    for (int c = 0; c < C; ++c) RT_HIP(hipGraphLaunch(d->graph_execs[c], d->chain_streams[c]));
+    for (int c = 1; c < C; ++c) {
+        RT_HIP(hipEventRecord(d->chain_join[c], d->chain_streams[c]));
+        RT_HIP(hipStreamWaitEvent(d->stream, d->chain_join[c], 0));
+    }
+    return run_decode(d);
 }
 
 static int run_nms(rtmodt_detector *d, const LbHost &g, int h, int w, rtmodt_detector::Slot &sl) {
     NmsArgs a{};
     a.B = d->B; a.n_anchors = d->n_anchors; a.max_det = d->cfg.max_det; a.agnostic = d->cfg.agnostic; a.iou = d->cfg.iou;
-    a.box = d->d_box; a.score = d->d_score; a.cls = d->d_cls;
+    const rtmodt_detector::Dense &dn = d->dense[d->cur_dense];
+    a.box = dn.box; a.score = dn.score; a.cls = dn.cls;
     a.keys = d->d_keys; a.sbox = d->d_sbox; a.sidx = d->d_sidx;
     a.gain = (float)g.gain; a.pad_x = (float)g.pad_x; a.pad_y = (float)g.pad_y; a.src_w = (float)w; a.src_h = (float)h; a.rescale = 1;
     a.out_xyxy = sl.o_xyxy; a.out_conf = sl.o_conf; a.out_cls = sl.o_cls; a.out_anchor = sl.o_anchor; a.out_n = sl.o_n;
-    return launch_nms(a, d->stream);
+    return launch_nms(a, d->post_stream);
 }
 
 int detector_outputs(rtmodt_detector *d, DetOutputs *o) {
@@ -508,7 +663,7 @@ int detector_outputs(rtmodt_detector *d, DetOutputs *o) {
     RT_CHECK(d->newest >= 0, RTMODT_E_INVALID, "detector has no enqueued batch");
     const rtmodt_detector::Slot &sl = d->slots[d->newest];
     o->box = (const float4 *)sl.o_xyxy; o->conf = sl.o_conf; o->cls = sl.o_cls; o->n = sl.o_n;
-    o->stride = d->cfg.max_det; o->count = sl.n; o->device = d->device; o->stream = d->stream;
+    o->stride = d->cfg.max_det; o->count = sl.n; o->device = d->device; o->stream = d->post_stream;
     return RTMODT_OK;
 }
 
@@ -557,17 +712,24 @@ int rtmodt_memcpy_d2h(int device, void *dst, const void *src, size_t bytes) {
 void rtmodt_detector_destroy(rtmodt_detector *d) {
     if (!d) return;
     hipSetDevice(d->device);
-    if (d->stream) hipStreamSynchronize(d->stream);
-    if (d->graph_exec) hipGraphExecDestroy(d->graph_exec);
-    if (d->graph) hipGraphDestroy(d->graph);
+    hipDeviceSynchronize();
+    for (auto g : d->graph_execs) if (g) hipGraphExecDestroy(g);
+    for (auto g : d->graphs) if (g) hipGraphDestroy(g);
+    for (int k = 0; k < 2; ++k) { hipFree(d->dense[k].box); hipFree(d->dense[k].score); hipFree(d->dense[k].cls); }
+    for (size_t c = 1; c < d->chain_streams.size(); ++c) hipStreamDestroy(d->chain_streams[c]);
+    for (auto e : d->chain_fork) hipEventDestroy(e);
+    for (auto e : d->chain_join) hipEventDestroy(e);
+    if (d->post_stream) hipStreamDestroy(d->post_stream);
+    for (auto st : d->aux_streams) hipStreamDestroy(st);
+    for (auto e : d->aux_events) hipEventDestroy(e);
     for (void *p : d->dev_allocs) hipFree(p);
     hipFree(d->arena); hipFree(d->stage); hipFree(d->d_tab);
-    hipFree(d->d_box); hipFree(d->d_score); hipFree(d->d_cls); hipFree(d->d_pred);
+    hipFree(d->d_pred);
     hipFree(d->d_keys); hipFree(d->d_sbox); hipFree(d->d_sidx);
     for (auto &sl : d->slots) {
         hipFree(sl.o_xyxy); hipFree(sl.o_conf); hipFree(sl.o_cls); hipFree(sl.o_anchor); hipFree(sl.o_n);
         hipHostFree(sl.h_xyxy); hipHostFree(sl.h_conf); hipHostFree(sl.h_cls); hipHostFree(sl.h_n);
-        for (hipEvent_t e : {sl.ev0, sl.ev1, sl.ev2, sl.done}) if (e) hipEventDestroy(e);
+        for (hipEvent_t e : {sl.ev0, sl.ev1, sl.ev2, sl.done, sl.decoded}) if (e) hipEventDestroy(e);
     }
     if (d->stream) hipStreamDestroy(d->stream);
     delete d;
@@ -597,6 +759,7 @@ static int detector_create_impl(const rtmodt_det_cfg *cfg, rtmodt_detector *d) {
     RT_CHECK(d->nc >= 1 && d->nc <= 128, RTMODT_E_UNSUPPORTED, "nc %d (1..128 supported)", d->nc);
     RT_HIP(hipSetDevice(d->device));
     RT_HIP(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking));
+    RT_HIP(hipStreamCreateWithFlags(&d->post_stream, hipStreamNonBlocking));
     RT_TRY(build_graph(d, wf));
 
     int msw = cfg->max_src_w > 0 ? cfg->max_src_w : d->in_w, msh = cfg->max_src_h > 0 ? cfg->max_src_h : d->in_h;
@@ -607,9 +770,11 @@ static int detector_create_impl(const rtmodt_det_cfg *cfg, rtmodt_detector *d) {
     RT_HIP(hipMalloc((void **)&d->d_tab, d->tab_cap * sizeof(int32_t)));
 
     size_t BA = (size_t)d->B * d->n_anchors, BD = (size_t)d->B * cfg->max_det;
-    RT_HIP(hipMalloc((void **)&d->d_box, BA * sizeof(float4)));
-    RT_HIP(hipMalloc((void **)&d->d_score, BA * sizeof(float)));
-    RT_HIP(hipMalloc((void **)&d->d_cls, BA * sizeof(int32_t)));
+    for (auto &dn : d->dense) {
+        RT_HIP(hipMalloc((void **)&dn.box, BA * sizeof(float4)));
+        RT_HIP(hipMalloc((void **)&dn.score, BA * sizeof(float)));
+        RT_HIP(hipMalloc((void **)&dn.cls, BA * sizeof(int32_t)));
+    }
     RT_HIP(hipMalloc((void **)&d->d_pred, BA * (4 + d->nc) * sizeof(float)));
     RT_HIP(hipMalloc((void **)&d->d_keys, BA * sizeof(uint64_t)));
     RT_HIP(hipMalloc((void **)&d->d_sbox, BA * sizeof(float4)));
@@ -627,6 +792,7 @@ static int detector_create_impl(const rtmodt_det_cfg *cfg, rtmodt_detector *d) {
         RT_HIP(hipHostMalloc((void **)&sl.h_n, d->B * sizeof(int32_t), hipHostMallocDefault));
         RT_HIP(hipEventCreate(&sl.ev0)); RT_HIP(hipEventCreate(&sl.ev1)); RT_HIP(hipEventCreate(&sl.ev2));
         RT_HIP(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+        RT_HIP(hipEventCreateWithFlags(&sl.decoded, hipEventDisableTiming));
     }
 
     // one eager pass (also sets kernel attributes) before capturing the graph
@@ -639,6 +805,7 @@ static int detector_create_impl(const rtmodt_det_cfg *cfg, rtmodt_detector *d) {
 
 int rtmodt_detector_create(const rtmodt_det_cfg *cfg, rtmodt_detector **out) {
     RT_CHECK(cfg && out && cfg->weight_path, RTMODT_E_INVALID, "null argument");
+    install_debug_handlers();
     rtmodt_detector *d = new rtmodt_detector();
     int rc = detector_create_impl(cfg, d);
     if (rc != RTMODT_OK) {
@@ -690,20 +857,25 @@ int rtmodt_detector_enqueue_batch(rtmodt_detector *d, const uint8_t *const *fram
     }
     LetterboxGeom lg{h, w, g.new_w, g.new_h, g.top, g.left, g.resize};
     TensorView img; img.base = d->tensors[d->img_t].ptr; img.H = d->in_h; img.W = d->in_w; img.C = 4; img.pad = 1; img.c = 4;
+    d->cur_dense = d->head;                            // ring slot == dense set == graph
     RT_HIP(hipEventRecord(sl.ev0, d->stream));
     RT_TRY(launch_letterbox(d->fptrs, stride_bytes, lg, d->tabs, img, d->B, d->stream));
-    if (d->graph_exec && !d->want_pred) RT_HIP(hipGraphLaunch(d->graph_exec, d->stream));
+    if (!d->graph_execs.empty() && !d->want_pred) RT_TRY(forward_graphs(d));
     else RT_TRY(forward_eager(d));
     RT_HIP(hipEventRecord(sl.ev1, d->stream));
+    RT_HIP(hipEventRecord(sl.decoded, d->stream));
+    // post-processing on its own stream: one small workgroup per image, latency-bound -- it runs
+    // underneath the next batch's forward pass instead of in front of it
+    RT_HIP(hipStreamWaitEvent(d->post_stream, sl.decoded, 0));
     RT_TRY(run_nms(d, g, h, w, sl));
-    RT_HIP(hipEventRecord(sl.ev2, d->stream));
+    RT_HIP(hipEventRecord(sl.ev2, d->post_stream));
     // results travel to pinned host memory right behind the kernels; fetch() only waits for `done`
     const int md = d->cfg.max_det;
-    RT_HIP(hipMemcpyAsync(sl.h_n, sl.o_n, n * sizeof(int32_t), hipMemcpyDeviceToHost, d->stream));
-    RT_HIP(hipMemcpyAsync(sl.h_xyxy, sl.o_xyxy, (size_t)n * md * 4 * sizeof(float), hipMemcpyDeviceToHost, d->stream));
-    RT_HIP(hipMemcpyAsync(sl.h_conf, sl.o_conf, (size_t)n * md * sizeof(float), hipMemcpyDeviceToHost, d->stream));
-    RT_HIP(hipMemcpyAsync(sl.h_cls, sl.o_cls, (size_t)n * md * sizeof(int32_t), hipMemcpyDeviceToHost, d->stream));
-    RT_HIP(hipEventRecord(sl.done, d->stream));
+    RT_HIP(hipMemcpyAsync(sl.h_n, sl.o_n, n * sizeof(int32_t), hipMemcpyDeviceToHost, d->post_stream));
+    RT_HIP(hipMemcpyAsync(sl.h_xyxy, sl.o_xyxy, (size_t)n * md * 4 * sizeof(float), hipMemcpyDeviceToHost, d->post_stream));
+    RT_HIP(hipMemcpyAsync(sl.h_conf, sl.o_conf, (size_t)n * md * sizeof(float), hipMemcpyDeviceToHost, d->post_stream));
+    RT_HIP(hipMemcpyAsync(sl.h_cls, sl.o_cls, (size_t)n * md * sizeof(int32_t), hipMemcpyDeviceToHost, d->post_stream));
+    RT_HIP(hipEventRecord(sl.done, d->post_stream));
     sl.n = n;
     d->newest = d->head;
     d->head = (d->head + 1) % rtmodt_detector::RING_SLOTS;
@@ -772,7 +944,8 @@ static int fetch_view(rtmodt_detector *d, const TensorView &v, int img, uint16_t
 int rtmodt_detector_debug_fetch(rtmodt_detector *d, int img, uint16_t *input_f16, uint16_t *heads_f16, float *pred) {
     RT_CHECK(d && img >= 0 && img < d->B, RTMODT_E_INVALID, "bad argument");
     RT_HIP(hipSetDevice(d->device));
-    RT_HIP(hipStreamSynchronize(d->stream));
+    RT_HIP(hipDeviceSynchronize());
+    if (d->newest >= 0) d->cur_dense = d->newest;
     if (input_f16) {
         TensorView v; const Tensor &t = d->tensors[d->img_t];
         v.base = t.ptr; v.H = t.H; v.W = t.W; v.C = 4; v.pad = 1; v.coff = 0; v.c = 3;
@@ -840,9 +1013,8 @@ int rtmodt_detector_profile(rtmodt_detector *d, int iters, int max_entries, cons
     for (auto &op : d->ops) {
         char buf[160];
         if (op.kind == OP_CONV) {
-            TileShape ts = tile_shape(op.conv.tile);
-            snprintf(buf, sizeof(buf), "%s [M=%d N=%d K=%d k%d s%d tile %dx%d]", op.name.c_str(), d->B * op.conv.out.H * op.conv.out.W,
-                     op.conv.cout, op.conv.ks * op.conv.ks * op.conv.cin, op.conv.ks, op.conv.stride, ts.bm, ts.bn);
+            snprintf(buf, sizeof(buf), "%s [M=%d N=%d K=%d k%d s%d tile %s]", op.name.c_str(), d->B * op.conv.out.H * op.conv.out.W,
+                     op.conv.cout, op.conv.ks * op.conv.ks * op.conv.cin, op.conv.ks, op.conv.stride, tile_name(op.conv.tile));
         } else {
             snprintf(buf, sizeof(buf), "%s", op.name.c_str());
         }

@@ -21,7 +21,13 @@ struct TensorView {
 };
 
 // Tile configurations of the implicit-GEMM kernel (conv.hip)
-enum ConvTile { TILE_128x128 = 0, TILE_128x64 = 1, TILE_64x64 = 2, TILE_256x32 = 3, TILE_64x128 = 4, TILE_COUNT = 5 };
+enum ConvTile {
+    TILE_128x128 = 0, TILE_128x64 = 1, TILE_64x64 = 2, TILE_256x32 = 3, TILE_64x128 = 4,   // 4 waves share one tile
+    TILE_WSK_64x64 = 5, TILE_WSK_32x64 = 6, TILE_WSK_64x32 = 7,                           // 4 waves split K over one tile
+    TILE_128x128_S4 = 8, TILE_128x64_S5 = 9, TILE_64x64_S6 = 10, TILE_64x128_S5 = 11, TILE_128x128_S6 = 12,   // deeper DMA pipelines
+    TILE_COUNT = 13
+};
+const char *tile_name(int tile);
 struct TileShape { int bm, bn; };
 TileShape tile_shape(int tile);
 

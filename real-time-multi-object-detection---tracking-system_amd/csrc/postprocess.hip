@@ -20,6 +20,7 @@
 #include "kernels.h"
 
 #include <climits>
+#include <type_traits>
 
 namespace rtmodt {
 
@@ -27,7 +28,7 @@ namespace rtmodt {
 
 constexpr int PP_THREADS = 256;
 constexpr int PP_WAVES = PP_THREADS / 64;
-constexpr int SORT_LDS_MAX = 8192;          // keys sorted in LDS (64 KiB); beyond: global rank sort
+constexpr int SORT_LDS_MAX = 4096;          // keys sorted in LDS (32 KiB); beyond: global rank sort
 constexpr int MAX_NMS = 30000;              // ultralytics max_nms
 constexpr float MAX_WH = 7680.0f;           // ultralytics max_wh (per-class coordinate offset)
 
@@ -158,13 +159,76 @@ __device__ __forceinline__ int pp_scan_flag(bool flag, int *wsum, int &total) {
     return off + within;
 }
 
-__global__ __launch_bounds__(PP_THREADS) void nms_kernel(NmsArgs a) {
+constexpr int SBOX_LDS_MAX = 2048;          // sorted boxes kept in LDS (32 KiB); beyond: global scratch
+constexpr int RANK_LDS_MAX = 2048;          // up to here: LDS rank sort (no barriers); above: bitonic network
+
+// Greedy suppression over boxes sorted by descending score.  A shared LDS bitmap holds
+// the "removed or already kept" bits; every thread finds the next kept box `cur` by itself
+// from that bitmap (same-address LDS reads broadcast, so no reduction and no hot-spot atomic),
+// then tests the boxes it owns (sorted positions t, t+256, ... -- their alive bits live in
+// two registers) against `cur` and publishes removals with one atomicOr each.  ONE barrier
+// per kept box.  Stops after max_det keeps (keep[:max_det], App. B.3 step 6).
+template <bool LDSBOX>
+__device__ __forceinline__ int greedy_nms(const float4 *lbox, const float4 *gbox, int n, int max_det, double thr,
+                                          unsigned long long *removed, int *sel) {
+    const int tid = threadIdx.x;
+    const int nwords = (n + 63) >> 6;
+    unsigned long long alive0 = 0ull, alive1 = 0ull;
+    for (int k = 0; k < 64; ++k) {
+        if (tid + PP_THREADS * k < n) alive0 |= 1ull << k;
+        if (tid + PP_THREADS * (64 + k) < n) alive1 |= 1ull << k;
+    }
+    int kept = 0, pos = 0;
+    while (pos < n) {
+        // next position >= pos whose bit is clear
+        int w = pos >> 6, cur = -1;
+        unsigned long long avail = ~removed[w] & ~((1ull << (pos & 63)) - 1ull);
+        while (true) {
+            int last = n - (w << 6);
+            if (last < 64) avail &= (1ull << last) - 1ull;
+            if (avail) { cur = (w << 6) + __builtin_ctzll(avail); break; }
+            if (++w >= nwords) break;
+            avail = ~removed[w];
+        }
+        if (cur < 0) break;
+        if (tid == 0) sel[kept] = cur;
+        ++kept;
+        pos = cur + 1;
+        if (kept >= max_det) break;
+        const float4 cb = LDSBOX ? lbox[cur] : gbox[cur];
+        const float carea = (cb.z - cb.x) * (cb.w - cb.y);
+        if ((cur & (PP_THREADS - 1)) == tid) {                // the kept box is mine: drop it from my pool
+            int k = cur / PP_THREADS;
+            if (k < 64) alive0 &= ~(1ull << k); else alive1 &= ~(1ull << (k - 64));
+        }
+        for (unsigned long long m = alive0; m; m &= m - 1) {
+            int k = __builtin_ctzll(m);
+            int j = tid + PP_THREADS * k;
+            if (j > cur && nms_overlaps(cb, carea, LDSBOX ? lbox[j] : gbox[j], thr)) {
+                alive0 &= ~(1ull << k);
+                atomicOr(&removed[j >> 6], 1ull << (j & 63));
+            }
+        }
+        for (unsigned long long m = alive1; m; m &= m - 1) {
+            int k = __builtin_ctzll(m);
+            int j = tid + PP_THREADS * (64 + k);
+            if (j > cur && nms_overlaps(cb, carea, LDSBOX ? lbox[j] : gbox[j], thr)) {
+                alive1 &= ~(1ull << k);
+                atomicOr(&removed[j >> 6], 1ull << (j & 63));
+            }
+        }
+        __syncthreads();                                      // removals visible before the next search
+    }
+    return kept;
+}
+
+__global__ __launch_bounds__(PP_THREADS) void nms_kernel(NmsArgs a, int dbg_stop) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned long long *skeys = (unsigned long long *)smem;                  // [SORT_LDS_MAX]
-    unsigned long long *removed = skeys + SORT_LDS_MAX;                      // [ceil(MAX_NMS/64)]
+    unsigned long long *skeys = (unsigned long long *)smem;                  // [SORT_LDS_MAX] sort keys, kept for the index part
+    float4 *lbox = (float4 *)(skeys + SORT_LDS_MAX);                         // [SBOX_LDS_MAX] sorted, class-offset boxes
+    unsigned long long *removed = (unsigned long long *)(lbox + SBOX_LDS_MAX);   // [ceil(MAX_NMS/64)] removed-or-kept bitmap
     int *sel = (int *)(removed + (MAX_NMS + 63) / 64);                        // [max_det]
     __shared__ int wsum[PP_WAVES + 1];
-    __shared__ int s_next;
 
     const int b = blockIdx.x, tid = threadIdx.x;
     const int A = a.n_anchors;
@@ -172,105 +236,142 @@ __global__ __launch_bounds__(PP_THREADS) void nms_kernel(NmsArgs a) {
     const float *score = a.score + (size_t)b * A;
     const int32_t *cls = a.cls + (size_t)b * A;
     unsigned long long *gkeys = (unsigned long long *)a.keys + (size_t)b * A;
-    float4 *sbox = a.sbox + (size_t)b * A;
+    float4 *gsbox = a.sbox + (size_t)b * A;
     int32_t *sidx = a.sidx + (size_t)b * A;
 
-    // ---- 1. compaction in anchor order ----
-    int n = 0;
-    for (int base = 0; base < A; base += PP_THREADS) {
-        int i = base + tid;
-        float sc = i < A ? score[i] : -1.0f;
-        bool f = sc >= 0.0f;
-        int tot;
-        int pos = pp_scan_flag(f, wsum, tot);
-        if (f) gkeys[n + pos] = ((unsigned long long)__float_as_uint(sc) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)i);
-        n += tot;
+    // ---- 1. compaction in anchor order: thread t owns the contiguous anchors [t*per, (t+1)*per) ----
+    const int per = (A + PP_THREADS - 1) / PP_THREADS;
+    const int lo = min(tid * per, A), hi = min(lo + per, A);
+    int mine = 0;
+    for (int i0 = lo; i0 < hi; i0 += 8) {                    // 8 independent loads in flight per trip
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = i0 + k < hi ? score[i0 + k] : -1.0f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) mine += v[k] >= 0.0f;
+    }
+    int n, base;
+    {   // block exclusive scan of the per-thread counts
+        const int lane = tid & 63, wave = tid >> 6;
+        int incl = mine;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            int o = __shfl_up(incl, d);
+            if (lane >= d) incl += o;
+        }
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        int off = 0, tot = 0;
+#pragma unroll
+        for (int w = 0; w < PP_WAVES; ++w) {
+            int v = wsum[w];
+            if (w < wave) off += v;
+            tot += v;
+        }
+        base = off + incl - mine;
+        n = tot;
+    }
+    if (dbg_stop == 1) return;
+    const bool lds_sort = n <= SORT_LDS_MAX;
+    if (mine) {
+        int o = base;
+        for (int i0 = lo; i0 < hi; i0 += 8) {
+            float v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = i0 + k < hi ? score[i0 + k] : -1.0f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (v[k] >= 0.0f) {
+                    unsigned long long key = ((unsigned long long)__float_as_uint(v[k]) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)(i0 + k));
+                    if (lds_sort) skeys[o] = key; else gkeys[o] = key;
+                    ++o;
+                }
+        }
     }
     __syncthreads();
+    if (dbg_stop == 2) return;
 
-    // ---- 2. sort by (score desc, anchor asc) ----
-    if (n <= SORT_LDS_MAX) {
+    // ---- 2. sort by (score desc, anchor asc); keys are unique ----
+    if (n <= RANK_LDS_MAX) {
+        // LDS rank sort: each thread ranks its <= 8 keys against all n (16-byte broadcast reads, no barriers)
+        const int npad = (n + 1) & ~1;
+        if (tid == 0 && (n & 1)) skeys[n] = 0ull;
+        __syncthreads();
+        unsigned long long mk[8];
+        int rk[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { int i = tid + PP_THREADS * e; mk[e] = i < n ? skeys[i] : ~0ull; rk[e] = 0; }
+        const ulonglong2 *k2 = (const ulonglong2 *)skeys;
+        const int E = (n + PP_THREADS - 1) / PP_THREADS;     // keys per thread actually in use (uniform)
+        auto rank_loop = [&](auto ne) {
+            constexpr int NE = decltype(ne)::value;
+            for (int j = 0; j < (npad >> 1); ++j) {
+                ulonglong2 kk = k2[j];
+#pragma unroll
+                for (int e = 0; e < NE; ++e) rk[e] += (kk.x > mk[e]) + (kk.y > mk[e]);
+            }
+        };
+        if (E <= 1) rank_loop(std::integral_constant<int, 1>{});
+        else if (E <= 2) rank_loop(std::integral_constant<int, 2>{});
+        else if (E <= 4) rank_loop(std::integral_constant<int, 4>{});
+        else rank_loop(std::integral_constant<int, 8>{});
+        __syncthreads();                                      // everyone has read skeys
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            if (tid + PP_THREADS * e < n) skeys[rk[e]] = mk[e];
+        __syncthreads();
+    } else if (lds_sort) {
         int P = 1;
         while (P < n) P <<= 1;
-        for (int i = tid; i < P; i += PP_THREADS) skeys[i] = i < n ? gkeys[i] : 0ull;
+        for (int i = n + tid; i < P; i += PP_THREADS) skeys[i] = 0ull;
         __syncthreads();
         for (int k = 2; k <= P; k <<= 1) {
             for (int j = k >> 1; j > 0; j >>= 1) {
-                for (int i = tid; i < P; i += PP_THREADS) {
-                    int ixj = i ^ j;
-                    if (ixj > i) {
-                        unsigned long long x = skeys[i], y = skeys[ixj];
-                        bool desc = (i & k) == 0;
-                        if (desc ? (x < y) : (x > y)) { skeys[i] = y; skeys[ixj] = x; }
-                    }
+                for (int i = tid; i < (P >> 1); i += PP_THREADS) {
+                    int lo_i = ((i & ~(j - 1)) << 1) | (i & (j - 1));          // index with bit j cleared
+                    int hi_i = lo_i | j;
+                    unsigned long long x = skeys[lo_i], y = skeys[hi_i];
+                    bool desc = (lo_i & k) == 0;
+                    if (desc ? (x < y) : (x > y)) { skeys[lo_i] = y; skeys[hi_i] = x; }
                 }
                 __syncthreads();
             }
         }
-        for (int i = tid; i < n; i += PP_THREADS) {
-            unsigned idx = 0xFFFFFFFFu - (unsigned)(skeys[i] & 0xFFFFFFFFull);
-            sidx[i] = (int)idx;
-        }
     } else {
-        // rank sort through global memory (keys are unique): only reachable above 640x640 input
+        // rank sort through global memory (> 4096 candidates: a saturated head, not a trained one)
         for (int i = tid; i < n; i += PP_THREADS) {
             unsigned long long k = gkeys[i];
             int rank = 0;
             for (int j = 0; j < n; ++j) rank += gkeys[j] > k;
             sidx[rank] = (int)(0xFFFFFFFFu - (unsigned)(k & 0xFFFFFFFFull));
         }
+        __syncthreads();
     }
-    __syncthreads();
+    if (dbg_stop == 3) return;
     if (n > MAX_NMS) n = MAX_NMS;                          // top-max_nms by confidence (B.3 step 5)
+    const bool lds_box = n <= SBOX_LDS_MAX;
     for (int i = tid; i < n; i += PP_THREADS) {
-        int idx = sidx[i];
+        int idx = lds_sort ? (int)(0xFFFFFFFFu - (unsigned)(skeys[i] & 0xFFFFFFFFull)) : sidx[i];
         float4 bx = box[idx];
         float off = a.agnostic ? 0.0f : (float)cls[idx] * MAX_WH;
-        sbox[i] = make_float4(bx.x + off, bx.y + off, bx.z + off, bx.w + off);
+        float4 ob = make_float4(bx.x + off, bx.y + off, bx.z + off, bx.w + off);
+        if (lds_box) lbox[i] = ob; else gsbox[i] = ob;
     }
-    const int nwords = (n + 63) >> 6;
-    for (int w = tid; w < nwords; w += PP_THREADS) removed[w] = 0ull;
+    for (int w = tid; w < ((n + 63) >> 6); w += PP_THREADS) removed[w] = 0ull;
     __syncthreads();
+    if (dbg_stop == 4) return;
 
-    // ---- 3. greedy suppression, stops after max_det keeps ----
+    // ---- 3. greedy suppression ----
     const double thr = (double)a.iou;
-    int kept = 0, pos = 0;
-    while (kept < a.max_det && pos < n) {
-        if (tid == 0) s_next = INT_MAX;
-        __syncthreads();
-        const int w0 = pos >> 6;
-        for (int wb = w0; wb < nwords; wb += PP_THREADS) {
-            int w = wb + tid;
-            int cand = INT_MAX;
-            if (w < nwords) {
-                unsigned long long avail = ~removed[w];
-                if (w == w0) avail &= ~((1ull << (pos & 63)) - 1ull);
-                int last = n - (w << 6);
-                if (last < 64) avail &= (1ull << last) - 1ull;
-                if (avail) cand = (w << 6) + __builtin_ctzll(avail);
-            }
-            if (cand != INT_MAX) atomicMin(&s_next, cand);
-            __syncthreads();
-            if (s_next != INT_MAX) break;
-        }
-        const int cur = s_next;
-        if (cur == INT_MAX) break;
-        if (tid == 0) sel[kept] = cur;
-        ++kept;
-        pos = cur + 1;
-        const float4 cb = sbox[cur];
-        const float carea = (cb.z - cb.x) * (cb.w - cb.y);
-        for (int j = pos + tid; j < n; j += PP_THREADS) {
-            if ((removed[j >> 6] >> (j & 63)) & 1ull) continue;
-            if (nms_overlaps(cb, carea, sbox[j], thr)) atomicOr(&removed[j >> 6], 1ull << (j & 63));
-        }
-        __syncthreads();
-    }
+    const int kept = lds_box ? greedy_nms<true>(lbox, gsbox, n, a.max_det, thr, removed, sel)
+                             : greedy_nms<false>(lbox, gsbox, n, a.max_det, thr, removed, sel);
     __syncthreads();
+    if (dbg_stop == 5) return;
 
     // ---- 4. outputs (+ scale_boxes / clip) ----
     for (int k = tid; k < kept; k += PP_THREADS) {
-        int idx = sidx[sel[k]];
+        int sp = sel[k];
+        int idx = lds_sort ? (int)(0xFFFFFFFFu - (unsigned)(skeys[sp] & 0xFFFFFFFFull)) : sidx[sp];
         float4 bx = box[idx];
         if (a.rescale) {
             bx.x = (bx.x - a.pad_x) / a.gain; bx.z = (bx.z - a.pad_x) / a.gain;
@@ -288,10 +389,11 @@ __global__ __launch_bounds__(PP_THREADS) void nms_kernel(NmsArgs a) {
 }
 
 int launch_nms(const NmsArgs &a, hipStream_t s) {
-    size_t smem = (size_t)SORT_LDS_MAX * 8 + (size_t)((MAX_NMS + 63) / 64) * 8 + (size_t)a.max_det * 4 + 16;
+    size_t smem = (size_t)SORT_LDS_MAX * 8 + (size_t)SBOX_LDS_MAX * 16 + (size_t)((MAX_NMS + 63) / 64) * 8 + (size_t)a.max_det * 4 + 16;
     RT_CHECK(smem <= 150 * 1024, RTMODT_E_INVALID, "nms: max_det %d too large", a.max_det);
     RT_HIP(hipFuncSetAttribute((const void *)nms_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    hipLaunchKernelGGL(nms_kernel, dim3(a.B), dim3(PP_THREADS), smem, s, a);
+    static const int dbg_stop = getenv("RTMODT_NMS_STOP") ? atoi(getenv("RTMODT_NMS_STOP")) : 0;   // timing-only builds of the phases
+    hipLaunchKernelGGL(nms_kernel, dim3(a.B), dim3(PP_THREADS), smem, s, a, dbg_stop);
     RT_HIP(hipGetLastError());
     return RTMODT_OK;
 }

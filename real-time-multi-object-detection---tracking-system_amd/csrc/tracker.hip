@@ -66,27 +66,33 @@ struct AssocSmem {
 // One association pass.  rows: n_rows track indices (rows == nullptr -> identity);
 // cols: n_cols detection indices.  Afterwards row r is matched iff
 // row_best[r] >= 0 && col_winner[row_best[r]] == r.
+// R = 2^k lanes cooperate on a row (R chosen so that all rows are in flight at once when
+// they fit): with hundreds of live tracks R is 1 -- one lane per row, no cross-lane traffic,
+// detection boxes read as LDS broadcasts; with a handful of tracks a whole wave shares a
+// row and finishes with a wave64 butterfly (max value, then lowest column).
 __device__ __forceinline__ void assoc_pass(const AssocSmem &s, const int *rows, int n_rows, const int *cols, int n_cols,
                                            float thresh) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int c = threadIdx.x; c < n_cols; c += TRK_THREADS) s.col_winner[c] = INT_MAX;
     __syncthreads();
-    for (int r = wave; r < n_rows; r += TRK_WAVES) {
+    int R = 64;
+    while (R > 1 && (n_rows * R > TRK_THREADS || (R >> 1) >= n_cols)) R >>= 1;
+    const int groups = TRK_THREADS / R;
+    const int gid = threadIdx.x / R, sub = threadIdx.x & (R - 1);
+    for (int r = gid; r < n_rows; r += groups) {
         const float4 tb = s.tbox[rows ? rows[r] : r];
         float bv = -INFINITY;
         int bc = INT_MAX;
-        for (int c = lane; c < n_cols; c += 64) {
+        for (int c = sub; c < n_cols; c += R) {
             float v = iou_ref(tb, s.dbox[cols[c]]);
             if (bc == INT_MAX || v > bv) { bv = v; bc = c; }        // increasing c: first maximum wins
         }
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) {                          // wave64 butterfly: max value, then lowest column
+        for (int d = R >> 1; d >= 1; d >>= 1) {                      // butterfly inside the R-lane group
             float ov = __shfl_xor(bv, d);
             int oc = __shfl_xor(bc, d);
             bool take = (oc != INT_MAX) && (bc == INT_MAX || ov > bv || (ov == bv && oc < bc));
             if (take) { bv = ov; bc = oc; }
         }
-        if (lane == 0) {
+        if (sub == 0) {
             bool ok = (bc != INT_MAX) && (bv >= thresh);
             s.row_best[r] = ok ? bc : -1;
             if (ok) atomicMin(&s.col_winner[bc], r);

@@ -92,6 +92,7 @@ class Detector:
         max_source_size: Optional[tuple] = None,
         use_graph: bool = True,
         autotune: bool = True,
+        chains: int = 0,
         warmup: bool = True,
     ) -> None:
         self.input_size = input_size
@@ -126,7 +127,7 @@ class Detector:
         cfg = _ffi.DetCfg(chosen.encode(), side, side, float(confidence), float(iou),
                           None if cls_arr is None else cls_arr.ctypes.data_as(C.POINTER(C.c_int32)),
                           0 if cls_arr is None else len(cls_arr), 1, self._ordinal, int(max_det), int(bool(agnostic_nms)),
-                          self.batch, int(msw), int(msh), int(bool(use_graph)), int(bool(autotune)))
+                          self.batch, int(msw), int(msh), int(bool(use_graph)), int(bool(autotune)), int(chains))
         h = C.c_void_p()
         _ffi.check(L.rtmodt_detector_create(C.byref(cfg), C.byref(h)))
         sid, nc, na, ncv = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
