@@ -241,6 +241,108 @@ __global__ __launch_bounds__(256) void conv_mfma(ConvArgs p) {
 }
 
 // ---------------------------------------------------------------------------------------
+// conv_mfma64: the same block-tile kernel with 64-deep k-steps for layers whose cin is a
+// multiple of 64.  A DMA piece is 8 rows x 128 B (whole cache lines: a 16-lane quarter of the
+// wave instruction covers 2 rows = 2 lines), a stage holds two MFMA k-substeps, so there is
+// one barrier per 64 of K.  Chunk c (0..7) of row r sits in slot c ^ ((r>>1)&7): conflict-free
+// ds_read_b128 for both k-substeps.
+// ---------------------------------------------------------------------------------------
+template <int BM, int BN, int WM, int WN, int NSTAGE>
+__global__ __launch_bounds__(256) void conv_mfma64(ConvArgs p) {
+    static_assert(WM * WN == 4, "4 waves per workgroup");
+    static_assert(BM % 32 == 0 && BN % 32 == 0, "tile shape");
+    constexpr int NA = BM / 8, NB = BN / 8, NP = NA + NB;   // pieces per k-step
+    constexpr int LA = NA / 4, LBp = NB / 4;                 // per wave (NA, NB multiples of 4)
+    constexpr int DEPTH = NSTAGE - 1;
+    constexpr int STAGE = NP * 1024;
+    constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
+    static_assert((LA + LBp) * (DEPTH > 1 ? DEPTH - 1 : 1) <= 63, "vmcnt is a 6-bit counter");
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[NSTAGE * STAGE];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r = lane & 15, q = lane >> 4;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    // DMA lane map: row8 = lane>>3 of the piece, slot = lane&7
+    const int ld_row8 = lane >> 3, ld_slot = lane & 7;
+    // fragment read offsets inside a 16-row tile (two pieces) for the two k-substeps
+    const int rd_base = (r >> 3) * 1024 + (r & 7) * 128;
+    const int rd_off0 = rd_base + (((0 + q) ^ ((r >> 1) & 7)) << 4);
+    const int rd_off1 = rd_base + (((4 + q) ^ ((r >> 1) & 7)) << 4);
+
+    int a_off[LA], b_off[LBp];
+#pragma unroll
+    for (int i = 0; i < LA; ++i) {
+        int row = (wave + 4 * i) * 8 + ld_row8;              // row inside the BM tile
+        a_off[i] = input_offset(p, m0 + row) + ((ld_slot ^ ((row >> 1) & 7)) << 3);
+    }
+#pragma unroll
+    for (int i = 0; i < LBp; ++i) {
+        int row = (wave + 4 * i) * 8 + ld_row8;
+        b_off[i] = (n0 + row) * p.kp + ((ld_slot ^ ((row >> 1) & 7)) << 3);
+    }
+
+    floatx4 acc[TM][TN];
+#pragma unroll
+    for (int t = 0; t < TM; ++t)
+#pragma unroll
+        for (int u = 0; u < TN; ++u) acc[t][u] = floatx4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = p.kp / 64;
+    int kh = 0, kw = 0, c0 = 0;
+    auto issue = [&](int kt, int stage) {
+        unsigned char *sbase = lds + stage * STAGE;
+        const int tap_off = (kh * p.in_Wp + kw) * p.in_cs + c0;
+#pragma unroll
+        for (int i = 0; i < LA; ++i) glds16(p.in + (a_off[i] + tap_off), sbase + (wave + 4 * i) * 1024);
+#pragma unroll
+        for (int i = 0; i < LBp; ++i) glds16(p.wt + (b_off[i] + kt * 64), sbase + (NA + wave + 4 * i) * 1024);
+        c0 += 64;
+        if (c0 >= p.cin) { c0 = 0; if (++kw == p.ks) { kw = 0; ++kh; } }
+    };
+
+    const int wm = wave / WN, wn = wave % WN;
+#pragma unroll
+    for (int i = 0; i < DEPTH; ++i)
+        if (i < nk) issue(i, i);
+    int rstage = 0, wstage = DEPTH % NSTAGE;
+    for (int kt = 0; kt < nk; ++kt) {
+        wait_steps<LA + LBp, DEPTH - 1>(min(DEPTH - 1, nk - 1 - kt));
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (kt + DEPTH < nk) issue(kt + DEPTH, wstage);
+        const unsigned char *sbase = lds + rstage * STAGE;
+        rstage = rstage + 1 == NSTAGE ? 0 : rstage + 1;
+        wstage = wstage + 1 == NSTAGE ? 0 : wstage + 1;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int ro = kk ? rd_off1 : rd_off0;
+            half8 fa[TM], fb[TN];
+#pragma unroll
+            for (int t = 0; t < TM; ++t) fa[t] = *(const half8 *)(sbase + (wm * TM + t) * 2048 + ro);
+#pragma unroll
+            for (int u = 0; u < TN; ++u) fb[u] = *(const half8 *)(sbase + NA * 1024 + (wn * TN + u) * 2048 + ro);
+#pragma unroll
+            for (int t = 0; t < TM; ++t)
+#pragma unroll
+                for (int u = 0; u < TN; ++u)
+                    acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[u], fa[t], acc[t][u], 0, 0, 0);
+        }
+    }
+
+#pragma unroll
+    for (int t = 0; t < TM; ++t) {
+        long opix, rpix;
+        if (!pixel_offsets(p, m0 + (wm * TM + t) * 16 + r, opix, rpix)) continue;
+#pragma unroll
+        for (int u = 0; u < TN; ++u) {
+            int n = n0 + (wn * TN + u) * 16 + q * 4;
+            if (n < p.cout) store_tile(p, acc[t][u], opix, rpix, n);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
 // conv_mfma_wsk: "wave-split-K" for the deep, small-M layers (P5: M = 400 per frame,
 // K up to 4608).  The 4 waves of a workgroup all own the SAME BM x BN output tile but take
 // every 4th k-step each, stage their operands in wave-private LDS (two stages per wave) and
@@ -334,9 +436,12 @@ __global__ __launch_bounds__(256) void conv_mfma_wsk(ConvArgs p) {
 
 const char *tile_name(int tile) {
     static const char *names[TILE_COUNT] = {"128x128s3", "128x64s3", "64x64s3", "256x32s3", "64x128s3", "wsk64x64", "wsk32x64", "wsk64x32",
-                                            "128x128s4", "128x64s5", "64x64s6", "64x128s5", "128x128s6"};
+                                            "128x128s4", "128x64s5", "64x64s6", "64x128s5", "128x128s6",
+                                            "k64:128x128s2", "k64:128x128s3", "k64:128x64s3", "k64:64x128s3", "k64:64x64s3", "k64:64x64s4", "k64:256x64s2"};
     return tile >= 0 && tile < TILE_COUNT ? names[tile] : "?";
 }
+
+bool tile_needs_cin64(int tile) { return tile >= TILE_K64_128x128_S2 && tile <= TILE_K64_256x64_S2; }
 
 TileShape tile_shape(int tile) {
     switch (tile) {
@@ -352,6 +457,11 @@ TileShape tile_shape(int tile) {
         case TILE_128x64_S5: return {128, 64};
         case TILE_64x64_S6: return {64, 64};
         case TILE_64x128_S5: return {64, 128};
+        case TILE_K64_128x128_S2: case TILE_K64_128x128_S3: return {128, 128};
+        case TILE_K64_128x64_S3: return {128, 64};
+        case TILE_K64_64x128_S3: return {64, 128};
+        case TILE_K64_64x64_S3: case TILE_K64_64x64_S4: return {64, 64};
+        case TILE_K64_256x64_S2: return {256, 64};
     }
     return {0, 0};
 }
@@ -363,6 +473,12 @@ static void launch_tile(const ConvArgs &a, bool general, hipStream_t s) {
         hipLaunchKernelGGL((conv_mfma<BM, BN, WM, WN, NSTAGE, true>), grid, dim3(256), 0, s, a);
     else
         hipLaunchKernelGGL((conv_mfma<BM, BN, WM, WN, NSTAGE, false>), grid, dim3(256), 0, s, a);
+}
+
+template <int BM, int BN, int WM, int WN, int NSTAGE>
+static void launch_k64(const ConvArgs &a, hipStream_t s) {
+    dim3 grid(cdiv(a.M, BM), cdiv(a.cout, BN));
+    hipLaunchKernelGGL((conv_mfma64<BM, BN, WM, WN, NSTAGE>), grid, dim3(256), 0, s, a);
 }
 
 template <int BM, int BN>
@@ -407,6 +523,7 @@ int launch_conv(const ConvLaunch &c, hipStream_t s) {
     RT_CHECK((long)c.B * a.in_Hp * a.in_Wp * a.in_cs < (1L << 31) && (long)c.B * a.out_Hp * a.out_Wp * a.out_cs < (1L << 31),
              RTMODT_E_INVALID, "launch_conv: tensor exceeds 2^31 elements");
     const bool general = (c.cin % 32) != 0;
+    if (tile_needs_cin64(c.tile)) RT_CHECK(c.cin % 64 == 0 && a.kp % 64 == 0, RTMODT_E_INVALID, "launch_conv: tile %s needs cin %% 64 == 0 (cin %d)", tile_name(c.tile), c.cin);
     switch (c.tile) {
         case TILE_128x128: launch_tile<128, 128, 2, 2, 3>(a, general, s); break;
         case TILE_128x64: launch_tile<128, 64, 2, 2, 3>(a, general, s); break;
@@ -418,6 +535,13 @@ int launch_conv(const ConvLaunch &c, hipStream_t s) {
         case TILE_64x64_S6: launch_tile<64, 64, 2, 2, 6>(a, general, s); break;
         case TILE_64x128_S5: launch_tile<64, 128, 1, 4, 5>(a, general, s); break;
         case TILE_128x128_S6: launch_tile<128, 128, 2, 2, 6>(a, general, s); break;
+        case TILE_K64_128x128_S2: launch_k64<128, 128, 2, 2, 2>(a, s); break;
+        case TILE_K64_128x128_S3: launch_k64<128, 128, 2, 2, 3>(a, s); break;
+        case TILE_K64_128x64_S3: launch_k64<128, 64, 2, 2, 3>(a, s); break;
+        case TILE_K64_64x128_S3: launch_k64<64, 128, 1, 4, 3>(a, s); break;
+        case TILE_K64_64x64_S3: launch_k64<64, 64, 2, 2, 3>(a, s); break;
+        case TILE_K64_64x64_S4: launch_k64<64, 64, 2, 2, 4>(a, s); break;
+        case TILE_K64_256x64_S2: launch_k64<256, 64, 4, 1, 2>(a, s); break;
         case TILE_WSK_64x64: launch_wsk<64, 64>(a, general, s); break;
         case TILE_WSK_32x64: launch_wsk<32, 64>(a, general, s); break;
         case TILE_WSK_64x32: launch_wsk<64, 32>(a, general, s); break;

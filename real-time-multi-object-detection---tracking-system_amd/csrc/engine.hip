@@ -268,11 +268,12 @@ static int pick_tile(int M, int cout) {
         int t = atoi(e);
         if (t >= 0 && t < TILE_COUNT) return t;
     }
-    static const float eff[TILE_COUNT] = {1.0f, 0.85f, 0.62f, 0.75f, 0.85f, 0.5f, 0.4f, 0.4f, 1.05f, 0.9f, 0.65f, 0.9f, 1.0f};
-    static const int occ[TILE_COUNT] = {3, 5, 8, 4, 5, 2, 3, 3, 2, 2, 3, 2, 1};
+    static const float eff[TILE_COUNT] = {1.0f, 0.85f, 0.62f, 0.75f, 0.85f, 0.5f, 0.4f, 0.4f, 1.05f, 0.9f, 0.65f, 0.9f, 1.0f, 0, 0, 0, 0, 0, 0, 0};
+    static const int occ[TILE_COUNT] = {3, 5, 8, 4, 5, 2, 3, 3, 2, 2, 3, 2, 1, 1, 1, 1, 1, 1, 1, 1};
     int best = 0;
     double best_cost = 1e30;
     for (int t = 0; t < TILE_COUNT; ++t) {
+        if (eff[t] <= 0.f) continue;                       // only reachable through the autotuner
         TileShape ts = tile_shape(t);
         long nblk = (long)cdiv(M, ts.bm) * cdiv(cout, ts.bn);
         long slots = 256L * occ[t];
@@ -528,6 +529,7 @@ static int autotune_ops(rtmodt_detector *d, std::vector<Op> &ops) {
         float best = 1e30f;
         int best_tile = op.conv.tile;
         for (int t = 0; t < TILE_COUNT; ++t) {
+            if (tile_needs_cin64(t) && (op.conv.cin % 64 != 0 || op.conv.kp % 64 != 0)) continue;
             op.conv.tile = t;
             for (int w = 0; w < 2; ++w) RT_TRY(launch_conv(op.conv, d->stream));
             float ms_min = 1e30f;

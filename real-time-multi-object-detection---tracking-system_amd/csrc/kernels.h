@@ -25,9 +25,12 @@ enum ConvTile {
     TILE_128x128 = 0, TILE_128x64 = 1, TILE_64x64 = 2, TILE_256x32 = 3, TILE_64x128 = 4,   // 4 waves share one tile
     TILE_WSK_64x64 = 5, TILE_WSK_32x64 = 6, TILE_WSK_64x32 = 7,                           // 4 waves split K over one tile
     TILE_128x128_S4 = 8, TILE_128x64_S5 = 9, TILE_64x64_S6 = 10, TILE_64x128_S5 = 11, TILE_128x128_S6 = 12,   // deeper DMA pipelines
-    TILE_COUNT = 13
+    TILE_K64_128x128_S2 = 13, TILE_K64_128x128_S3 = 14, TILE_K64_128x64_S3 = 15, TILE_K64_64x128_S3 = 16,   // 64-deep k-steps (cin % 64 == 0)
+    TILE_K64_64x64_S3 = 17, TILE_K64_64x64_S4 = 18, TILE_K64_256x64_S2 = 19,
+    TILE_COUNT = 20
 };
 const char *tile_name(int tile);
+bool tile_needs_cin64(int tile);
 struct TileShape { int bm, bn; };
 TileShape tile_shape(int tile);
 
