@@ -21,6 +21,8 @@
 //                  pixel, weights wave-uniform (scalar loads), fp32 accumulate.
 //  * sppf_pool  -- the three chained 5x5 max-pools of SPPF as 5/9/13 windows from one LDS tile.
 //  * upsample2  -- nearest 2x into a channel slice of the concat tensor.
+#include <algorithm>
+
 #include "kernels.h"
 
 namespace rtmodt {
@@ -151,7 +153,7 @@ __device__ __forceinline__ void wait_steps(int steps) {
 }
 
 template <int BM, int BN, int WM, int WN, int NSTAGE, bool GENERAL>
-__global__ __launch_bounds__(256) void conv_mfma(ConvArgs p) {
+__device__ __forceinline__ void conv_mfma_body(const ConvArgs &p, const int bx, const int by) {
     static_assert(WM * WN == 4, "4 waves per workgroup");
     static_assert(BM % 64 == 0 && BN % 16 == 0, "tile shape");
     constexpr int NA = BM / 16, NB = BN / 16, NRB = NA + NB;
@@ -168,7 +170,7 @@ __global__ __launch_bounds__(256) void conv_mfma(ConvArgs p) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r = lane & 15, q = lane >> 4;
     const LaneMap lm(lane);
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const int m0 = bx * BM, n0 = by * BN;
 
     // ---- loader set-up: element offsets of this lane's 16-byte chunk in each piece ----
     int a_off[LA];
@@ -248,7 +250,7 @@ __global__ __launch_bounds__(256) void conv_mfma(ConvArgs p) {
 // ds_read_b128 for both k-substeps.
 // ---------------------------------------------------------------------------------------
 template <int BM, int BN, int WM, int WN, int NSTAGE>
-__global__ __launch_bounds__(256) void conv_mfma64(ConvArgs p) {
+__device__ __forceinline__ void conv_mfma64_body(const ConvArgs &p, const int bx, const int by) {
     static_assert(WM * WN == 4, "4 waves per workgroup");
     static_assert(BM % 32 == 0 && BN % 32 == 0, "tile shape");
     constexpr int NA = BM / 8, NB = BN / 8, NP = NA + NB;   // pieces per k-step
@@ -262,7 +264,7 @@ __global__ __launch_bounds__(256) void conv_mfma64(ConvArgs p) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r = lane & 15, q = lane >> 4;
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const int m0 = bx * BM, n0 = by * BN;
     // DMA lane map: row8 = lane>>3 of the piece, slot = lane&7
     const int ld_row8 = lane >> 3, ld_slot = lane & 7;
     // fragment read offsets inside a 16-row tile (two pieces) for the two k-substeps
@@ -351,7 +353,7 @@ __global__ __launch_bounds__(256) void conv_mfma64(ConvArgs p) {
 // the k-parallelism per CU exactly where a 64-wide tile leaves most CUs waiting on memory.
 // ---------------------------------------------------------------------------------------
 template <int BM, int BN, bool GENERAL>
-__global__ __launch_bounds__(256) void conv_mfma_wsk(ConvArgs p) {
+__device__ __forceinline__ void conv_mfma_wsk_body(const ConvArgs &p, const int bx, const int by) {
     constexpr int NA = BM / 16, NB = BN / 16, NP = NA + NB;
     constexpr int WSTAGE = NP * 1024;
     constexpr int TM = NA, TN = NB;
@@ -364,7 +366,7 @@ __global__ __launch_bounds__(256) void conv_mfma_wsk(ConvArgs p) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r = lane & 15, q = lane >> 4;
     const LaneMap lm(lane);
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const int m0 = bx * BM, n0 = by * BN;
     unsigned char *wbase = lds + wave * 2 * WSTAGE;
 
     int a_off[NA], b_off[NB];
@@ -434,6 +436,37 @@ __global__ __launch_bounds__(256) void conv_mfma_wsk(ConvArgs p) {
     }
 }
 
+// ---- kernel entry points: one problem per launch, or a GROUP of independent problems that
+// share a tile configuration (blockIdx.z picks the problem; surplus blocks of the smaller
+// problems exit at once).  Grouping turns the Detect head's 15 small launches into 3.
+constexpr int MAX_GROUP = 6;
+struct ConvGroupArgs { ConvArgs p[MAX_GROUP]; };
+
+template <int BM, int BN, int WM, int WN, int NSTAGE, bool GENERAL>
+__global__ __launch_bounds__(256) void conv_mfma(ConvArgs p) { conv_mfma_body<BM, BN, WM, WN, NSTAGE, GENERAL>(p, blockIdx.x, blockIdx.y); }
+template <int BM, int BN, int WM, int WN, int NSTAGE, bool GENERAL>
+__global__ __launch_bounds__(256) void conv_mfma_grp(ConvGroupArgs g) {
+    const ConvArgs &p = g.p[blockIdx.z];
+    if ((int)blockIdx.x * BM >= p.M || (int)blockIdx.y * BN >= p.cout) return;
+    conv_mfma_body<BM, BN, WM, WN, NSTAGE, GENERAL>(p, blockIdx.x, blockIdx.y);
+}
+template <int BM, int BN, int WM, int WN, int NSTAGE>
+__global__ __launch_bounds__(256) void conv_mfma64(ConvArgs p) { conv_mfma64_body<BM, BN, WM, WN, NSTAGE>(p, blockIdx.x, blockIdx.y); }
+template <int BM, int BN, int WM, int WN, int NSTAGE>
+__global__ __launch_bounds__(256) void conv_mfma64_grp(ConvGroupArgs g) {
+    const ConvArgs &p = g.p[blockIdx.z];
+    if ((int)blockIdx.x * BM >= p.M || (int)blockIdx.y * BN >= p.cout) return;
+    conv_mfma64_body<BM, BN, WM, WN, NSTAGE>(p, blockIdx.x, blockIdx.y);
+}
+template <int BM, int BN, bool GENERAL>
+__global__ __launch_bounds__(256) void conv_mfma_wsk(ConvArgs p) { conv_mfma_wsk_body<BM, BN, GENERAL>(p, blockIdx.x, blockIdx.y); }
+template <int BM, int BN, bool GENERAL>
+__global__ __launch_bounds__(256) void conv_mfma_wsk_grp(ConvGroupArgs g) {
+    const ConvArgs &p = g.p[blockIdx.z];
+    if ((int)blockIdx.x * BM >= p.M || (int)blockIdx.y * BN >= p.cout) return;
+    conv_mfma_wsk_body<BM, BN, GENERAL>(p, blockIdx.x, blockIdx.y);
+}
+
 const char *tile_name(int tile) {
     static const char *names[TILE_COUNT] = {"128x128s3", "128x64s3", "64x64s3", "256x32s3", "64x128s3", "wsk64x64", "wsk32x64", "wsk64x32",
                                             "128x128s4", "128x64s5", "64x64s6", "64x128s5", "128x128s6",
@@ -466,31 +499,53 @@ TileShape tile_shape(int tile) {
     return {0, 0};
 }
 
+struct LaunchPlan { const ConvArgs *a; int n; bool general; dim3 grid(int bm, int bn) const {
+    int gx = 0, gy = 0;
+    for (int i = 0; i < n; ++i) { gx = std::max(gx, cdiv(a[i].M, bm)); gy = std::max(gy, cdiv(a[i].cout, bn)); }
+    return dim3(gx, gy, n);
+} };
+
 template <int BM, int BN, int WM, int WN, int NSTAGE>
-static void launch_tile(const ConvArgs &a, bool general, hipStream_t s) {
-    dim3 grid(cdiv(a.M, BM), cdiv(a.cout, BN));
-    if (general)
-        hipLaunchKernelGGL((conv_mfma<BM, BN, WM, WN, NSTAGE, true>), grid, dim3(256), 0, s, a);
-    else
-        hipLaunchKernelGGL((conv_mfma<BM, BN, WM, WN, NSTAGE, false>), grid, dim3(256), 0, s, a);
+static void launch_tile(const LaunchPlan &l, hipStream_t s) {
+    dim3 grid = l.grid(BM, BN);
+    if (l.n == 1) {
+        if (l.general) hipLaunchKernelGGL((conv_mfma<BM, BN, WM, WN, NSTAGE, true>), grid, dim3(256), 0, s, l.a[0]);
+        else hipLaunchKernelGGL((conv_mfma<BM, BN, WM, WN, NSTAGE, false>), grid, dim3(256), 0, s, l.a[0]);
+    } else {
+        ConvGroupArgs g;
+        for (int i = 0; i < l.n; ++i) g.p[i] = l.a[i];
+        if (l.general) hipLaunchKernelGGL((conv_mfma_grp<BM, BN, WM, WN, NSTAGE, true>), grid, dim3(256), 0, s, g);
+        else hipLaunchKernelGGL((conv_mfma_grp<BM, BN, WM, WN, NSTAGE, false>), grid, dim3(256), 0, s, g);
+    }
 }
 
 template <int BM, int BN, int WM, int WN, int NSTAGE>
-static void launch_k64(const ConvArgs &a, hipStream_t s) {
-    dim3 grid(cdiv(a.M, BM), cdiv(a.cout, BN));
-    hipLaunchKernelGGL((conv_mfma64<BM, BN, WM, WN, NSTAGE>), grid, dim3(256), 0, s, a);
+static void launch_k64(const LaunchPlan &l, hipStream_t s) {
+    dim3 grid = l.grid(BM, BN);
+    if (l.n == 1) {
+        hipLaunchKernelGGL((conv_mfma64<BM, BN, WM, WN, NSTAGE>), grid, dim3(256), 0, s, l.a[0]);
+    } else {
+        ConvGroupArgs g;
+        for (int i = 0; i < l.n; ++i) g.p[i] = l.a[i];
+        hipLaunchKernelGGL((conv_mfma64_grp<BM, BN, WM, WN, NSTAGE>), grid, dim3(256), 0, s, g);
+    }
 }
 
 template <int BM, int BN>
-static void launch_wsk(const ConvArgs &a, bool general, hipStream_t s) {
-    dim3 grid(cdiv(a.M, BM), cdiv(a.cout, BN));
-    if (general)
-        hipLaunchKernelGGL((conv_mfma_wsk<BM, BN, true>), grid, dim3(256), 0, s, a);
-    else
-        hipLaunchKernelGGL((conv_mfma_wsk<BM, BN, false>), grid, dim3(256), 0, s, a);
+static void launch_wsk(const LaunchPlan &l, hipStream_t s) {
+    dim3 grid = l.grid(BM, BN);
+    if (l.n == 1) {
+        if (l.general) hipLaunchKernelGGL((conv_mfma_wsk<BM, BN, true>), grid, dim3(256), 0, s, l.a[0]);
+        else hipLaunchKernelGGL((conv_mfma_wsk<BM, BN, false>), grid, dim3(256), 0, s, l.a[0]);
+    } else {
+        ConvGroupArgs g;
+        for (int i = 0; i < l.n; ++i) g.p[i] = l.a[i];
+        if (l.general) hipLaunchKernelGGL((conv_mfma_wsk_grp<BM, BN, true>), grid, dim3(256), 0, s, g);
+        else hipLaunchKernelGGL((conv_mfma_wsk_grp<BM, BN, false>), grid, dim3(256), 0, s, g);
+    }
 }
 
-int launch_conv(const ConvLaunch &c, hipStream_t s) {
+static int make_args(const ConvLaunch &c, ConvArgs &a) {
     RT_CHECK(c.in.base && c.out.base && c.wt && c.bias, RTMODT_E_INVALID, "launch_conv: null operand");
     RT_CHECK(c.ks == 1 || c.ks == 3, RTMODT_E_INVALID, "launch_conv: kernel size %d", c.ks);
     RT_CHECK(c.cin % 8 == 0 && c.cout % 4 == 0, RTMODT_E_INVALID, "launch_conv: cin %d / cout %d granularity", c.cin, c.cout);
@@ -498,7 +553,6 @@ int launch_conv(const ConvLaunch &c, hipStream_t s) {
     RT_CHECK(c.in.c == c.cin && c.out.c == c.cout, RTMODT_E_INVALID, "launch_conv: view/channel mismatch");
     RT_CHECK(c.in.coff % 8 == 0 && c.out.coff % 4 == 0 && c.in.C % 8 == 0 && c.out.C % 4 == 0, RTMODT_E_INVALID,
              "launch_conv: slice alignment");
-    ConvArgs a;
     a.in = c.in.base + c.in.coff;
     a.wt = c.wt;
     a.bias = c.bias;
@@ -522,88 +576,109 @@ int launch_conv(const ConvLaunch &c, hipStream_t s) {
     // 32-bit element offsets inside the kernel
     RT_CHECK((long)c.B * a.in_Hp * a.in_Wp * a.in_cs < (1L << 31) && (long)c.B * a.out_Hp * a.out_Wp * a.out_cs < (1L << 31),
              RTMODT_E_INVALID, "launch_conv: tensor exceeds 2^31 elements");
-    const bool general = (c.cin % 32) != 0;
-    if (tile_needs_cin64(c.tile)) RT_CHECK(c.cin % 64 == 0 && a.kp % 64 == 0, RTMODT_E_INVALID, "launch_conv: tile %s needs cin %% 64 == 0 (cin %d)", tile_name(c.tile), c.cin);
-    switch (c.tile) {
-        case TILE_128x128: launch_tile<128, 128, 2, 2, 3>(a, general, s); break;
-        case TILE_128x64: launch_tile<128, 64, 2, 2, 3>(a, general, s); break;
-        case TILE_64x64: launch_tile<64, 64, 2, 2, 3>(a, general, s); break;
-        case TILE_256x32: launch_tile<256, 32, 4, 1, 3>(a, general, s); break;
-        case TILE_64x128: launch_tile<64, 128, 1, 4, 3>(a, general, s); break;
-        case TILE_128x128_S4: launch_tile<128, 128, 2, 2, 4>(a, general, s); break;
-        case TILE_128x64_S5: launch_tile<128, 64, 2, 2, 5>(a, general, s); break;
-        case TILE_64x64_S6: launch_tile<64, 64, 2, 2, 6>(a, general, s); break;
-        case TILE_64x128_S5: launch_tile<64, 128, 1, 4, 5>(a, general, s); break;
-        case TILE_128x128_S6: launch_tile<128, 128, 2, 2, 6>(a, general, s); break;
-        case TILE_K64_128x128_S2: launch_k64<128, 128, 2, 2, 2>(a, s); break;
-        case TILE_K64_128x128_S3: launch_k64<128, 128, 2, 2, 3>(a, s); break;
-        case TILE_K64_128x64_S3: launch_k64<128, 64, 2, 2, 3>(a, s); break;
-        case TILE_K64_64x128_S3: launch_k64<64, 128, 1, 4, 3>(a, s); break;
-        case TILE_K64_64x64_S3: launch_k64<64, 64, 2, 2, 3>(a, s); break;
-        case TILE_K64_64x64_S4: launch_k64<64, 64, 2, 2, 4>(a, s); break;
-        case TILE_K64_256x64_S2: launch_k64<256, 64, 4, 1, 2>(a, s); break;
-        case TILE_WSK_64x64: launch_wsk<64, 64>(a, general, s); break;
-        case TILE_WSK_32x64: launch_wsk<32, 64>(a, general, s); break;
-        case TILE_WSK_64x32: launch_wsk<64, 32>(a, general, s); break;
-        default: return fail(RTMODT_E_INVALID, "launch_conv: tile %d", c.tile);
+    return RTMODT_OK;
+}
+
+// n independent convolutions in ONE launch with tile configuration `tile`
+int launch_conv_group(const ConvLaunch *c, int n, int tile, hipStream_t s) {
+    RT_CHECK(n >= 1 && n <= MAX_GROUP, RTMODT_E_INVALID, "launch_conv_group: %d problems", n);
+    ConvArgs a[MAX_GROUP];
+    bool general = false;
+    for (int i = 0; i < n; ++i) {
+        RT_TRY(make_args(c[i], a[i]));
+        general = general || (c[i].cin % 32) != 0;
+        if (tile_needs_cin64(tile))
+            RT_CHECK(c[i].cin % 64 == 0 && a[i].kp % 64 == 0, RTMODT_E_INVALID, "launch_conv: tile %s needs cin %% 64 == 0 (cin %d)", tile_name(tile), c[i].cin);
+    }
+    LaunchPlan l{a, n, general};
+    switch (tile) {
+        case TILE_128x128: launch_tile<128, 128, 2, 2, 3>(l, s); break;
+        case TILE_128x64: launch_tile<128, 64, 2, 2, 3>(l, s); break;
+        case TILE_64x64: launch_tile<64, 64, 2, 2, 3>(l, s); break;
+        case TILE_256x32: launch_tile<256, 32, 4, 1, 3>(l, s); break;
+        case TILE_64x128: launch_tile<64, 128, 1, 4, 3>(l, s); break;
+        case TILE_WSK_64x64: launch_wsk<64, 64>(l, s); break;
+        case TILE_WSK_32x64: launch_wsk<32, 64>(l, s); break;
+        case TILE_WSK_64x32: launch_wsk<64, 32>(l, s); break;
+        case TILE_128x128_S4: launch_tile<128, 128, 2, 2, 4>(l, s); break;
+        case TILE_128x64_S5: launch_tile<128, 64, 2, 2, 5>(l, s); break;
+        case TILE_64x64_S6: launch_tile<64, 64, 2, 2, 6>(l, s); break;
+        case TILE_64x128_S5: launch_tile<64, 128, 1, 4, 5>(l, s); break;
+        case TILE_128x128_S6: launch_tile<128, 128, 2, 2, 6>(l, s); break;
+        case TILE_K64_128x128_S2: launch_k64<128, 128, 2, 2, 2>(l, s); break;
+        case TILE_K64_128x128_S3: launch_k64<128, 128, 2, 2, 3>(l, s); break;
+        case TILE_K64_128x64_S3: launch_k64<128, 64, 2, 2, 3>(l, s); break;
+        case TILE_K64_64x128_S3: launch_k64<64, 128, 1, 4, 3>(l, s); break;
+        case TILE_K64_64x64_S3: launch_k64<64, 64, 2, 2, 3>(l, s); break;
+        case TILE_K64_64x64_S4: launch_k64<64, 64, 2, 2, 4>(l, s); break;
+        case TILE_K64_256x64_S2: launch_k64<256, 64, 4, 1, 2>(l, s); break;
+        default: return fail(RTMODT_E_INVALID, "launch_conv: tile %d", tile);
     }
     RT_HIP(hipGetLastError());
     return RTMODT_OK;
 }
 
+int launch_conv(const ConvLaunch &c, hipStream_t s) { return launch_conv_group(&c, 1, c.tile, s); }
+
 // ---------------------------------------------------------------------------------------
-// stem: out[b,oy,ox,:] = silu(bias + sum_{kh,kw,c<3} w[(kh*3+kw)*3+c][:] * img[b, 2oy+kh-1, 2ox+kw-1, c])
-// img is the letterboxed RGB0 fp16 image with a 1-pixel zero border (== conv zero padding).
+// stem: 3->cout 3x3/s2 conv on the letterboxed RGB0 fp16 image (1-pixel zero border == the
+// conv's zero padding).  K = 27 is re-indexed so that the matrix cores can take it straight
+// from NHWC4 memory with 16-byte loads and no gather: k' = kh*16 + kw*4 + c with kw in 0..3,
+// c in 0..3 (the 4th tap and the 4th channel meet zero weights), K' = 48 padded to 64 = two
+// v_mfma_f32_16x16x32_f16 steps.  Lane (pixel p, chunk q) of step kk reads the two adjacent
+// pixels (2ox + 2(q&1), +1) of input row 2oy + 2kk + (q>>1): 16 contiguous bytes.
+// One wave owns 16 consecutive output pixels of a row per iteration; weights live in VGPRs.
 // ---------------------------------------------------------------------------------------
-template <int COUT>
-__global__ __launch_bounds__(256) void stem_conv(const f16 *__restrict__ img, int Hp, int Wp, f16 *__restrict__ out,
-                                                 int Ho, int Wo, int oHp, int oWp, int ocs, int opad,
-                                                 const float *__restrict__ w, const float *__restrict__ bias, int total) {
-    int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= total) return;
-    int b = idx / (Ho * Wo), rem = idx - b * (Ho * Wo);
-    int oy = rem / Wo, ox = rem - oy * Wo;
-    float x[27];
+template <int NT>
+__global__ __launch_bounds__(256) void stem_mfma(const f16 *__restrict__ img, int Hp, int Wp, f16 *__restrict__ out, int Ho, int Wo,
+                                                 int oHp, int oWp, int ocs, int opad, const f16 *__restrict__ wm,
+                                                 const float *__restrict__ bias, int groups) {
+    const int lane = threadIdx.x & 63;
+    const int p = lane & 15, q = lane >> 4;
+    half8 wf[NT][2];
 #pragma unroll
-    for (int kh = 0; kh < 3; ++kh)
+    for (int u = 0; u < NT; ++u)
 #pragma unroll
-        for (int kw = 0; kw < 3; ++kw) {
-            half4 v = *(const half4 *)(img + ((long)(b * Hp + 2 * oy + kh) * Wp + 2 * ox + kw) * 4);
-            x[(kh * 3 + kw) * 3 + 0] = (float)v[0];
-            x[(kh * 3 + kw) * 3 + 1] = (float)v[1];
-            x[(kh * 3 + kw) * 3 + 2] = (float)v[2];
+        for (int kk = 0; kk < 2; ++kk) wf[u][kk] = *(const half8 *)(wm + (u * 16 + p) * 64 + kk * 32 + q * 8);
+    floatx4 bv[NT];
+#pragma unroll
+    for (int u = 0; u < NT; ++u) bv[u] = *(const floatx4 *)(bias + u * 16 + q * 4);
+    const int gpr = Wo >> 4;                                   // 16-pixel groups per output row
+    const int wave_global = (blockIdx.x * 256 + threadIdx.x) >> 6;
+    const int n_waves = (gridDim.x * 256) >> 6;
+    for (int g = wave_global; g < groups; g += n_waves) {
+        int row = g / gpr, gx = g - row * gpr;
+        int b = row / Ho, oy = row - b * Ho;
+        int ox = gx * 16 + p;
+        const int kh0 = q >> 1, kh1 = min(2 + (q >> 1), 2);     // k' >= 48 has zero weights: re-read row 2
+        const f16 *base = img + ((long)(b * Hp + 2 * oy) * Wp + 2 * ox + 2 * (q & 1)) * 4;
+        half8 a0 = *(const half8 *)(base + (long)kh0 * Wp * 4);
+        half8 a1 = *(const half8 *)(base + (long)kh1 * Wp * 4);
+        f16 *o = out + ((long)(b * oHp + oy + opad) * oWp + ox + opad) * ocs + q * 4;
+#pragma unroll
+        for (int u = 0; u < NT; ++u) {
+            floatx4 acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[u][0], a0, bv[u], 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[u][1], a1, acc, 0, 0, 0);
+            half4 h = {(f16)silu_f(acc[0]), (f16)silu_f(acc[1]), (f16)silu_f(acc[2]), (f16)silu_f(acc[3])};
+            *(half4 *)(o + u * 16) = h;
         }
-    f16 *o = out + ((long)(b * oHp + oy + opad) * oWp + ox + opad) * ocs;
-#pragma unroll
-    for (int c8 = 0; c8 < COUT; c8 += 8) {
-        float acc[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) acc[j] = bias[c8 + j];
-#pragma unroll
-        for (int k = 0; k < 27; ++k)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) acc[j] = fmaf(x[k], w[k * COUT + c8 + j], acc[j]);
-        half8 hv;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) hv[j] = (f16)silu_f(acc[j]);
-        *(half8 *)(o + c8) = hv;
     }
 }
 
-int launch_stem(const TensorView &img4, const TensorView &out, const float *w, const float *bias, int B, int cout,
-                hipStream_t s) {
+int launch_stem(const TensorView &img4, const TensorView &out, const f16 *wm, const float *bias, int B, int cout, hipStream_t s) {
     RT_CHECK(img4.C == 4 && img4.pad == 1, RTMODT_E_INVALID, "launch_stem: image tensor must be 4-channel with border");
     int Ho = (img4.H - 1) / 2 + 1, Wo = (img4.W - 1) / 2 + 1;
-    RT_CHECK(Ho == out.H && Wo == out.W && out.c == cout && out.coff == 0 && out.C % 8 == 0, RTMODT_E_INVALID, "launch_stem: output shape");
-    int total = B * Ho * Wo;
-    dim3 grid(cdiv(total, 256));
-#define STEM_CASE(NC)                                                                                                \
-    case NC:                                                                                                         \
-        hipLaunchKernelGGL((stem_conv<NC>), grid, dim3(256), 0, s, img4.base, img4.H + 2, img4.W + 2, out.base, Ho, Wo, \
-                           out.H + 2 * out.pad, out.W + 2 * out.pad, out.C, out.pad, w, bias, total);                 \
+    RT_CHECK(Ho == out.H && Wo == out.W && out.c == cout && out.coff == 0 && out.C % 4 == 0, RTMODT_E_INVALID, "launch_stem: output shape");
+    RT_CHECK(Wo % 16 == 0 && img4.W % 2 == 0 && cout % 16 == 0 && cout <= 80, RTMODT_E_UNSUPPORTED, "launch_stem: Wo %d / cout %d", Wo, cout);
+    int groups = B * Ho * (Wo / 16);
+    dim3 grid(std::min(cdiv(groups, 4), 256 * 8));
+#define STEM_CASE(NTILES)                                                                                              \
+    case NTILES:                                                                                                       \
+        hipLaunchKernelGGL((stem_mfma<NTILES>), grid, dim3(256), 0, s, img4.base, img4.H + 2, img4.W + 2, out.base, Ho, Wo, \
+                           out.H + 2 * out.pad, out.W + 2 * out.pad, out.C, out.pad, wm, bias, groups);                 \
         break;
-    switch (cout) {
-        STEM_CASE(16) STEM_CASE(32) STEM_CASE(48) STEM_CASE(64) STEM_CASE(80)
+    switch (cout / 16) {
+        STEM_CASE(1) STEM_CASE(2) STEM_CASE(3) STEM_CASE(4) STEM_CASE(5)
         default: return fail(RTMODT_E_UNSUPPORTED, "launch_stem: cout %d", cout);
     }
 #undef STEM_CASE

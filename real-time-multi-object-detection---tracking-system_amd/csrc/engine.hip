@@ -137,14 +137,16 @@ static void build_resize_tables(int dst, int src, std::vector<int32_t> &ofs, std
 // ------------------------------------------------------------------ graph description
 struct Tensor { f16 *ptr = nullptr; int H, W, C, pad; size_t per_image; };
 
-enum OpKind { OP_STEM, OP_CONV, OP_POOL, OP_UP };
+enum OpKind { OP_STEM, OP_CONV, OP_POOL, OP_UP, OP_GROUP };
 
 struct Op {
     OpKind kind;
     std::string name;
     ConvLaunch conv;                 // OP_CONV
+    std::vector<ConvLaunch> group;   // OP_GROUP: independent convs issued as one launch
+    int group_tile = TILE_64x64;
     TensorView v[4];                 // STEM: in,out; POOL: y,p1,p2,p3; UP: in,out
-    const float *stem_w = nullptr, *stem_b = nullptr;
+    const f16 *stem_w = nullptr; const float *stem_b = nullptr;
     int64_t flops = 0;               // per frame
     int B = 1;                       // images this launch covers
     int head_level = -1;             // >= 0: belongs to the Detect branch of that level (independent of the other levels)
@@ -259,6 +261,7 @@ static Op sub_batch(const Op &op, int b0, int nb) {
     };
     o.B = nb;
     if (o.kind == OP_CONV) { shift(o.conv.in); shift(o.conv.out); shift(o.conv.res); o.conv.B = nb; }
+    else if (o.kind == OP_GROUP) for (auto &c : o.group) { shift(c.in); shift(c.out); shift(c.res); c.B = nb; }
     else for (auto &v : o.v) shift(v);
     return o;
 }
@@ -288,7 +291,8 @@ static int pick_tile(int M, int cout) {
 
 // upload a fused conv (one or more records concatenated along cout) in the MFMA layout
 static int make_conv(rtmodt_detector *d, WeightFile &wf, const std::vector<std::string> &names, const std::string &op_name,
-                     const TensorView &in, const TensorView &out, const TensorView *res, int cout_pad4) {
+                     const TensorView &in, const TensorView &out, const TensorView *res, int cout_pad4,
+                     std::vector<Op> *dst = nullptr) {
     std::vector<const WeightRec *> rs;
     for (auto &n : names) {
         auto it = wf.recs.find(n);
@@ -326,7 +330,7 @@ static int make_conv(rtmodt_detector *d, WeightFile &wf, const std::vector<std::
     int M = d->B * out.H * out.W;
     c.tile = pick_tile(M, cout_eff);
     op.flops = 2LL * out.H * out.W * cout * K;
-    d->ops.push_back(op);
+    (dst ? *dst : d->ops).push_back(op);
     int off = 0;
     for (auto *r : rs) {
         TensorView lv = out; lv.coff = out.coff + off; lv.c = r->cout;
@@ -373,14 +377,16 @@ static int build_graph(rtmodt_detector *d, WeightFile &wf) {
         RT_CHECK(it != wf.recs.end(), RTMODT_E_IO, "weight file lacks conv 0");
         const WeightRec &r = it->second;
         RT_CHECK(r.cin == 3 && r.k == 3 && r.stride == 2 && r.cout == c1, RTMODT_E_IO, "stem conv shape mismatch");
-        std::vector<float> w(27 * (size_t)c1);
+        std::vector<f16> w(64 * (size_t)c1, (f16)0.0f);   // [cout][k' = kh*16 + kw*4 + c], zero elsewhere
         for (int o = 0; o < c1; ++o)
-            for (int k = 0; k < 27; ++k) w[(size_t)k * c1 + o] = (float)r.w[(size_t)o * 27 + k];
+            for (int kh = 0; kh < 3; ++kh)
+                for (int kw = 0; kw < 3; ++kw)
+                    for (int c = 0; c < 3; ++c) w[(size_t)o * 64 + kh * 16 + kw * 4 + c] = r.w[(size_t)o * 27 + (kh * 3 + kw) * 3 + c];
         void *dw, *db;
-        RT_TRY(upload(d, w.data(), w.size() * 4, &dw));
+        RT_TRY(upload(d, w.data(), w.size() * sizeof(f16), &dw));
         RT_TRY(upload(d, r.b.data(), r.b.size() * 4, &db));
         Op op; op.kind = OP_STEM; op.name = "0";
-        op.v[0] = V(d->img_t); op.v[1] = V(t0); op.stem_w = (const float *)dw; op.stem_b = (const float *)db;
+        op.v[0] = V(d->img_t); op.v[1] = V(t0); op.stem_w = (const f16 *)dw; op.stem_b = (const float *)db;
         op.flops = 2LL * (H / 2) * (W / 2) * c1 * 27;
         d->ops.push_back(op);
         d->layer_out["0"] = V(t0);
@@ -434,21 +440,44 @@ static int build_graph(rtmodt_detector *d, WeightFile &wf) {
     const int cbox = std::max(16, std::max(c3 / 4, 64)), ccls = std::max(c3, std::min(d->nc, 100));
     const int nc4 = (int)align_up(d->nc, 4), no = 64 + (int)align_up(d->nc, 8);
     const int src[3] = {t15, t18, t21};
+    std::vector<Op> hops;                                   // 5 convs per level: A, B2, B3, C2, C3
     for (int l = 0; l < 3; ++l) {
         const Tensor &s = d->tensors[src[l]];
         std::string L = std::to_string(l);
         int hA = T(s.H, s.W, cbox + ccls, 1);
-        RT_TRY(make_conv(d, wf, {"22.cv2." + L + ".0", "22.cv3." + L + ".0"}, "22.cv2+cv3." + L + ".0", V(src[l]), V(hA), nullptr, 0));
+        RT_TRY(make_conv(d, wf, {"22.cv2." + L + ".0", "22.cv3." + L + ".0"}, "22.cv2+cv3." + L + ".0", V(src[l]), V(hA), nullptr, 0, &hops));
         int hB2 = T(s.H, s.W, cbox, 0), hB3 = T(s.H, s.W, ccls, 0);
-        RT_TRY(make_conv(d, wf, {"22.cv2." + L + ".1"}, "22.cv2." + L + ".1", V(hA, 0, cbox), V(hB2), nullptr, 0));
-        RT_TRY(make_conv(d, wf, {"22.cv3." + L + ".1"}, "22.cv3." + L + ".1", V(hA, cbox, ccls), V(hB3), nullptr, 0));
+        RT_TRY(make_conv(d, wf, {"22.cv2." + L + ".1"}, "22.cv2." + L + ".1", V(hA, 0, cbox), V(hB2), nullptr, 0, &hops));
+        RT_TRY(make_conv(d, wf, {"22.cv3." + L + ".1"}, "22.cv3." + L + ".1", V(hA, cbox, ccls), V(hB3), nullptr, 0, &hops));
         d->head_t[l] = T(s.H, s.W, no, 0);
-        RT_TRY(make_conv(d, wf, {"22.cv2." + L + ".2"}, "22.cv2." + L + ".2", V(hB2), V(d->head_t[l], 0, 64), nullptr, 0));
-        RT_TRY(make_conv(d, wf, {"22.cv3." + L + ".2"}, "22.cv3." + L + ".2", V(hB3), V(d->head_t[l], 64, nc4), nullptr, 1));
+        RT_TRY(make_conv(d, wf, {"22.cv2." + L + ".2"}, "22.cv2." + L + ".2", V(hB2), V(d->head_t[l], 0, 64), nullptr, 0, &hops));
+        RT_TRY(make_conv(d, wf, {"22.cv3." + L + ".2"}, "22.cv3." + L + ".2", V(hB3), V(d->head_t[l], 64, nc4), nullptr, 1, &hops));
+    }
+    // Detect head launches: 0 = 15 separate convs; 1 = the two branches of a level share a launch
+    // (9 launches); 2 = every level and branch of a stage in one launch (3 launches)
+    int grouping = 2;
+    if (const char *e = getenv("RTMODT_HEAD_GROUP")) grouping = atoi(e);
+    auto add_group = [&](const std::string &name, std::initializer_list<int> idx) {
+        Op g; g.kind = OP_GROUP; g.name = name;
+        for (int i : idx) { g.group.push_back(hops[i].conv); g.flops += hops[i].flops; }
+        d->ops.push_back(g);
+    };
+    if (grouping == 2) {
+        add_group("22.stage0 (cv2+cv3 x3 levels)", {0, 5, 10});
+        add_group("22.stage1 (6 convs)", {1, 2, 6, 7, 11, 12});
+        add_group("22.stage2 (6 convs)", {3, 4, 8, 9, 13, 14});
+    } else if (grouping == 1) {
+        for (int l = 0; l < 3; ++l) {
+            d->ops.push_back(hops[5 * l]);
+            add_group("22.L" + std::to_string(l) + ".1 (cv2+cv3)", {5 * l + 1, 5 * l + 2});
+            add_group("22.L" + std::to_string(l) + ".2 (cv2+cv3)", {5 * l + 3, 5 * l + 4});
+        }
+    } else {
+        for (auto &h : hops) d->ops.push_back(h);
     }
     for (auto &op : d->ops) {
         op.B = d->B;
-        if (op.name.rfind("22.", 0) == 0) {                // "22.cv2+cv3.<l>.0", "22.cv3.<l>.2": level = next-to-last field
+        if (op.kind == OP_CONV && op.name.rfind("22.", 0) == 0) {   // "22.cv2+cv3.<l>.0", "22.cv3.<l>.2": level = next-to-last field
             size_t last = op.name.rfind('.'), prev = op.name.rfind('.', last - 1);
             op.head_level = atoi(op.name.substr(prev + 1, last - prev - 1).c_str());
         }
@@ -468,6 +497,8 @@ static int build_graph(rtmodt_detector *d, WeightFile &wf) {
         if (op.kind == OP_CONV) {
             rebase(op.conv.in); rebase(op.conv.out);
             if (op.conv.res.c) rebase(op.conv.res);
+        } else if (op.kind == OP_GROUP) {
+            for (auto &c : op.group) { rebase(c.in); rebase(c.out); if (c.res.c) rebase(c.res); }
         } else {
             for (auto &v : op.v) if (v.c) rebase(v);
         }
@@ -491,6 +522,7 @@ static int run_op_on(const Op &op, hipStream_t s) {
     switch (op.kind) {
         case OP_STEM: return launch_stem(op.v[0], op.v[1], op.stem_w, op.stem_b, op.B, op.v[1].c, s);
         case OP_CONV: return launch_conv(op.conv, s);
+        case OP_GROUP: return launch_conv_group(op.group.data(), (int)op.group.size(), op.group_tile, s);
         case OP_POOL: return launch_sppf_pool(op.v[0], op.v[1], op.v[2], op.v[3], op.B, s);
         case OP_UP: return launch_upsample2(op.v[0], op.v[1], op.B, s);
     }
@@ -506,6 +538,7 @@ static int run_decode(rtmodt_detector *d) {
         a.lvl[l] = HeadLevel{t.ptr, t.H, t.W, strides[l]};
     }
     a.B = d->B; a.nc = d->nc; a.n_anchors = d->n_anchors; a.conf = d->cfg.conf;
+    a.no = d->tensors[d->head_t[0]].C;
     a.class_mask[0] = d->class_mask[0]; a.class_mask[1] = d->class_mask[1];
     const rtmodt_detector::Dense &dn = d->dense[d->cur_dense];
     a.box = dn.box; a.score = dn.score; a.cls = dn.cls;
@@ -525,26 +558,35 @@ static int autotune_ops(rtmodt_detector *d, std::vector<Op> &ops) {
     hipEvent_t e0, e1;
     RT_HIP(hipEventCreate(&e0)); RT_HIP(hipEventCreate(&e1));
     for (auto &op : ops) {
-        if (op.kind != OP_CONV) continue;
-        float best = 1e30f;
-        int best_tile = op.conv.tile;
-        for (int t = 0; t < TILE_COUNT; ++t) {
-            if (tile_needs_cin64(t) && (op.conv.cin % 64 != 0 || op.conv.kp % 64 != 0)) continue;
+        if (op.kind != OP_CONV && op.kind != OP_GROUP) continue;
+        const bool grp = op.kind == OP_GROUP;
+        bool cin64 = true;
+        if (grp) { for (auto &c : op.group) cin64 = cin64 && c.cin % 64 == 0 && c.kp % 64 == 0; }
+        else cin64 = op.conv.cin % 64 == 0 && op.conv.kp % 64 == 0;
+        auto launch = [&](int t) -> int {
+            if (grp) return launch_conv_group(op.group.data(), (int)op.group.size(), t, d->stream);
             op.conv.tile = t;
-            for (int w = 0; w < 2; ++w) RT_TRY(launch_conv(op.conv, d->stream));
+            return launch_conv(op.conv, d->stream);
+        };
+        float best = 1e30f;
+        int best_tile = grp ? op.group_tile : op.conv.tile;
+        for (int t = 0; t < TILE_COUNT; ++t) {
+            if (tile_needs_cin64(t) && !cin64) continue;
+            for (int w = 0; w < 2; ++w) RT_TRY(launch(t));
             float ms_min = 1e30f;
             for (int rep = 0; rep < 3; ++rep) {
                 RT_HIP(hipEventRecord(e0, d->stream));
-                for (int k = 0; k < 4; ++k) RT_TRY(launch_conv(op.conv, d->stream));
+                for (int k = 0; k < 4; ++k) RT_TRY(launch(t));
                 RT_HIP(hipEventRecord(e1, d->stream));
                 RT_HIP(hipEventSynchronize(e1));
                 float ms = 0;
                 RT_HIP(hipEventElapsedTime(&ms, e0, e1));
                 ms_min = std::min(ms_min, ms);
             }
+            if (getenv("RTMODT_TUNE_LOG")) fprintf(stderr, "[tune] %-28s %-16s %8.2f us\n", op.name.c_str(), tile_name(t), ms_min * 250.0f);
             if (ms_min < best) { best = ms_min; best_tile = t; }
         }
-        op.conv.tile = best_tile;
+        if (grp) op.group_tile = best_tile; else op.conv.tile = best_tile;
     }
     hipEventDestroy(e0); hipEventDestroy(e1);
     return RTMODT_OK;
@@ -555,9 +597,9 @@ static int autotune_tiles(rtmodt_detector *d) {
     if (d->n_chains > 1) {
         RT_TRY(autotune_ops(d, d->chain_ops[0]));          // the sub-batch GEMMs have their own best tiles
         for (int c = 1; c < d->n_chains; ++c)
-            for (size_t i = 0; i < d->ops.size(); ++i) d->chain_ops[c][i].conv.tile = d->chain_ops[0][i].conv.tile;
+            for (size_t i = 0; i < d->ops.size(); ++i) { d->chain_ops[c][i].conv.tile = d->chain_ops[0][i].conv.tile; d->chain_ops[c][i].group_tile = d->chain_ops[0][i].group_tile; }
     } else {
-        for (size_t i = 0; i < d->ops.size(); ++i) d->chain_ops[0][i].conv.tile = d->ops[i].conv.tile;
+        for (size_t i = 0; i < d->ops.size(); ++i) { d->chain_ops[0][i].conv.tile = d->ops[i].conv.tile; d->chain_ops[0][i].group_tile = d->ops[i].group_tile; }
     }
     // the tuning launches left stale activations; run one clean pass
     RT_TRY(forward_eager(d));
@@ -586,16 +628,18 @@ static int capture_chain(rtmodt_detector *d, int c) {
         for (auto &op : ops) if (op.head_level == level) RT_TRY(run_op_on(op, st));
         return RTMODT_OK;
     };
+    auto has_level = [&](int level) { for (auto &op : ops) if (op.head_level == level) return true; return false; };
+    bool forked0 = false, forked1 = false;
     auto body = [&]() -> int {
         for (auto &op : ops) {
             if (op.head_level >= 0) continue;
             RT_TRY(run_op_on(op, main));
-            if (op.name == "15.cv2") { RT_TRY(fork(main, h0)); RT_TRY(run_head(0, h0)); }
-            if (op.name == "18.cv2") { RT_TRY(fork(main, h1)); RT_TRY(run_head(1, h1)); }
+            if (op.name == "15.cv2" && has_level(0)) { RT_TRY(fork(main, h0)); RT_TRY(run_head(0, h0)); forked0 = true; }
+            if (op.name == "18.cv2" && has_level(1)) { RT_TRY(fork(main, h1)); RT_TRY(run_head(1, h1)); forked1 = true; }
         }
         RT_TRY(run_head(2, main));
-        RT_TRY(fork(h0, main));                            // joins
-        RT_TRY(fork(h1, main));
+        if (forked0) RT_TRY(fork(h0, main));               // joins
+        if (forked1) RT_TRY(fork(h1, main));
         return RTMODT_OK;
     };
     RT_HIP(hipStreamBeginCapture(main, hipStreamCaptureModeRelaxed));
@@ -924,7 +968,7 @@ int rtmodt_detector_info(rtmodt_detector *d, int32_t *scale_id, int32_t *nc, int
     if (n_anchors) *n_anchors = d->n_anchors;
     if (n_convs) {
         int c = 0;
-        for (auto &op : d->ops) c += (op.kind == OP_CONV || op.kind == OP_STEM);
+        for (auto &op : d->ops) c += op.kind == OP_GROUP ? (int)op.group.size() : (op.kind == OP_CONV || op.kind == OP_STEM);
         *n_convs = c;
     }
     if (conv_flops_per_frame) *conv_flops_per_frame = d->flops_per_frame;
@@ -1017,6 +1061,8 @@ int rtmodt_detector_profile(rtmodt_detector *d, int iters, int max_entries, cons
         if (op.kind == OP_CONV) {
             snprintf(buf, sizeof(buf), "%s [M=%d N=%d K=%d k%d s%d tile %s]", op.name.c_str(), d->B * op.conv.out.H * op.conv.out.W,
                      op.conv.cout, op.conv.ks * op.conv.ks * op.conv.cin, op.conv.ks, op.conv.stride, tile_name(op.conv.tile));
+        } else if (op.kind == OP_GROUP) {
+            snprintf(buf, sizeof(buf), "%s [group of %zu, tile %s]", op.name.c_str(), op.group.size(), tile_name(op.group_tile));
         } else {
             snprintf(buf, sizeof(buf), "%s", op.name.c_str());
         }

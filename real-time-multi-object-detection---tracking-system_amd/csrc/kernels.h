@@ -45,9 +45,12 @@ struct ConvLaunch {
 };
 
 int launch_conv(const ConvLaunch &c, hipStream_t s);
+// n (<= 6) independent convolutions sharing one tile configuration, in ONE launch
+int launch_conv_group(const ConvLaunch *c, int n, int tile, hipStream_t s);
 
-// stem: 3x3 stride-2 conv on the 4-channel (RGB0) padded fp16 image, cout in {16,32,48,64,80}
-int launch_stem(const TensorView &img4, const TensorView &out, const float *w27xc, const float *bias, int B,
+// stem: 3x3 stride-2 conv on the 4-channel (RGB0) padded fp16 image, cout in {16,32,48,64,80};
+// wm = [cout][64] fp16 in the k' = kh*16 + kw*4 + c order (zero where kw == 3, c == 3 or k' >= 48)
+int launch_stem(const TensorView &img4, const TensorView &out, const f16 *wm, const float *bias, int B,
                 int cout, hipStream_t s);
 // SPPF: y -> (max5(y), max5(max5(y)), max5^3(y)) written to three channel slices of the same tensor
 int launch_sppf_pool(const TensorView &y, const TensorView &p1, const TensorView &p2, const TensorView &p3, int B,
@@ -75,6 +78,7 @@ struct HeadLevel { const f16 *ptr; int H, W, stride; };   // [B][H][W][64+nc] fp
 struct DecodeArgs {
     HeadLevel lvl[3];
     int B, nc, n_anchors;
+    int no;                    // halves per anchor row in the head tensors (64 + nc rounded up to 8)
     float conf;
     uint64_t class_mask[2];    // allowed classes (bit per class id < 128)
     // per-anchor dense outputs [B][A]

@@ -33,12 +33,19 @@ constexpr int MAX_NMS = 30000;              // ultralytics max_nms
 constexpr float MAX_WH = 7680.0f;           // ultralytics max_wh (per-class coordinate offset)
 
 // ---------------------------------------------------------------------------------------
-// decode: one thread per (image, anchor)
+// decode: FOUR lanes per (image, anchor).  Lane j of the quad owns box side j (16 DFL bins:
+// softmax . arange) and a quarter of the classes; an anchor's 64+nc logits are contiguous in
+// the NHWC head tensor, so a wave reads 16 anchors x (64+nc) halves as one dense run.  The
+// quad combines through two wave shuffles (best class: larger score, then LOWER class id =
+// first maximum).
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void decode_kernel(DecodeArgs a) {
-    long gid = (long)blockIdx.x * 256 + threadIdx.x;
-    if (gid >= (long)a.B * a.n_anchors) return;
-    int b = (int)(gid / a.n_anchors), an = (int)(gid - (long)b * a.n_anchors);
+    const long gid = ((long)blockIdx.x * 256 + threadIdx.x) >> 2;
+    const int j = threadIdx.x & 3;
+    const long total = (long)a.B * a.n_anchors;
+    const bool live = gid < total;
+    const long g = live ? gid : total - 1;                  // dead quads shadow the last anchor (shuffles stay convergent)
+    int b = (int)(g / a.n_anchors), an = (int)(g - (long)b * a.n_anchors);
     int l = 0, local = an;
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
@@ -46,40 +53,54 @@ __global__ __launch_bounds__(256) void decode_kernel(DecodeArgs a) {
         if (l == k && local >= cnt) { local -= cnt; l = k + 1; }
     }
     const HeadLevel L = l == 0 ? a.lvl[0] : (l == 1 ? a.lvl[1] : a.lvl[2]);
-    const int no = 64 + a.nc;
-    const f16 *p = L.ptr + ((long)b * L.H * L.W + local) * no;
+    const f16 *p = L.ptr + ((long)b * L.H * L.W + local) * a.no;
     int gy = local / L.W, gx = local - gy * L.W;
-    float ax = (float)gx + 0.5f, ay = (float)gy + 0.5f;
 
-    float dist[4];
+    // ---- this lane's box side ----
+    float v[16];
+    {
+        typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+        half8 h0 = *(const half8 *)(p + j * 16), h1 = *(const half8 *)(p + j * 16 + 8);
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        float v[16];
-        float mx = -INFINITY;
-#pragma unroll
-        for (int j = 0; j < 16; ++j) { v[j] = (float)p[s * 16 + j]; mx = fmaxf(mx, v[j]); }
-        float sum = 0.f;
-#pragma unroll
-        for (int j = 0; j < 16; ++j) { v[j] = expf(v[j] - mx); sum += v[j]; }
-        float d = 0.f;
-#pragma unroll
-        for (int j = 0; j < 16; ++j) d += (v[j] / sum) * (float)j;
-        dist[s] = d;
+        for (int k = 0; k < 8; ++k) { v[k] = (float)h0[k]; v[8 + k] = (float)h1[k]; }
     }
-    float x1 = ax - dist[0], y1 = ay - dist[1], x2 = ax + dist[2], y2 = ay + dist[3];
+    float mx = v[0];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) mx = fmaxf(mx, v[k]);
+    float sum = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { v[k] = expf(v[k] - mx); sum += v[k]; }
+    float dist = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) dist += (v[k] / sum) * (float)k;
+    // gather l, t, r, b into every lane of the quad
+    const int qbase = (threadIdx.x & 63) & ~3;
+    float dl = __shfl(dist, qbase + 0), dt = __shfl(dist, qbase + 1), dr = __shfl(dist, qbase + 2), db = __shfl(dist, qbase + 3);
+    float ax = (float)gx + 0.5f, ay = (float)gy + 0.5f;
+    float x1 = ax - dl, y1 = ay - dt, x2 = ax + dr, y2 = ay + db;
     float st = (float)L.stride;
     float cx = ((x1 + x2) / 2.0f) * st, cy = ((y1 + y2) / 2.0f) * st;
     float bw = (x2 - x1) * st, bh = (y2 - y1) * st;
 
+    // ---- this lane's quarter of the classes: ids [c0, c1) ----
+    const int per = (a.nc + 3) >> 2;
+    const int c0 = j * per, c1 = min(c0 + per, a.nc);
     float best = -1.0f;
-    int bj = 0;
-    float *pr = a.pred ? a.pred + (long)b * (4 + a.nc) * a.n_anchors + an : nullptr;
-    for (int j = 0; j < a.nc; ++j) {
-        float x = (float)p[64 + j];
+    int bj = c0;
+    float *pr = (a.pred && live) ? a.pred + (long)b * (4 + a.nc) * a.n_anchors + an : nullptr;
+    for (int c = c0; c < c1; ++c) {
+        float x = (float)p[64 + c];
         float sg = 1.0f / (1.0f + expf(-x));
-        if (sg > best) { best = sg; bj = j; }            // first maximum
-        if (pr) pr[(long)(4 + j) * a.n_anchors] = sg;
+        if (sg > best) { best = sg; bj = c; }              // first maximum inside the quarter
+        if (pr) pr[(long)(4 + c) * a.n_anchors] = sg;
     }
+#pragma unroll
+    for (int d = 1; d <= 2; d <<= 1) {
+        float ob = __shfl_xor(best, d);
+        int oj = __shfl_xor(bj, d);
+        if (ob > best || (ob == best && oj < bj)) { best = ob; bj = oj; }
+    }
+    if (!live || j != 0) return;
     if (pr) {
         pr[0] = cx; pr[(long)a.n_anchors] = cy; pr[2L * a.n_anchors] = bw; pr[3L * a.n_anchors] = bh;
     }
@@ -94,7 +115,8 @@ __global__ __launch_bounds__(256) void decode_kernel(DecodeArgs a) {
 int launch_decode(const DecodeArgs &a, hipStream_t s) {
     long total = (long)a.B * a.n_anchors;
     RT_CHECK(a.nc >= 1 && a.nc <= 128, RTMODT_E_UNSUPPORTED, "decode: nc %d", a.nc);
-    hipLaunchKernelGGL(decode_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a);
+    RT_CHECK(a.no % 8 == 0 && a.no >= 64 + a.nc, RTMODT_E_INVALID, "decode: head row stride %d", a.no);
+    hipLaunchKernelGGL(decode_kernel, dim3((unsigned)((total * 4 + 255) / 256)), dim3(256), 0, s, a);
     RT_HIP(hipGetLastError());
     return RTMODT_OK;
 }

@@ -248,7 +248,7 @@ def test_reference_constructor_behaviour(pkg, wdir, tmp_path):
     out = det.detect(np.zeros((160, 160, 3), np.uint8))
     assert len(out) == 0 and out.xyxy.shape == (0, 4) and out.xyxy.dtype == np.float32 and out.class_id.dtype == np.int32
     prof = det.profile(2)
-    assert len(prof) > 60 and all(ms >= 0 for _, ms, _ in prof)
+    assert len(prof) > 40 and all(ms >= 0 for _, ms, _ in prof)
     det.close()
     bad = tmp_path / "bad.rtw"
     bad.write_bytes(b"not a weight file")
