@@ -45,6 +45,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--host-frames", action="store_true", help="feed host (pageable) frames: PCIe-inclusive rate, never the headline value")
     return ap.parse_args()
 
 
@@ -87,22 +88,13 @@ def cpu_baseline(pkg, weights, args, budget_s=20.0):
 
 def main():
     args = parse()
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus != world and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    dist = None
-    torch = None
-    if world > 1:
-        import torch
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-
     import rtmodt_amd  # noqa: F401
     pkg = sys.modules["rtmodt_amd"]
+    sync = pkg.streams.NodeSync(backend="nccl")          # RCCL; no process group when WORLD_SIZE == 1
+    rank, local_rank, world = sync.rank, sync.local_rank, sync.world
+    if args.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
     from importlib import import_module
     core_cls = import_module(pkg.__name__ + ".tracking.tracker")._ByteTrackCore
     dev = local_rank
@@ -116,14 +108,14 @@ def main():
         tmp = wpath + f".{os.getpid()}"
         pkg.weights.save(tmp, weights, args.model)
         os.replace(tmp, wpath)
-    if dist is not None:
-        dist.barrier()
+    sync.barrier()
 
-    # ---- frames resident in HBM: stream s of this rank = global stream rank*S + s, seed 1234 + id ----
+    # ---- frames resident in HBM: this rank owns the global streams {id : id % world == rank}, seed 1234 + id ----
     per = size * size * 3
     ring = pkg._ffi.DeviceBuffer(S * R * per, dev)
-    for s in range(S):
-        ring.upload(pkg.synth.frames(R, size, size, seed=1234 + rank * S + s), offset=s * R * per)
+    my_streams = pkg.streams.shard(S * world, world, rank)
+    for s, gid in enumerate(my_streams):
+        ring.upload(pkg.synth.frames(R, size, size, seed=1234 + gid), offset=s * R * per)
 
     det = pkg.Detector(wpath, input_size=(size, size), max_det=args.max_det, device=f"cuda:{dev}", batch=S,
                        use_graph=not args.no_graph, warmup=False)
@@ -132,8 +124,15 @@ def main():
 
     ptrs = [[ring.ptr + (s * R + r) * per for s in range(S)] for r in range(R)]
 
+    host_ring = None
+    if args.host_frames:
+        host_ring = [[pkg.synth.frames(1, size, size, seed=1234 + gid + 1000 * r)[0] for gid in my_streams] for r in range(4)]
+
     def submit(t):
-        det.enqueue(ptrs[t % R], height=size, width=size)
+        if host_ring is not None:
+            det.enqueue(host_ring[t % 4])               # H2D of 8 x 1.23 MB inside the step
+        else:
+            det.enqueue(ptrs[t % R], height=size, width=size)
         trk.update_from_detector(det)
 
     def step(t):
@@ -143,16 +142,14 @@ def main():
         return det.fetch()
 
     def sync_all():
-        det.synchronize()
-        if torch is not None:
-            torch.cuda.synchronize()
+        det.synchronize()                           # hipDeviceSynchronize through the C ABI
+        sync.device_synchronize()                   # + torch.cuda.synchronize() when torch.distributed is up
 
     submit(0)                                       # prime the pipeline: one batch always in flight
     for t in range(1, args.warmup + 1):
         step(t)
     sync_all()
-    if dist is not None:
-        dist.barrier()
+    sync.barrier()
     sync_all()
     fwd_ms = tot_ms = 0.0
     n_det = 0
@@ -164,24 +161,17 @@ def main():
         fwd_ms += b
         n_det += sum(len(d) for d in out)
     sync_all()
-    if dist is not None:
-        dist.barrier()
+    sync.barrier()
     sync_all()
     elapsed = time.perf_counter() - t0
-    if dist is not None:
-        te = torch.tensor([elapsed], device=f"cuda:{local_rank}", dtype=torch.float64)
-        dist.all_reduce(te, op=dist.ReduceOp.MAX)
-        elapsed = float(te.item())
-        # optional stats reduce: total detections over the node
-        nd = torch.tensor([n_det], device=f"cuda:{local_rank}", dtype=torch.int64)
-        dist.all_reduce(nd)
-        n_det = int(nd.item())
+    elapsed = sync.max_time(elapsed)                # MAX over ranks
     det.fetch()                                      # drain the batch still in flight (outside the timed region)
     n_tracks = sum(len(trk.snapshot(s)["ids"]) for s in range(S))
+    # optional stats reduce: ~24 bytes over RCCL, once per run
+    n_det, n_tracks_node = sync.sum_stats([n_det, n_tracks])
 
     if rank != 0:
-        if dist is not None:
-            dist.destroy_process_group()
+        sync.close()
         return
 
     frames_total = world * S * args.steps
@@ -203,8 +193,17 @@ def main():
                      "kernel": "forward pass = conv_mfma<*> launches (+ stem, SPPF pool, upsample, decode) replayed as one hipGraph",
                      "flops_per_step": int(flops_step), "forward_ms_per_step": round(fwd_ms_step, 4),
                      "device_ms_per_step": round(tot_ms / args.steps, 4)},
-        "detections_per_frame": round(n_det / frames_total, 2), "live_tracks_rank0": n_tracks,
+        "detections_per_frame": round(n_det / frames_total, 2), "live_tracks_node": n_tracks_node,
+        "frames_source": "host memory (PCIe-inclusive, NOT the headline metric)" if args.host_frames else "HBM-resident ring",
     }
+
+    tpath = os.path.join(ROOT, "profiles", "traffic_current.json")
+    if os.path.exists(tpath) and not args.host_frames:
+        tj = json.load(open(tpath))
+        if tj.get("workload_key") == f"{args.model}-{size}-{S}":
+            res["roofline"]["traffic"] = tj["hbm_bytes_per_step"]      # rocprofv3 PMC passes, see profiles/r01/README.md
+            res["roofline"]["traffic_unit"] = "bytes per step (FETCH_SIZE x2 + WRITE_SIZE over the forward-pass launches)"
+            res["roofline"]["traffic_source"] = tj["source"]
 
     # ---- per-kernel view (eager, HIP events around every launch) ----
     prof = det.profile(3)
@@ -238,8 +237,7 @@ def main():
             weights = pkg.weights.load(wpath)[0]
         res["cpu_baseline"] = cpu_baseline(pkg, weights, args)
     print(json.dumps(res), flush=True)
-    if dist is not None:
-        dist.destroy_process_group()
+    sync.close()
 
 
 if __name__ == "__main__":

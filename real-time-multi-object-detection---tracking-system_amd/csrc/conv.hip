@@ -48,6 +48,20 @@ __device__ __forceinline__ float silu_f(float x) {
     return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x));
 }
 
+// XCD-aware tile order (speed only, any placement is correct).  Workgroups are dealt round-robin
+// over the 8 XCDs, each with its own 4 MiB L2; a 3x3 conv re-reads its input 9 times (taps) and
+// once per cout tile, so the tiles an XCD works on should be NEIGHBOURS: the launch-linear id is
+// remapped (bijectively) so that ids congruent mod 8 -- one XCD under round-robin placement --
+// cover one contiguous run of pixel tiles with all their cout tiles.
+__device__ __forceinline__ void xcd_tile(int gx, int gy, int bx, int by, int &mt, int &nt) {
+    const int n = gx * gy, lin = bx + by * gx;
+    const int q = n >> 3, r = n & 7, xcd = lin & 7, k = lin >> 3;
+    const int start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    const int id = start + k;
+    mt = id / gy;
+    nt = id - mt * gy;
+}
+
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -170,7 +184,9 @@ __device__ __forceinline__ void conv_mfma_body(const ConvArgs &p, const int bx, 
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r = lane & 15, q = lane >> 4;
     const LaneMap lm(lane);
-    const int m0 = bx * BM, n0 = by * BN;
+    int mt, nt;
+    xcd_tile((p.M + BM - 1) / BM, (p.cout + BN - 1) / BN, bx, by, mt, nt);
+    const int m0 = mt * BM, n0 = nt * BN;
 
     // ---- loader set-up: element offsets of this lane's 16-byte chunk in each piece ----
     int a_off[LA];
@@ -264,7 +280,9 @@ __device__ __forceinline__ void conv_mfma64_body(const ConvArgs &p, const int bx
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r = lane & 15, q = lane >> 4;
-    const int m0 = bx * BM, n0 = by * BN;
+    int mt, nt;
+    xcd_tile((p.M + BM - 1) / BM, (p.cout + BN - 1) / BN, bx, by, mt, nt);
+    const int m0 = mt * BM, n0 = nt * BN;
     // DMA lane map: row8 = lane>>3 of the piece, slot = lane&7
     const int ld_row8 = lane >> 3, ld_slot = lane & 7;
     // fragment read offsets inside a 16-row tile (two pieces) for the two k-substeps
@@ -366,7 +384,9 @@ __device__ __forceinline__ void conv_mfma_wsk_body(const ConvArgs &p, const int 
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r = lane & 15, q = lane >> 4;
     const LaneMap lm(lane);
-    const int m0 = bx * BM, n0 = by * BN;
+    int mt, nt;
+    xcd_tile((p.M + BM - 1) / BM, (p.cout + BN - 1) / BN, bx, by, mt, nt);
+    const int m0 = mt * BM, n0 = nt * BN;
     unsigned char *wbase = lds + wave * 2 * WSTAGE;
 
     int a_off[NA], b_off[NB];

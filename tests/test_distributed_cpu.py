@@ -1,0 +1,79 @@
+"""CPU, world_size 2 over gloo: the N > 1 layout of the hot path -- streams sharded by
+``stream_id % world``, no data-path collective, barrier + max-time + stats all-reduce -- with
+the pinned tracker oracle standing in for the per-rank GPU work."""
+import socket
+
+import numpy as np
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n_streams, q):
+    import sys
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import rtmodt_amd  # noqa: F401
+    pkg = sys.modules["rtmodt_amd"]
+    from oracle import tracker_oracle as T
+    sync = pkg.streams.NodeSync(world=world, rank=rank, local_rank=rank, backend="gloo", init_method=f"tcp://127.0.0.1:{port}")
+    mine = pkg.streams.shard(n_streams, world, rank)
+    sync.barrier()
+    births = frames = 0
+    digests = {}
+    for sid in mine:                                   # independent streams: nothing crosses ranks
+        xy, cf, cl = pkg.synth.box_sequence(20 + sid, 320, 6, seed=1234 + sid)
+        trk = T.TrackerOracle()
+        for f in range(6):
+            trk.update(xy[f], cf, cl)
+            frames += 1
+        births += trk.next_id - 1
+        digests[sid] = T.state_digest(trk.snapshot()).tolist()
+    sync.barrier()
+    t = sync.max_time(0.25 * (rank + 1))
+    tot = sync.sum_stats([frames, births, len(mine)])
+    q.put((rank, mine, t, tot, digests))
+    sync.close()
+
+
+def test_two_ranks_shard_streams_and_reduce(pkg):
+    world, n_streams = 2, 7
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_streams, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    shards = [r[1] for r in res]
+    assert sorted(shards[0] + shards[1]) == list(range(n_streams))            # every stream exactly once
+    assert all(pkg.streams.owner(s, world) == r for r in range(world) for s in shards[r])
+    assert all(abs(r[2] - 0.5) < 1e-9 for r in res)                           # MAX over ranks
+    assert res[0][3] == res[1][3] == [n_streams * 6, res[0][3][1], n_streams]  # SUM identical on every rank
+    # a stream's result does not depend on which rank ran it
+    from oracle import tracker_oracle as T
+    xy, cf, cl = pkg.synth.box_sequence(20 + 3, 320, 6, seed=1234 + 3)
+    trk = T.TrackerOracle()
+    for f in range(6):
+        trk.update(xy[f], cf, cl)
+    assert res[1][4][3] == T.state_digest(trk.snapshot()).tolist()
+
+
+def test_shard_properties(pkg):
+    for world in (1, 2, 4, 8):
+        got = [pkg.streams.shard(64, world, r) for r in range(world)]
+        assert sorted(sum(got, [])) == list(range(64))
+        assert all(len(g) == 64 // world for g in got)
+    assert pkg.streams.shard(64, 8, 3)[:3] == [3, 11, 19]
+    s = pkg.streams.NodeSync(world=1, rank=0)
+    assert s.max_time(1.5) == 1.5 and s.sum_stats([1, 2]) == [1, 2]
+    s.barrier()
