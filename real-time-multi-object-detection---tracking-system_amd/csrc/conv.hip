@@ -121,8 +121,8 @@ __device__ __forceinline__ void glds16(const f16 *src, unsigned char *dst) {
 
 // fused epilogue for one 16(pixel) x 16(cout) accumulator tile: lane holds pixel (lane&15),
 // channels n .. n+3
-__device__ __forceinline__ void store_tile(const ConvArgs &p, const floatx4 &acc, long opix, long rpix, int n) {
-    floatx4 v = acc + *(const floatx4 *)(p.bias + n);
+__device__ __forceinline__ void store_tile(const ConvArgs &p, const floatx4 &acc, const floatx4 &bias, long opix, long rpix, int n) {
+    floatx4 v = acc + bias;
     if (p.act) { v[0] = silu_f(v[0]); v[1] = silu_f(v[1]); v[2] = silu_f(v[2]); v[3] = silu_f(v[3]); }
     if (p.res) {
         half4 rv = *(const half4 *)(p.res + rpix + n);
@@ -219,6 +219,9 @@ __device__ __forceinline__ void conv_mfma_body(const ConvArgs &p, const int bx, 
     };
 
     const int wm = wave / WN, wn = wave % WN;
+    floatx4 bv[TN];                                        // bias fetched now, consumed after the k-loop (padded to 128 rows)
+#pragma unroll
+    for (int u = 0; u < TN; ++u) bv[u] = *(const floatx4 *)(p.bias + n0 + (wn * TN + u) * 16 + q * 4);
 #pragma unroll
     for (int i = 0; i < DEPTH; ++i)
         if (i < nk) issue(i, i);
@@ -253,7 +256,7 @@ __device__ __forceinline__ void conv_mfma_body(const ConvArgs &p, const int bx, 
 #pragma unroll
         for (int u = 0; u < TN; ++u) {
             int n = n0 + (wn * TN + u) * 16 + q * 4;
-            if (n < p.cout) store_tile(p, acc[t][u], opix, rpix, n);
+            if (n < p.cout) store_tile(p, acc[t][u], bv[u], opix, rpix, n);
         }
     }
 }
@@ -322,6 +325,9 @@ __device__ __forceinline__ void conv_mfma64_body(const ConvArgs &p, const int bx
     };
 
     const int wm = wave / WN, wn = wave % WN;
+    floatx4 bv[TN];                                        // bias fetched now, consumed after the k-loop (padded to 128 rows)
+#pragma unroll
+    for (int u = 0; u < TN; ++u) bv[u] = *(const floatx4 *)(p.bias + n0 + (wn * TN + u) * 16 + q * 4);
 #pragma unroll
     for (int i = 0; i < DEPTH; ++i)
         if (i < nk) issue(i, i);
@@ -357,7 +363,152 @@ __device__ __forceinline__ void conv_mfma64_body(const ConvArgs &p, const int bx
 #pragma unroll
         for (int u = 0; u < TN; ++u) {
             int n = n0 + (wn * TN + u) * 16 + q * 4;
-            if (n < p.cout) store_tile(p, acc[t][u], opix, rpix, n);
+            if (n < p.cout) store_tile(p, acc[t][u], bv[u], opix, rpix, n);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// conv3x3_rows: 3x3 / stride-1 convolution with TAP REUSE.  The generic kernels above fetch
+// the input tile once per tap -- nine times -- and the global->LDS path (about 16 B/clk/CU of
+// LDS-DMA) is what bounds them.  Here the GEMM's M dimension enumerates *padded* pixel
+// positions (border columns and rows included, ~5 % junk at 80x80, masked at the store), which
+// makes "the pixel one tap to the right" simply the next row of the A tile: one strip of
+// BM + 2 consecutive padded pixels, loaded once per (kh, channel chunk), serves kw = 0, 1, 2 by
+// reading LDS at row offsets 0, 1, 2.  A "super-step" = one strip + the weights of three taps
+// + 3 x (BK/32) x TM x TN MFMAs: ~1.8x fewer DMA bytes at 128x64, ~2.4x at 256x32.
+// Two LDS stages (a super-step is long enough to cover one DMA batch), vmcnt(0) + one barrier
+// per super-step.  Requires stride 1, input border 1, cin % BK == 0.
+// ---------------------------------------------------------------------------------------
+template <int BM, int BN, int WM, int WN, bool K64>
+__device__ __forceinline__ void conv3x3_rows_body(const ConvArgs &p, const int bx, const int by) {
+    static_assert(WM * WN == 4, "4 waves per workgroup");
+    constexpr int RP = K64 ? 8 : 16;               // rows per DMA piece
+    constexpr int RB = K64 ? 128 : 64;             // bytes per row in LDS
+    constexpr int BK = K64 ? 64 : 32;
+    constexpr int NAS = BM / RP + 1;               // strip pieces (BM + RP rows >= BM + 2)
+    constexpr int NBT = BN / RP;                   // weight pieces per tap
+    constexpr int NP = NAS + 3 * NBT;
+    constexpr int STAGE = NP * 1024;
+    constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
+    constexpr int TILE_BYTES = 16 * RB;            // LDS bytes of a 16-row operand tile
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * STAGE];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r = lane & 15, q = lane >> 4;
+    const int Mp = p.M;                            // = B * in_Hp * in_Wp (padded positions)
+    int mt, nt;
+    xcd_tile((Mp + BM - 1) / BM, (p.cout + BN - 1) / BN, bx, by, mt, nt);
+    const int m0 = mt * BM, n0 = nt * BN;
+
+    // row R of a piece-structured image: byte offset of k-chunk c (8 halves)
+    auto lds_off = [](int R, int c) -> int {
+        if (K64) return (R >> 3) * 1024 + (R & 7) * 128 + ((c ^ ((R >> 1) & 7)) << 4);
+        return (R >> 4) * 1024 + (R & 15) * 64 + ((c ^ swz16(R)) << 4);
+    };
+    // DMA lane map
+    const int ld_row = K64 ? lane >> 3 : lane >> 2;
+    const int ld_slot = K64 ? lane & 7 : lane & 3;
+    // fragment read offsets: A row r + kw of a 16-row tile (tile base is a multiple of 16 rows)
+    int a_rd[3][K64 ? 2 : 1], b_rd[K64 ? 2 : 1];
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+        for (int kk = 0; kk < (K64 ? 2 : 1); ++kk) a_rd[kw][kk] = lds_off(r + kw, kk * 4 + q);
+#pragma unroll
+    for (int kk = 0; kk < (K64 ? 2 : 1); ++kk) b_rd[kk] = lds_off(r, kk * 4 + q);
+
+    // per-wave piece lists: strip pieces wave, wave+4, ...; weight pieces likewise over 3*NBT
+    constexpr int LA = (NAS + 3) / 4, LB = (3 * NBT + 3) / 4;
+    int a_off[LA], b_off[LB];
+    const int last_pix = Mp - 1;
+#pragma unroll
+    for (int i = 0; i < LA; ++i) {
+        int R = (wave + 4 * i) * RP + ld_row;                  // strip row
+        int chunk = K64 ? (ld_slot ^ ((R >> 1) & 7)) : (ld_slot ^ swz16(R));
+        // pixel index is clamped per tap row at issue time; keep row and chunk parts separate
+        a_off[i] = (m0 + R) | (chunk << 28);
+    }
+#pragma unroll
+    for (int i = 0; i < LB; ++i) {
+        int pc = wave + 4 * i;                                  // 0 .. 3*NBT-1
+        int kw = pc / NBT, R = (pc - kw * NBT) * RP + ld_row;   // cout row inside the BN tile
+        int chunk = K64 ? (ld_slot ^ ((R >> 1) & 7)) : (ld_slot ^ swz16(R));
+        b_off[i] = (n0 + R) * p.kp + kw * p.cin + chunk * 8;
+    }
+
+    floatx4 acc[TM][TN];
+#pragma unroll
+    for (int t = 0; t < TM; ++t)
+#pragma unroll
+        for (int u = 0; u < TN; ++u) acc[t][u] = floatx4{0.f, 0.f, 0.f, 0.f};
+
+    const int wm = wave / WN, wn = wave % WN;
+    floatx4 bv[TN];
+#pragma unroll
+    for (int u = 0; u < TN; ++u) bv[u] = *(const floatx4 *)(p.bias + n0 + (wn * TN + u) * 16 + q * 4);
+
+    const int cpk = p.cin / BK;                     // channel chunks per tap row
+    const int ns = 3 * cpk;                         // super-steps: (kh, chunk)
+    int kh = 0, c0 = 0;
+    auto issue = [&](int stage) {
+        unsigned char *sbase = lds + stage * STAGE;
+        const int row_shift = kh * p.in_Wp;
+#pragma unroll
+        for (int i = 0; i < LA; ++i) {
+            if (wave + 4 * i < NAS) {
+                int pix = min((a_off[i] & 0x0FFFFFFF) + row_shift, last_pix);
+                glds16(p.in + ((long)pix * p.in_cs + c0 + (a_off[i] >> 28) * 8), sbase + (wave + 4 * i) * 1024);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < LB; ++i)
+            if (wave + 4 * i < 3 * NBT) glds16(p.wt + (b_off[i] + kh * 3 * p.cin + c0), sbase + (NAS + wave + 4 * i) * 1024);
+        c0 += BK;
+        if (c0 >= p.cin) { c0 = 0; ++kh; }
+    };
+
+    issue(0);
+    for (int st = 0; st < ns; ++st) {
+        wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();                   // stage st landed; everyone finished stage st-1
+        asm volatile("" ::: "memory");
+        if (st + 1 < ns) issue((st + 1) & 1);
+        const unsigned char *sA = lds + (st & 1) * STAGE + wm * TM * TILE_BYTES;
+        const unsigned char *sB = lds + (st & 1) * STAGE + NAS * 1024 + wn * TN * TILE_BYTES;
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+            for (int kk = 0; kk < (K64 ? 2 : 1); ++kk) {
+                half8 fa[TM], fb[TN];
+#pragma unroll
+                for (int t = 0; t < TM; ++t) fa[t] = *(const half8 *)(sA + t * TILE_BYTES + a_rd[kw][kk]);
+#pragma unroll
+                for (int u = 0; u < TN; ++u) fb[u] = *(const half8 *)(sB + kw * NBT * 1024 + u * TILE_BYTES + b_rd[kk]);
+#pragma unroll
+                for (int t = 0; t < TM; ++t)
+#pragma unroll
+                    for (int u = 0; u < TN; ++u)
+                        acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[u], fa[t], acc[t][u], 0, 0, 0);
+            }
+    }
+
+    // ---- epilogue: padded position -> (b, y, x); border rows/columns are junk ----
+    const int HW = p.in_Hp * p.in_Wp;
+#pragma unroll
+    for (int t = 0; t < TM; ++t) {
+        int m = m0 + (wm * TM + t) * 16 + r;
+        if (m >= Mp) continue;
+        int b = m / HW, rem = m - b * HW;
+        int oy = rem / p.in_Wp, ox = rem - oy * p.in_Wp;
+        if (oy >= p.Ho || ox >= p.Wo) continue;
+        long opix = ((long)(b * p.out_Hp + oy + p.out_pad) * p.out_Wp + ox + p.out_pad) * p.out_cs;
+        long rpix = p.res ? ((long)(b * p.res_Hp + oy + p.res_pad) * p.res_Wp + ox + p.res_pad) * p.res_cs : 0;
+#pragma unroll
+        for (int u = 0; u < TN; ++u) {
+            int n = n0 + (wn * TN + u) * 16 + q * 4;
+            if (n < p.cout) store_tile(p, acc[t][u], bv[u], opix, rpix, n);
         }
     }
 }
@@ -452,7 +603,7 @@ __device__ __forceinline__ void conv_mfma_wsk_body(const ConvArgs &p, const int 
         long opix, rpix;
         if (!pixel_offsets(p, m0 + t * 16 + r, opix, rpix)) continue;
         int n = n0 + u * 16 + q * 4;
-        if (n < p.cout) store_tile(p, v, opix, rpix, n);
+        if (n < p.cout) store_tile(p, v, *(const floatx4 *)(p.bias + n), opix, rpix, n);
     }
 }
 
@@ -478,6 +629,14 @@ __global__ __launch_bounds__(256) void conv_mfma64_grp(ConvGroupArgs g) {
     if ((int)blockIdx.x * BM >= p.M || (int)blockIdx.y * BN >= p.cout) return;
     conv_mfma64_body<BM, BN, WM, WN, NSTAGE>(p, blockIdx.x, blockIdx.y);
 }
+template <int BM, int BN, int WM, int WN, bool K64>
+__global__ __launch_bounds__(256) void conv3x3_rows(ConvArgs p) { conv3x3_rows_body<BM, BN, WM, WN, K64>(p, blockIdx.x, blockIdx.y); }
+template <int BM, int BN, int WM, int WN, bool K64>
+__global__ __launch_bounds__(256) void conv3x3_rows_grp(ConvGroupArgs g) {
+    const ConvArgs &p = g.p[blockIdx.z];
+    if ((int)blockIdx.x * BM >= p.M || (int)blockIdx.y * BN >= p.cout) return;
+    conv3x3_rows_body<BM, BN, WM, WN, K64>(p, blockIdx.x, blockIdx.y);
+}
 template <int BM, int BN, bool GENERAL>
 __global__ __launch_bounds__(256) void conv_mfma_wsk(ConvArgs p) { conv_mfma_wsk_body<BM, BN, GENERAL>(p, blockIdx.x, blockIdx.y); }
 template <int BM, int BN, bool GENERAL>
@@ -490,11 +649,13 @@ __global__ __launch_bounds__(256) void conv_mfma_wsk_grp(ConvGroupArgs g) {
 const char *tile_name(int tile) {
     static const char *names[TILE_COUNT] = {"128x128s3", "128x64s3", "64x64s3", "256x32s3", "64x128s3", "wsk64x64", "wsk32x64", "wsk64x32",
                                             "128x128s4", "128x64s5", "64x64s6", "64x128s5", "128x128s6",
-                                            "k64:128x128s2", "k64:128x128s3", "k64:128x64s3", "k64:64x128s3", "k64:64x64s3", "k64:64x64s4", "k64:256x64s2"};
+                                            "k64:128x128s2", "k64:128x128s3", "k64:128x64s3", "k64:64x128s3", "k64:64x64s3", "k64:64x64s4", "k64:256x64s2", "k64:256x128s2", "k64:128x128s2w",
+                                            "rows:128x64", "rows:256x32", "rows:128x32", "rows64:128x64", "rows64:128x128", "rows64:64x64", "rows64:256x64"};
     return tile >= 0 && tile < TILE_COUNT ? names[tile] : "?";
 }
 
-bool tile_needs_cin64(int tile) { return tile >= TILE_K64_128x128_S2 && tile <= TILE_K64_256x64_S2; }
+bool tile_needs_cin64(int tile) { return (tile >= TILE_K64_128x128_S2 && tile <= TILE_K64_128x128_S2W) || tile >= TILE_ROWS_K64_128x64; }
+bool tile_is_rows(int tile) { return tile >= TILE_ROWS_128x64 && tile < TILE_COUNT; }
 
 TileShape tile_shape(int tile) {
     switch (tile) {
@@ -515,6 +676,14 @@ TileShape tile_shape(int tile) {
         case TILE_K64_64x128_S3: return {64, 128};
         case TILE_K64_64x64_S3: case TILE_K64_64x64_S4: return {64, 64};
         case TILE_K64_256x64_S2: return {256, 64};
+        case TILE_K64_256x128_S2: return {256, 128};
+        case TILE_K64_128x128_S2W: return {128, 128};
+        case TILE_ROWS_128x64: case TILE_ROWS_K64_128x64: return {128, 64};
+        case TILE_ROWS_256x32: return {256, 32};
+        case TILE_ROWS_128x32: return {128, 32};
+        case TILE_ROWS_K64_128x128: return {128, 128};
+        case TILE_ROWS_K64_64x64: return {64, 64};
+        case TILE_ROWS_K64_256x64: return {256, 64};
     }
     return {0, 0};
 }
@@ -548,6 +717,18 @@ static void launch_k64(const LaunchPlan &l, hipStream_t s) {
         ConvGroupArgs g;
         for (int i = 0; i < l.n; ++i) g.p[i] = l.a[i];
         hipLaunchKernelGGL((conv_mfma64_grp<BM, BN, WM, WN, NSTAGE>), grid, dim3(256), 0, s, g);
+    }
+}
+
+template <int BM, int BN, int WM, int WN, bool K64>
+static void launch_rows(const LaunchPlan &l, hipStream_t s) {
+    dim3 grid = l.grid(BM, BN);
+    if (l.n == 1) {
+        hipLaunchKernelGGL((conv3x3_rows<BM, BN, WM, WN, K64>), grid, dim3(256), 0, s, l.a[0]);
+    } else {
+        ConvGroupArgs g;
+        for (int i = 0; i < l.n; ++i) g.p[i] = l.a[i];
+        hipLaunchKernelGGL((conv3x3_rows_grp<BM, BN, WM, WN, K64>), grid, dim3(256), 0, s, g);
     }
 }
 
@@ -610,6 +791,15 @@ int launch_conv_group(const ConvLaunch *c, int n, int tile, hipStream_t s) {
         if (tile_needs_cin64(tile))
             RT_CHECK(c[i].cin % 64 == 0 && a[i].kp % 64 == 0, RTMODT_E_INVALID, "launch_conv: tile %s needs cin %% 64 == 0 (cin %d)", tile_name(tile), c[i].cin);
     }
+    if (tile_is_rows(tile)) {
+        const int bk = tile_needs_cin64(tile) ? 64 : 32;
+        for (int i = 0; i < n; ++i) {
+            RT_CHECK(c[i].ks == 3 && c[i].stride == 1 && c[i].in.pad == 1 && c[i].cin % bk == 0, RTMODT_E_INVALID,
+                     "launch_conv: tile %s needs a 3x3 stride-1 conv on a bordered input with cin %% %d == 0", tile_name(tile), bk);
+            a[i].M = c[i].B * a[i].in_Hp * a[i].in_Wp;       // the GEMM runs over padded positions
+            RT_CHECK((long)a[i].M * a[i].in_cs < (1L << 31) && a[i].M < (1 << 28), RTMODT_E_INVALID, "launch_conv: tensor exceeds 2^31 elements");
+        }
+    }
     LaunchPlan l{a, n, general};
     switch (tile) {
         case TILE_128x128: launch_tile<128, 128, 2, 2, 3>(l, s); break;
@@ -632,6 +822,15 @@ int launch_conv_group(const ConvLaunch *c, int n, int tile, hipStream_t s) {
         case TILE_K64_64x64_S3: launch_k64<64, 64, 2, 2, 3>(l, s); break;
         case TILE_K64_64x64_S4: launch_k64<64, 64, 2, 2, 4>(l, s); break;
         case TILE_K64_256x64_S2: launch_k64<256, 64, 4, 1, 2>(l, s); break;
+        case TILE_K64_256x128_S2: launch_k64<256, 128, 2, 2, 2>(l, s); break;
+        case TILE_K64_128x128_S2W: launch_k64<128, 128, 4, 1, 2>(l, s); break;
+        case TILE_ROWS_128x64: launch_rows<128, 64, 2, 2, false>(l, s); break;
+        case TILE_ROWS_256x32: launch_rows<256, 32, 4, 1, false>(l, s); break;
+        case TILE_ROWS_128x32: launch_rows<128, 32, 4, 1, false>(l, s); break;
+        case TILE_ROWS_K64_128x64: launch_rows<128, 64, 2, 2, true>(l, s); break;
+        case TILE_ROWS_K64_128x128: launch_rows<128, 128, 2, 2, true>(l, s); break;
+        case TILE_ROWS_K64_64x64: launch_rows<64, 64, 2, 2, true>(l, s); break;
+        case TILE_ROWS_K64_256x64: launch_rows<256, 64, 4, 1, true>(l, s); break;
         default: return fail(RTMODT_E_INVALID, "launch_conv: tile %d", tile);
     }
     RT_HIP(hipGetLastError());

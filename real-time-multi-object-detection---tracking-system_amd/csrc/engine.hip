@@ -271,8 +271,8 @@ static int pick_tile(int M, int cout) {
         int t = atoi(e);
         if (t >= 0 && t < TILE_COUNT) return t;
     }
-    static const float eff[TILE_COUNT] = {1.0f, 0.85f, 0.62f, 0.75f, 0.85f, 0.5f, 0.4f, 0.4f, 1.05f, 0.9f, 0.65f, 0.9f, 1.0f, 0, 0, 0, 0, 0, 0, 0};
-    static const int occ[TILE_COUNT] = {3, 5, 8, 4, 5, 2, 3, 3, 2, 2, 3, 2, 1, 1, 1, 1, 1, 1, 1, 1};
+    static const float eff[TILE_COUNT] = {1.0f, 0.85f, 0.62f, 0.75f, 0.85f, 0.5f, 0.4f, 0.4f, 1.05f, 0.9f, 0.65f, 0.9f, 1.0f, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    static const int occ[TILE_COUNT] = {3, 5, 8, 4, 5, 2, 3, 3, 2, 2, 3, 2, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1};
     int best = 0;
     double best_cost = 1e30;
     for (int t = 0; t < TILE_COUNT; ++t) {
@@ -329,6 +329,12 @@ static int make_conv(rtmodt_detector *d, WeightFile &wf, const std::vector<std::
     c.B = d->B; c.cin = r0.cin; c.cout = cout_eff; c.ks = r0.k; c.stride = r0.stride; c.act = r0.act; c.kp = kp;
     int M = d->B * out.H * out.W;
     c.tile = pick_tile(M, cout_eff);
+    if (const char *e = getenv("RTMODT_TILE_3X3S1")) {          // test hook: force a tap-reuse tile wherever it is legal
+        int t = atoi(e);
+        if (t >= 0 && t < TILE_COUNT && tile_is_rows(t) && c.ks == 3 && c.stride == 1 && c.in.pad == 1 &&
+            c.cin % (tile_needs_cin64(t) ? 64 : 32) == 0)
+            c.tile = t;
+    }
     op.flops = 2LL * out.H * out.W * cout * K;
     (dst ? *dst : d->ops).push_back(op);
     int off = 0;
@@ -460,6 +466,9 @@ static int build_graph(rtmodt_detector *d, WeightFile &wf) {
     auto add_group = [&](const std::string &name, std::initializer_list<int> idx) {
         Op g; g.kind = OP_GROUP; g.name = name;
         for (int i : idx) { g.group.push_back(hops[i].conv); g.flops += hops[i].flops; }
+        bool same = true;
+        for (auto &c : g.group) same = same && c.tile == g.group[0].tile;
+        if (same && tile_is_rows(g.group[0].tile)) g.group_tile = g.group[0].tile;   // RTMODT_TILE_3X3S1 test hook
         d->ops.push_back(g);
     };
     if (grouping == 2) {
@@ -560,9 +569,12 @@ static int autotune_ops(rtmodt_detector *d, std::vector<Op> &ops) {
     for (auto &op : ops) {
         if (op.kind != OP_CONV && op.kind != OP_GROUP) continue;
         const bool grp = op.kind == OP_GROUP;
-        bool cin64 = true;
-        if (grp) { for (auto &c : op.group) cin64 = cin64 && c.cin % 64 == 0 && c.kp % 64 == 0; }
-        else cin64 = op.conv.cin % 64 == 0 && op.conv.kp % 64 == 0;
+        bool cin64 = true, rows_ok = true;
+        auto check = [&](const ConvLaunch &c) {
+            cin64 = cin64 && c.cin % 64 == 0 && c.kp % 64 == 0;
+            rows_ok = rows_ok && c.ks == 3 && c.stride == 1 && c.in.pad == 1 && c.cin % 32 == 0;
+        };
+        if (grp) { for (auto &c : op.group) check(c); } else check(op.conv);
         auto launch = [&](int t) -> int {
             if (grp) return launch_conv_group(op.group.data(), (int)op.group.size(), t, d->stream);
             op.conv.tile = t;
@@ -572,6 +584,7 @@ static int autotune_ops(rtmodt_detector *d, std::vector<Op> &ops) {
         int best_tile = grp ? op.group_tile : op.conv.tile;
         for (int t = 0; t < TILE_COUNT; ++t) {
             if (tile_needs_cin64(t) && !cin64) continue;
+            if (tile_is_rows(t) && !rows_ok) continue;
             for (int w = 0; w < 2; ++w) RT_TRY(launch(t));
             float ms_min = 1e30f;
             for (int rep = 0; rep < 3; ++rep) {

@@ -26,11 +26,14 @@ enum ConvTile {
     TILE_WSK_64x64 = 5, TILE_WSK_32x64 = 6, TILE_WSK_64x32 = 7,                           // 4 waves split K over one tile
     TILE_128x128_S4 = 8, TILE_128x64_S5 = 9, TILE_64x64_S6 = 10, TILE_64x128_S5 = 11, TILE_128x128_S6 = 12,   // deeper DMA pipelines
     TILE_K64_128x128_S2 = 13, TILE_K64_128x128_S3 = 14, TILE_K64_128x64_S3 = 15, TILE_K64_64x128_S3 = 16,   // 64-deep k-steps (cin % 64 == 0)
-    TILE_K64_64x64_S3 = 17, TILE_K64_64x64_S4 = 18, TILE_K64_256x64_S2 = 19,
-    TILE_COUNT = 20
+    TILE_K64_64x64_S3 = 17, TILE_K64_64x64_S4 = 18, TILE_K64_256x64_S2 = 19, TILE_K64_256x128_S2 = 20, TILE_K64_128x128_S2W = 21,
+    TILE_ROWS_128x64 = 22, TILE_ROWS_256x32 = 23, TILE_ROWS_128x32 = 24,                    // 3x3/s1 tap-reuse kernel, 32-deep chunks
+    TILE_ROWS_K64_128x64 = 25, TILE_ROWS_K64_128x128 = 26, TILE_ROWS_K64_64x64 = 27, TILE_ROWS_K64_256x64 = 28,   // ... 64-deep
+    TILE_COUNT = 29
 };
 const char *tile_name(int tile);
 bool tile_needs_cin64(int tile);
+bool tile_is_rows(int tile);      // 3x3 stride-1 only, bordered input
 struct TileShape { int bm, bn; };
 TileShape tile_shape(int tile);
 

@@ -148,6 +148,27 @@ def test_forward_layers_other_scales(pkg, wdir, scale, size):
     det.close()
 
 
+@pytest.mark.parametrize("tile", [22, 23, 24, 25, 26, 27, 28])
+def test_tap_reuse_conv_tiles(pkg, wdir, monkeypatch, tile):
+    """conv3x3_rows (the 3x3/s1 tap-reuse kernel) in each of its tile shapes, forced onto every
+    layer where it is legal; all layers are then checked one by one against the oracle."""
+    monkeypatch.setenv("RTMODT_TILE_3X3S1", str(tile))
+    det, w = make_detector(pkg, wdir, "s", 320, autotune=False, batch=2)
+    frames = list(pkg.synth.frames(2, 320, 320, seed=31))
+    det.detect_batch(frames)
+    names = [c.name for c in pkg.weights.spec("s")]
+    for img in (0, 1):
+        inp, _, _ = det.debug_fetch(img, want_heads=False, want_pred=False)
+        gpu = {n: det.debug_layer(n, img).astype(np.float32) for n in names}
+        taps = {}
+        Y.forward(inp.astype(np.float32), w, "s", taps=taps, force=gpu)
+        for n in names:
+            tol = 2e-3 * np.abs(taps[n]).max() + 2e-3
+            err = float(np.abs(taps[n] - gpu[n]).max())
+            assert err <= tol, f"tile {tile} img {img} layer {n}: max err {err:.4g} > tol {tol:.4g}"
+    det.close()
+
+
 def iou_1to1(a, b):
     x1 = np.maximum(a[:, 0], b[:, 0]); y1 = np.maximum(a[:, 1], b[:, 1])
     x2 = np.minimum(a[:, 2], b[:, 2]); y2 = np.minimum(a[:, 3], b[:, 3])
