@@ -18,6 +18,7 @@ Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement" for every field).
 from __future__ import annotations
 
 import argparse
+import gc
 import json
 import os
 import sys
@@ -145,6 +146,11 @@ def main():
         det.synchronize()                           # hipDeviceSynchronize through the C ABI
         sync.device_synchronize()                   # + torch.cuda.synchronize() when torch.distributed is up
 
+    # a generation-2 Python GC pass walks every object torch's import created (~40 ms): keep the
+    # collector out of the loop (the per-step garbage is a few hundred short-lived objects)
+    gc.collect()
+    gc.freeze()
+    gc.disable()
     submit(0)                                       # prime the pipeline: one batch always in flight
     for t in range(1, args.warmup + 1):
         step(t)
@@ -164,6 +170,7 @@ def main():
     sync.barrier()
     sync_all()
     elapsed = time.perf_counter() - t0
+    gc.enable()
     elapsed = sync.max_time(elapsed)                # MAX over ranks
     det.fetch()                                      # drain the batch still in flight (outside the timed region)
     n_tracks = sum(len(trk.snapshot(s)["ids"]) for s in range(S))
@@ -219,12 +226,14 @@ def main():
         det1 = pkg.Detector(wpath, input_size=(size, size), max_det=args.max_det, device=f"cuda:{dev}", batch=1, warmup=False)
         trk1 = core_cls(device=dev, n_streams=1, max_dets=max(128, args.max_det), max_tracks=2048)
         lat = []
+        gc.disable()
         for t in range(50 + 300):
             t1 = time.perf_counter()
             det1.enqueue([ring.ptr + (t % R) * per], height=size, width=size)
             trk1.update_from_detector(det1)
             det1.fetch()
             lat.append(time.perf_counter() - t1)
+        gc.enable()
         lat = np.asarray(lat[50:]) * 1e3                         # 50 warm-up frames discarded (config/default.yaml:88)
         res["latency_single_stream_ms"] = {"p50": round(float(np.percentile(lat, 50)), 4), "mean": round(float(lat.mean()), 4),
                                            "p95": round(float(np.percentile(lat, 95)), 4), "p99": round(float(np.percentile(lat, 99)), 4),

@@ -41,6 +41,8 @@ struct ConvArgs {
     int out_Hp, out_Wp, out_cs, out_pad;
     int res_Hp, res_Wp, res_cs, res_pad;
     int Ho, Wo, M;                       // M = B*Ho*Wo
+    f16 *out2;                           // optional second destination: nearest-2x upsampled copy (neck concat slice)
+    int out2_Hp, out2_Wp, out2_cs, out2_pad;
     int cin, cout, ks, stride, act, kp, K;
 };
 
@@ -121,7 +123,7 @@ __device__ __forceinline__ void glds16(const f16 *src, unsigned char *dst) {
 
 // fused epilogue for one 16(pixel) x 16(cout) accumulator tile: lane holds pixel (lane&15),
 // channels n .. n+3
-__device__ __forceinline__ void store_tile(const ConvArgs &p, const floatx4 &acc, const floatx4 &bias, long opix, long rpix, int n) {
+__device__ __forceinline__ void store_tile(const ConvArgs &p, const floatx4 &acc, const floatx4 &bias, long opix, long rpix, int n, long opix2 = -1) {
     floatx4 v = acc + bias;
     if (p.act) { v[0] = silu_f(v[0]); v[1] = silu_f(v[1]); v[2] = silu_f(v[2]); v[3] = silu_f(v[3]); }
     if (p.res) {
@@ -130,15 +132,27 @@ __device__ __forceinline__ void store_tile(const ConvArgs &p, const floatx4 &acc
     }
     half4 o = {(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
     *(half4 *)(p.out + opix + n) = o;
+    if (opix2 >= 0) {                                    // Upsample(nearest, x2) + Concat folded into this epilogue
+        const long row = (long)p.out2_Wp * p.out2_cs;
+        *(half4 *)(p.out2 + opix2 + n) = o;
+        *(half4 *)(p.out2 + opix2 + p.out2_cs + n) = o;
+        *(half4 *)(p.out2 + opix2 + row + n) = o;
+        *(half4 *)(p.out2 + opix2 + row + p.out2_cs + n) = o;
+    }
 }
 
-__device__ __forceinline__ bool pixel_offsets(const ConvArgs &p, int m, long &opix, long &rpix) {
+__device__ __forceinline__ long upsampled_offset(const ConvArgs &p, int b, int oy, int ox) {
+    return p.out2 ? ((long)(b * p.out2_Hp + 2 * oy + p.out2_pad) * p.out2_Wp + 2 * ox + p.out2_pad) * p.out2_cs : -1;
+}
+
+__device__ __forceinline__ bool pixel_offsets(const ConvArgs &p, int m, long &opix, long &rpix, long &opix2) {
     if (m >= p.M) return false;
     const int HoWo = p.Ho * p.Wo;
     int b = m / HoWo, rem = m - b * HoWo;
     int oy = rem / p.Wo, ox = rem - oy * p.Wo;
     opix = ((long)(b * p.out_Hp + oy + p.out_pad) * p.out_Wp + ox + p.out_pad) * p.out_cs;
     rpix = p.res ? ((long)(b * p.res_Hp + oy + p.res_pad) * p.res_Wp + ox + p.res_pad) * p.res_cs : 0;
+    opix2 = upsampled_offset(p, b, oy, ox);
     return true;
 }
 
@@ -251,12 +265,12 @@ __device__ __forceinline__ void conv_mfma_body(const ConvArgs &p, const int bx, 
     // ---- epilogue: D[row = cout (lane>>4)*4+j][col = pixel lane&15] ----
 #pragma unroll
     for (int t = 0; t < TM; ++t) {
-        long opix, rpix;
-        if (!pixel_offsets(p, m0 + (wm * TM + t) * 16 + r, opix, rpix)) continue;
+        long opix, rpix, opix2;
+        if (!pixel_offsets(p, m0 + (wm * TM + t) * 16 + r, opix, rpix, opix2)) continue;
 #pragma unroll
         for (int u = 0; u < TN; ++u) {
             int n = n0 + (wn * TN + u) * 16 + q * 4;
-            if (n < p.cout) store_tile(p, acc[t][u], bv[u], opix, rpix, n);
+            if (n < p.cout) store_tile(p, acc[t][u], bv[u], opix, rpix, n, opix2);
         }
     }
 }
@@ -358,12 +372,12 @@ __device__ __forceinline__ void conv_mfma64_body(const ConvArgs &p, const int bx
 
 #pragma unroll
     for (int t = 0; t < TM; ++t) {
-        long opix, rpix;
-        if (!pixel_offsets(p, m0 + (wm * TM + t) * 16 + r, opix, rpix)) continue;
+        long opix, rpix, opix2;
+        if (!pixel_offsets(p, m0 + (wm * TM + t) * 16 + r, opix, rpix, opix2)) continue;
 #pragma unroll
         for (int u = 0; u < TN; ++u) {
             int n = n0 + (wn * TN + u) * 16 + q * 4;
-            if (n < p.cout) store_tile(p, acc[t][u], bv[u], opix, rpix, n);
+            if (n < p.cout) store_tile(p, acc[t][u], bv[u], opix, rpix, n, opix2);
         }
     }
 }
@@ -505,10 +519,11 @@ __device__ __forceinline__ void conv3x3_rows_body(const ConvArgs &p, const int b
         if (oy >= p.Ho || ox >= p.Wo) continue;
         long opix = ((long)(b * p.out_Hp + oy + p.out_pad) * p.out_Wp + ox + p.out_pad) * p.out_cs;
         long rpix = p.res ? ((long)(b * p.res_Hp + oy + p.res_pad) * p.res_Wp + ox + p.res_pad) * p.res_cs : 0;
+        long opix2 = upsampled_offset(p, b, oy, ox);
 #pragma unroll
         for (int u = 0; u < TN; ++u) {
             int n = n0 + (wn * TN + u) * 16 + q * 4;
-            if (n < p.cout) store_tile(p, acc[t][u], bv[u], opix, rpix, n);
+            if (n < p.cout) store_tile(p, acc[t][u], bv[u], opix, rpix, n, opix2);
         }
     }
 }
@@ -600,10 +615,10 @@ __device__ __forceinline__ void conv_mfma_wsk_body(const ConvArgs &p, const int 
         const int tile = wave * PER + k, t = tile / TN, u = tile % TN;
         floatx4 v = part[(0 * TM * TN + tile) * 64 + lane] + part[(1 * TM * TN + tile) * 64 + lane] +
                     part[(2 * TM * TN + tile) * 64 + lane] + part[(3 * TM * TN + tile) * 64 + lane];
-        long opix, rpix;
-        if (!pixel_offsets(p, m0 + t * 16 + r, opix, rpix)) continue;
+        long opix, rpix, opix2;
+        if (!pixel_offsets(p, m0 + t * 16 + r, opix, rpix, opix2)) continue;
         int n = n0 + u * 16 + q * 4;
-        if (n < p.cout) store_tile(p, v, *(const floatx4 *)(p.bias + n), opix, rpix, n);
+        if (n < p.cout) store_tile(p, v, *(const floatx4 *)(p.bias + n), opix, rpix, n, opix2);
     }
 }
 
@@ -768,6 +783,13 @@ static int make_args(const ConvLaunch &c, ConvArgs &a) {
     if (a.res) {
         RT_CHECK(c.res.H == c.out.H && c.res.W == c.out.W && c.res.c == c.cout && c.res.coff % 4 == 0 && c.res.C % 4 == 0,
                  RTMODT_E_INVALID, "launch_conv: residual shape");
+    }
+    a.out2 = nullptr; a.out2_Hp = a.out2_Wp = a.out2_cs = a.out2_pad = 0;
+    if (c.out2.base) {
+        RT_CHECK(c.out2.H == 2 * c.out.H && c.out2.W == 2 * c.out.W && c.out2.c == c.cout && c.out2.coff % 4 == 0 && c.out2.C % 4 == 0,
+                 RTMODT_E_INVALID, "launch_conv: upsampled destination shape");
+        a.out2 = c.out2.base + c.out2.coff;
+        a.out2_Hp = c.out2.H + 2 * c.out2.pad; a.out2_Wp = c.out2.W + 2 * c.out2.pad; a.out2_cs = c.out2.C; a.out2_pad = c.out2.pad;
     }
     a.M = c.B * a.Ho * a.Wo;
     a.cin = c.cin; a.cout = c.cout; a.ks = c.ks; a.stride = c.stride; a.act = c.act;

@@ -260,7 +260,7 @@ static Op sub_batch(const Op &op, int b0, int nb) {
         if (v.c) v.base += (size_t)b0 * (v.H + 2 * v.pad) * (v.W + 2 * v.pad) * v.C;
     };
     o.B = nb;
-    if (o.kind == OP_CONV) { shift(o.conv.in); shift(o.conv.out); shift(o.conv.res); o.conv.B = nb; }
+    if (o.kind == OP_CONV) { shift(o.conv.in); shift(o.conv.out); shift(o.conv.res); shift(o.conv.out2); o.conv.B = nb; }
     else if (o.kind == OP_GROUP) for (auto &c : o.group) { shift(c.in); shift(c.out); shift(c.res); c.B = nb; }
     else for (auto &v : o.v) shift(v);
     return o;
@@ -429,10 +429,13 @@ static int build_graph(rtmodt_detector *d, WeightFile &wf) {
     }
     TensorView out9 = V(cat20, c4, c5);
     conv("9.cv2", V(cat9), out9);
-    { Op op; op.kind = OP_UP; op.name = "10.up"; op.v[0] = out9; op.v[1] = V(cat11, 0, c5); d->ops.push_back(op); }
+    const bool fold_up = getenv("RTMODT_NO_UPFOLD") == nullptr;   // A/B switch: separate upsample2 launches instead
+    if (fold_up) d->ops.back().conv.out2 = V(cat11, 0, c5);   // layer 10 (Upsample) + 11 (Concat) folded into 9.cv2's epilogue
+    else { Op op; op.kind = OP_UP; op.name = "10.up"; op.v[0] = out9; op.v[1] = V(cat11, 0, c5); d->ops.push_back(op); }
     TensorView out12 = V(cat17, c3, c4);
     c2f("12", V(cat11), c4, rep(3), false, out12);
-    { Op op; op.kind = OP_UP; op.name = "13.up"; op.v[0] = out12; op.v[1] = V(cat14, 0, c4); d->ops.push_back(op); }
+    if (fold_up) d->ops.back().conv.out2 = V(cat14, 0, c4);   // layer 13 (Upsample) + 14 (Concat) folded into 12.cv2's epilogue
+    else { Op op; op.kind = OP_UP; op.name = "13.up"; op.v[0] = out12; op.v[1] = V(cat14, 0, c4); d->ops.push_back(op); }
     int t15 = T(H / 8, W / 8, c3, 1);
     c2f("15", V(cat14), c3, rep(3), false, V(t15));
     conv("16", V(t15), V(cat17, 0, c3));
@@ -506,6 +509,7 @@ static int build_graph(rtmodt_detector *d, WeightFile &wf) {
         if (op.kind == OP_CONV) {
             rebase(op.conv.in); rebase(op.conv.out);
             if (op.conv.res.c) rebase(op.conv.res);
+            if (op.conv.out2.c) rebase(op.conv.out2);
         } else if (op.kind == OP_GROUP) {
             for (auto &c : op.group) { rebase(c.in); rebase(c.out); if (c.res.c) rebase(c.res); }
         } else {
@@ -660,7 +664,9 @@ static int capture_chain(rtmodt_detector *d, int c) {
     hipError_t e = hipStreamEndCapture(main, &d->graphs[c]);
     RT_TRY(rc);
     RT_HIP(e);
-    RT_HIP(hipGraphInstantiate(&d->graph_execs[c], d->graphs[c], nullptr, nullptr, 0));
+    // two executable instances per graph, used by alternate batches: relaunching ONE instance while
+    // its previous launch is still running makes the runtime wait for it before submitting
+    for (int k = 0; k < 2; ++k) RT_HIP(hipGraphInstantiate(&d->graph_execs[2 * c + k], d->graphs[c], nullptr, nullptr, 0));
     return RTMODT_OK;
 }
 
@@ -668,7 +674,7 @@ static int capture_graph(rtmodt_detector *d) {
     const int C = d->n_chains;
     for (auto g : d->graph_execs) if (g) hipGraphExecDestroy(g);
     for (auto g : d->graphs) if (g) hipGraphDestroy(g);
-    d->graphs.assign(C, nullptr); d->graph_execs.assign(C, nullptr);
+    d->graphs.assign(C, nullptr); d->graph_execs.assign(2 * C, nullptr);
     while ((int)d->chain_streams.size() < C) {
         hipStream_t st = d->stream;
         if (!d->chain_streams.empty()) RT_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
@@ -698,7 +704,8 @@ static int forward_graphs(rtmodt_detector *d) {
         RT_HIP(hipEventRecord(d->chain_fork[c], d->stream));
         RT_HIP(hipStreamWaitEvent(d->chain_streams[c], d->chain_fork[c], 0));
     }
-    for (int c = 0; c < C; ++c) RT_HIP(hipGraphLaunch(d->graph_execs[c], d->chain_streams[c]));
+    const int inst = getenv("RTMODT_ONE_EXEC") ? 0 : (d->cur_dense & 1);   // ring slot parity
+    for (int c = 0; c < C; ++c) RT_HIP(hipGraphLaunch(d->graph_execs[2 * c + inst], d->chain_streams[c]));
     for (int c = 1; c < C; ++c) {
         RT_HIP(hipEventRecord(d->chain_join[c], d->chain_streams[c]));
         RT_HIP(hipStreamWaitEvent(d->stream, d->chain_join[c], 0));
@@ -1098,6 +1105,17 @@ int rtmodt_detector_last_timing(rtmodt_detector *d, float *total_ms, float *forw
     RT_HIP(hipEventSynchronize(sl.ev2));
     if (total_ms) RT_HIP(hipEventElapsedTime(total_ms, sl.ev0, sl.ev2));
     if (forward_ms) RT_HIP(hipEventElapsedTime(forward_ms, sl.ev0, sl.ev1));
+    if (getenv("RTMODT_DEBUG_GAPS")) {                    // idle time of the main stream between two batches
+        static hipEvent_t base = nullptr;
+        static float prev_end = -1.f;
+        if (!base) { hipEventCreate(&base); hipEventRecord(base, d->stream); hipEventSynchronize(base); }
+        float t0 = 0, t1 = 0, t2 = 0;
+        if (hipEventElapsedTime(&t0, base, sl.ev0) == hipSuccess && hipEventElapsedTime(&t1, base, sl.ev1) == hipSuccess &&
+            hipEventElapsedTime(&t2, base, sl.ev2) == hipSuccess) {
+            if (prev_end >= 0) fprintf(stderr, "[rtmodt] main-stream idle before this batch %.3f ms; forward %.3f; decode_end -> nms_end %.3f\n", t0 - prev_end, t1 - t0, t2 - t1);
+            prev_end = t1;
+        }
+    }
     return RTMODT_OK;
 }
 

@@ -39,6 +39,7 @@ TileShape tile_shape(int tile);
 
 struct ConvLaunch {
     TensorView in, out, res;      // res.base == nullptr -> no residual
+    TensorView out2;              // optional: the output is ALSO written nearest-2x upsampled into this slice
     const f16 *wt = nullptr;      // [cout_pad][kp] fp16, K order (kh, kw, cin), zero padded
     const float *bias = nullptr;  // [cout_pad]
     int B = 1;

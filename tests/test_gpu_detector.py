@@ -261,6 +261,51 @@ def test_device_resident_frames_and_tracker_chain(pkg, wdir):
     det.close()
 
 
+def test_config5_yolov8m_1280_dense_scene(pkg, wdir):
+    """BASELINE config 5: YOLOv8m at 1280x1280 (33 600 anchors, 83 fused convs, channel counts
+    48/96/192/384/576) + the 500-box tracker stress sequence on the same handles."""
+    from oracle import tracker_oracle as T
+    path = os.path.join(str(wdir), "yolov8m_1280.rtw")
+    if not os.path.exists(path):
+        pkg.weights.save(path, pkg.weights.synthetic("m", input_size=640), "m")      # calibrated at 640 (cheaper), run at 1280
+    w, _, _, _ = pkg.weights.load(path)
+    det = pkg.Detector(path, input_size=(1280, 1280), max_det=300, warmup=False)
+    assert det.model.n_anchors == 33600 and det.model.n_convs == 80           # 83 fused convs, the 3 Detect first-conv pairs share a launch
+    assert det.model.conv_flops_per_frame == Y.conv_flops("m", 1280, 1280) == 315742617600
+    frame = pkg.synth.frames(1, 1280, 1280, seed=55)[0]
+    d = det.detect(frame)
+    inp, heads, pred = det.debug_fetch(0)
+    # a few layers in isolation (full m/1280 oracle forward is ~300 GFLOP of NumPy: check the stem-side and head-side ends)
+    names = ["0", "1", "2.cv1", "2.m.0.cv1", "2.m.0.cv2", "2.m.1.cv2", "2.cv2"]
+    gpu = {n: det.debug_layer(n).astype(np.float32) for n in names}
+    x = inp.astype(np.float32)
+    ref0 = Y.conv2d_nhwc(x, *w["0"], stride=2)
+    assert np.abs(ref0 - gpu["0"]).max() <= 2e-3 * np.abs(ref0).max() + 2e-3
+    ref1 = Y.conv2d_nhwc(gpu["0"], *w["1"], stride=2)
+    assert np.abs(ref1 - gpu["1"]).max() <= 2e-3 * np.abs(ref1).max() + 2e-3
+    c = gpu["2.cv1"].shape[2] // 2
+    t = Y.conv2d_nhwc(gpu["2.cv1"][..., c:], *w["2.m.0.cv1"])                        # cin = 48: general K-chunk path
+    assert np.abs(t - gpu["2.m.0.cv1"]).max() <= 2e-3 * np.abs(t).max() + 2e-3
+    t2 = Y.conv2d_nhwc(gpu["2.m.0.cv1"], *w["2.m.0.cv2"]) + gpu["2.cv1"][..., c:]
+    assert np.abs(t2 - gpu["2.m.0.cv2"]).max() <= 2e-3 * np.abs(t2).max() + 2e-3
+    # decode + NMS on the engine's own tensors: exact
+    maps, off = [], 0
+    for s_ in (160, 80, 40):
+        maps.append(heads[off:off + s_ * s_ * 144].reshape(s_, s_, 144).astype(np.float32)); off += s_ * s_ * 144
+    np.testing.assert_allclose(pred, Y.decode(maps), rtol=2e-4, atol=2e-4)
+    dets, _ = Y.non_max_suppression(pred, 0.35, 0.45, None, False, 300)
+    assert len(d) == len(dets)
+    assert np.array_equal(d.xyxy.view(np.int32), Y.scale_boxes(dets[:, :4], 1280, 1280, 1280, 1280).view(np.int32))
+    det.close()
+    # tracker: 500 boxes per frame on a 1280 canvas (fixture G6 covers bit-exactness; here: capacity + speed path)
+    trk = pkg.MultiObjectTracker("bytetrack")
+    orc = T.TrackerOracle()
+    xy, cf, cl = pkg.synth.box_sequence(500, 1280, 12, seed=9)
+    for f in range(12):
+        trk.update(pkg.Detections(xy[f], cf, cl)); orc.update(xy[f], cf, cl)
+    assert np.array_equal(T.state_digest(trk._core.snapshot()), T.state_digest(orc.snapshot()))
+
+
 def test_reference_constructor_behaviour(pkg, wdir, tmp_path):
     path = os.path.join(str(wdir), "yolov8n_160.rtw")
     pkg.weights.save(path, pkg.weights.synthetic("n", input_size=160), "n")

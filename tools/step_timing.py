@@ -31,6 +31,13 @@ for t in range(40, 340):
 det.synchronize()
 wall = (time.perf_counter() - t_all) / 300
 print(f"step wall {wall*1e3:.3f} ms | host submit {np.mean(ts)*1e3:.3f} ms, fetch (incl. wait) {np.mean(tf)*1e3:.3f} ms, last_timing {np.mean(tt)*1e3:.3f} ms")
+per = np.asarray(ts) + np.asarray(tf) + np.asarray(tt)
+for i in range(0, 300, 50):
+    print(f"  steps {i:3d}-{i+49:3d}: {per[i:i+50].mean()*1e3:.3f} ms/step  live tracks stream0 = ?")
+idx = np.argsort(-per)[:6]
+print("slowest steps:", [(int(i), round(float(per[i])*1e3, 2), round(float(ts[i])*1e3,2), round(float(tf[i])*1e3,2)) for i in idx])
+print("median step", float(np.median(per))*1e3)
+print("tracks per stream now:", [len(trk.snapshot(s)["ids"]) for s in range(S)])
 # no tracker / no fetch-wait variants
 for t in range(340, 360):
     submit(t); det.fetch()
