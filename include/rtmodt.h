@@ -110,6 +110,9 @@ int rtmodt_detector_profile(rtmodt_detector *det, int iters, int max_entries, co
 /* Device time (ms, HIP events on the detector's stream) of the batch the last fetch returned:
  * whole pass, and the letterbox + forward-graph part alone. */
 int rtmodt_detector_last_timing(rtmodt_detector *det, float *total_ms, float *forward_ms);
+/* The same batch split into the stages the reference's profiler names (latency_profiler.py:38):
+ * preprocess = letterbox, inference = forward pass + decode, nms = NMS + rescale (device ms). */
+int rtmodt_detector_stage_times(rtmodt_detector *det, float *preprocess_ms, float *inference_ms, float *nms_ms);
 
 /* decode-free NMS on a caller-supplied pre-NMS tensor pred[(4+nc)*A] float32 (the layout
  * ultralytics' non_max_suppression receives): BASELINE config 2's

@@ -13,6 +13,9 @@ library being built):
 * ``_ffi``               -- ctypes binding of ``include/rtmodt.h`` (librtmodt_hip.so)
 * ``weights``            -- flat fused-conv weight format, synthetic weights, BN folding
 * ``synth``              -- deterministic synthetic frames / box sequences
+* ``streams``            -- stream sharding across GPUs + barrier / max-time / stats reduce (RCCL or gloo)
+* ``profiling``          -- ``LatencyProfiler`` (reference: src/profiling/latency_profiler.py:35-143)
+* ``pipeline``           -- the reference's per-frame loop (tools/run_pipeline.py:121-158) around the native classes
 """
 import importlib as _importlib
 
@@ -30,6 +33,6 @@ def __getattr__(name):
     if name in _LAZY:
         mod = _importlib.import_module(_LAZY[name], __name__)
         return getattr(mod, name)
-    if name in ("synth", "weights", "_ffi", "detection", "tracking", "yolo_spec", "streams"):
+    if name in ("synth", "weights", "_ffi", "detection", "tracking", "yolo_spec", "streams", "profiling", "pipeline"):
         return _importlib.import_module("." + name, __name__)
     raise AttributeError(name)

@@ -75,6 +75,7 @@ def lib() -> C.CDLL:
         "rtmodt_detector_profile": (C.c_int, [vp, C.c_int, C.c_int, C.POINTER(C.c_char_p), C.POINTER(f32),
                                               C.POINTER(i64), C.POINTER(i32)]),
         "rtmodt_detector_last_timing": (C.c_int, [vp, C.POINTER(f32), C.POINTER(f32)]),
+        "rtmodt_detector_stage_times": (C.c_int, [vp, C.POINTER(f32), C.POINTER(f32), C.POINTER(f32)]),
         "rtmodt_nms_pred": (C.c_int, [C.c_int, vp, C.c_int, C.c_int, f32, f32, vp, C.c_int, C.c_int, C.c_int,
                                       vp, vp, vp, vp, C.POINTER(i32)]),
         "rtmodt_preprocess": (C.c_int, [C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),

@@ -201,7 +201,7 @@ struct rtmodt_detector {
     struct Slot {
         float *o_xyxy = nullptr, *o_conf = nullptr; int32_t *o_cls = nullptr, *o_anchor = nullptr, *o_n = nullptr;   // device
         float *h_xyxy = nullptr, *h_conf = nullptr; int32_t *h_cls = nullptr, *h_n = nullptr;                        // pinned host
-        hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, done = nullptr, decoded = nullptr;
+        hipEvent_t ev0 = nullptr, evp = nullptr, ev1 = nullptr, ev2 = nullptr, done = nullptr, decoded = nullptr;   // evp: letterbox done
         int n = 0;
     };
     static constexpr int RING_SLOTS = 2;
@@ -795,7 +795,7 @@ void rtmodt_detector_destroy(rtmodt_detector *d) {
     for (auto &sl : d->slots) {
         hipFree(sl.o_xyxy); hipFree(sl.o_conf); hipFree(sl.o_cls); hipFree(sl.o_anchor); hipFree(sl.o_n);
         hipHostFree(sl.h_xyxy); hipHostFree(sl.h_conf); hipHostFree(sl.h_cls); hipHostFree(sl.h_n);
-        for (hipEvent_t e : {sl.ev0, sl.ev1, sl.ev2, sl.done, sl.decoded}) if (e) hipEventDestroy(e);
+        for (hipEvent_t e : {sl.ev0, sl.evp, sl.ev1, sl.ev2, sl.done, sl.decoded}) if (e) hipEventDestroy(e);
     }
     if (d->stream) hipStreamDestroy(d->stream);
     delete d;
@@ -856,7 +856,7 @@ static int detector_create_impl(const rtmodt_det_cfg *cfg, rtmodt_detector *d) {
         RT_HIP(hipHostMalloc((void **)&sl.h_conf, BD * sizeof(float), hipHostMallocDefault));
         RT_HIP(hipHostMalloc((void **)&sl.h_cls, BD * sizeof(int32_t), hipHostMallocDefault));
         RT_HIP(hipHostMalloc((void **)&sl.h_n, d->B * sizeof(int32_t), hipHostMallocDefault));
-        RT_HIP(hipEventCreate(&sl.ev0)); RT_HIP(hipEventCreate(&sl.ev1)); RT_HIP(hipEventCreate(&sl.ev2));
+        RT_HIP(hipEventCreate(&sl.ev0)); RT_HIP(hipEventCreate(&sl.evp)); RT_HIP(hipEventCreate(&sl.ev1)); RT_HIP(hipEventCreate(&sl.ev2));
         RT_HIP(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
         RT_HIP(hipEventCreateWithFlags(&sl.decoded, hipEventDisableTiming));
     }
@@ -926,6 +926,7 @@ int rtmodt_detector_enqueue_batch(rtmodt_detector *d, const uint8_t *const *fram
     d->cur_dense = d->head;                            // ring slot == dense set == graph
     RT_HIP(hipEventRecord(sl.ev0, d->stream));
     RT_TRY(launch_letterbox(d->fptrs, stride_bytes, lg, d->tabs, img, d->B, d->stream));
+    RT_HIP(hipEventRecord(sl.evp, d->stream));
     if (!d->graph_execs.empty() && !d->want_pred) RT_TRY(forward_graphs(d));
     else RT_TRY(forward_eager(d));
     RT_HIP(hipEventRecord(sl.ev1, d->stream));
@@ -1116,6 +1117,17 @@ int rtmodt_detector_last_timing(rtmodt_detector *d, float *total_ms, float *forw
             prev_end = t1;
         }
     }
+    return RTMODT_OK;
+}
+
+int rtmodt_detector_stage_times(rtmodt_detector *d, float *preprocess_ms, float *inference_ms, float *nms_ms) {
+    RT_CHECK(d && d->last_fetched >= 0, RTMODT_E_INVALID, "no batch has been fetched");
+    RT_HIP(hipSetDevice(d->device));
+    const rtmodt_detector::Slot &sl = d->slots[d->last_fetched];
+    RT_HIP(hipEventSynchronize(sl.ev2));
+    if (preprocess_ms) RT_HIP(hipEventElapsedTime(preprocess_ms, sl.ev0, sl.evp));
+    if (inference_ms) RT_HIP(hipEventElapsedTime(inference_ms, sl.evp, sl.ev1));
+    if (nms_ms) RT_HIP(hipEventElapsedTime(nms_ms, sl.ev1, sl.ev2));
     return RTMODT_OK;
 }
 

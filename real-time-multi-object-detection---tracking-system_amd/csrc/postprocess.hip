@@ -184,62 +184,96 @@ __device__ __forceinline__ int pp_scan_flag(bool flag, int *wsum, int &total) {
 constexpr int SBOX_LDS_MAX = 2048;          // sorted boxes kept in LDS (32 KiB); beyond: global scratch
 constexpr int RANK_LDS_MAX = 2048;          // up to here: LDS rank sort (no barriers); above: bitonic network
 
-// Greedy suppression over boxes sorted by descending score.  A shared LDS bitmap holds
-// the "removed or already kept" bits; every thread finds the next kept box `cur` by itself
-// from that bitmap (same-address LDS reads broadcast, so no reduction and no hot-spot atomic),
-// then tests the boxes it owns (sorted positions t, t+256, ... -- their alive bits live in
-// two registers) against `cur` and publishes removals with one atomicOr each.  ONE barrier
-// per kept box.  Stops after max_det keeps (keep[:max_det], App. B.3 step 6).
+// Greedy suppression over boxes sorted by descending score, 64 sorted positions at a time
+// (exactly torchvision's result: a box is kept iff no earlier KEPT box overlaps it):
+//   A. the 64 x 64 overlap matrix of the block is formed by the whole workgroup (thread t:
+//      row t>>2, columns 16 (t&3) ..), rows land in LDS as 64-bit masks;
+//   B. every wave resolves the block serially but entirely in registers -- lane i holds row i,
+//      v_readlane with a scalar index walks the rows: no LDS traffic, no barrier, ~64 short steps;
+//   C. the boxes kept in this block are applied to all later positions: each thread owns the
+//      sorted positions t, t+256, ... (alive bits in two registers) and publishes removals
+//      with one LDS atomicOr each.
+// Two barriers per 64 candidates instead of one (or two) per kept box; stops at max_det keeps.
 template <bool LDSBOX>
 __device__ __forceinline__ int greedy_nms(const float4 *lbox, const float4 *gbox, int n, int max_det, double thr,
-                                          unsigned long long *removed, int *sel) {
-    const int tid = threadIdx.x;
-    const int nwords = (n + 63) >> 6;
+                                          unsigned long long *removed, unsigned long long *rowmask, int *sel) {
+    const int tid = threadIdx.x, lane = tid & 63;
     unsigned long long alive0 = 0ull, alive1 = 0ull;
     for (int k = 0; k < 64; ++k) {
         if (tid + PP_THREADS * k < n) alive0 |= 1ull << k;
         if (tid + PP_THREADS * (64 + k) < n) alive1 |= 1ull << k;
     }
-    int kept = 0, pos = 0;
-    while (pos < n) {
-        // next position >= pos whose bit is clear
-        int w = pos >> 6, cur = -1;
-        unsigned long long avail = ~removed[w] & ~((1ull << (pos & 63)) - 1ull);
-        while (true) {
-            int last = n - (w << 6);
-            if (last < 64) avail &= (1ull << last) - 1ull;
-            if (avail) { cur = (w << 6) + __builtin_ctzll(avail); break; }
-            if (++w >= nwords) break;
-            avail = ~removed[w];
+    auto box_at = [&](int j) -> float4 { return LDSBOX ? lbox[j] : gbox[j]; };
+    int kept = 0;
+    const int nblocks = (n + 63) >> 6;
+    for (int b = 0; b < nblocks && kept < max_det; ++b) {
+        const int base = b << 6;
+        const int cnt = min(64, n - base);
+        unsigned long long avail = ~removed[b];
+        if (cnt < 64) avail &= (1ull << cnt) - 1ull;
+        if (avail == 0ull) continue;                          // uniform: everybody reads the same word
+        // ---- A: overlap rows of the block ----
+        {
+            const int i = tid >> 2, j0 = (tid & 3) << 4;
+            unsigned long long part = 0ull;
+            if (i < cnt && ((avail >> i) & 1ull)) {
+                const float4 bi = box_at(base + i);
+                const float ai = (bi.z - bi.x) * (bi.w - bi.y);
+#pragma unroll 4
+                for (int jj = 0; jj < 16; ++jj) {
+                    const int j = j0 + jj;
+                    if (j > i && j < cnt && ((avail >> j) & 1ull) && nms_overlaps(bi, ai, box_at(base + j), thr)) part |= 1ull << j;
+                }
+            }
+            part |= __shfl_xor(part, 1);
+            part |= __shfl_xor(part, 2);
+            if ((tid & 3) == 0) rowmask[i] = part;
         }
-        if (cur < 0) break;
-        if (tid == 0) sel[kept] = cur;
-        ++kept;
-        pos = cur + 1;
+        __syncthreads();
+        // ---- B: serial resolve in registers (identical in every wave) ----
+        const unsigned long long mine = rowmask[lane];
+        const unsigned lo = (unsigned)mine, hi = (unsigned)(mine >> 32);
+        unsigned long long live = avail, keepm = 0ull;
+        for (int i = 0; i < cnt; ++i) {
+            if ((live >> i) & 1ull) {
+                keepm |= 1ull << i;
+                unsigned long long row = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)hi, i) << 32) |
+                                         (unsigned)__builtin_amdgcn_readlane((int)lo, i);
+                live &= ~row;
+            }
+        }
+        int nk = __popcll(keepm);
+        if (kept + nk > max_det) {                            // keep[:max_det]
+            int drop = kept + nk - max_det;
+            while (drop--) keepm &= ~(1ull << (63 - __builtin_clzll(keepm)));
+            nk = max_det - kept;
+        }
+        if (tid < 64 && ((keepm >> tid) & 1ull)) sel[kept + __popcll(keepm & ((1ull << tid) - 1ull))] = base + tid;
+        kept += nk;
         if (kept >= max_det) break;
-        const float4 cb = LDSBOX ? lbox[cur] : gbox[cur];
-        const float carea = (cb.z - cb.x) * (cb.w - cb.y);
-        if ((cur & (PP_THREADS - 1)) == tid) {                // the kept box is mine: drop it from my pool
-            int k = cur / PP_THREADS;
-            if (k < 64) alive0 &= ~(1ull << k); else alive1 &= ~(1ull << (k - 64));
+        // ---- C: apply this block's kept boxes to every later position I own ----
+        const int first_later = base + 64;
+        {   // positions before the next block are settled: drop them from my pool
+            int kmin = first_later > tid ? (first_later - tid + PP_THREADS - 1) / PP_THREADS : 0;
+            if (kmin >= 64) { alive0 = 0ull; int k1 = kmin - 64; alive1 = k1 >= 64 ? 0ull : alive1 & ~((1ull << k1) - 1ull); }
+            else alive0 &= ~((1ull << kmin) - 1ull);
         }
-        for (unsigned long long m = alive0; m; m &= m - 1) {
-            int k = __builtin_ctzll(m);
-            int j = tid + PP_THREADS * k;
-            if (j > cur && nms_overlaps(cb, carea, LDSBOX ? lbox[j] : gbox[j], thr)) {
-                alive0 &= ~(1ull << k);
-                atomicOr(&removed[j >> 6], 1ull << (j & 63));
+        for (unsigned long long km = keepm; km; km &= km - 1) {
+            const int ci = base + __builtin_ctzll(km);
+            const float4 cb = box_at(ci);
+            const float carea = (cb.z - cb.x) * (cb.w - cb.y);
+            for (unsigned long long m = alive0; m; m &= m - 1) {
+                int k = __builtin_ctzll(m);
+                int j = tid + PP_THREADS * k;
+                if (nms_overlaps(cb, carea, box_at(j), thr)) { alive0 &= ~(1ull << k); atomicOr(&removed[j >> 6], 1ull << (j & 63)); }
+            }
+            for (unsigned long long m = alive1; m; m &= m - 1) {
+                int k = __builtin_ctzll(m);
+                int j = tid + PP_THREADS * (64 + k);
+                if (nms_overlaps(cb, carea, box_at(j), thr)) { alive1 &= ~(1ull << k); atomicOr(&removed[j >> 6], 1ull << (j & 63)); }
             }
         }
-        for (unsigned long long m = alive1; m; m &= m - 1) {
-            int k = __builtin_ctzll(m);
-            int j = tid + PP_THREADS * (64 + k);
-            if (j > cur && nms_overlaps(cb, carea, LDSBOX ? lbox[j] : gbox[j], thr)) {
-                alive1 &= ~(1ull << k);
-                atomicOr(&removed[j >> 6], 1ull << (j & 63));
-            }
-        }
-        __syncthreads();                                      // removals visible before the next search
+        __syncthreads();                                      // removals visible; rowmask reusable
     }
     return kept;
 }
@@ -249,7 +283,8 @@ __global__ __launch_bounds__(PP_THREADS) void nms_kernel(NmsArgs a, int dbg_stop
     unsigned long long *skeys = (unsigned long long *)smem;                  // [SORT_LDS_MAX] sort keys, kept for the index part
     float4 *lbox = (float4 *)(skeys + SORT_LDS_MAX);                         // [SBOX_LDS_MAX] sorted, class-offset boxes
     unsigned long long *removed = (unsigned long long *)(lbox + SBOX_LDS_MAX);   // [ceil(MAX_NMS/64)] removed-or-kept bitmap
-    int *sel = (int *)(removed + (MAX_NMS + 63) / 64);                        // [max_det]
+    unsigned long long *rowmask = removed + (MAX_NMS + 63) / 64;              // [64] overlap rows of the block being resolved
+    int *sel = (int *)(rowmask + 64);                                         // [max_det]
     __shared__ int wsum[PP_WAVES + 1];
 
     const int b = blockIdx.x, tid = threadIdx.x;
@@ -264,13 +299,23 @@ __global__ __launch_bounds__(PP_THREADS) void nms_kernel(NmsArgs a, int dbg_stop
     // ---- 1. compaction in anchor order: thread t owns the contiguous anchors [t*per, (t+1)*per) ----
     const int per = (A + PP_THREADS - 1) / PP_THREADS;
     const int lo = min(tid * per, A), hi = min(lo + per, A);
+    constexpr int REG_SCORES = 40;                           // 8400 anchors / 256 threads = 33
+    const bool in_regs = per <= REG_SCORES;                  // uniform
+    float sc[REG_SCORES];
     int mine = 0;
-    for (int i0 = lo; i0 < hi; i0 += 8) {                    // 8 independent loads in flight per trip
-        float v[8];
+    if (in_regs) {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) v[k] = i0 + k < hi ? score[i0 + k] : -1.0f;
+        for (int k = 0; k < REG_SCORES; ++k) sc[k] = lo + k < hi ? score[lo + k] : -1.0f;   // all loads in flight at once
 #pragma unroll
-        for (int k = 0; k < 8; ++k) mine += v[k] >= 0.0f;
+        for (int k = 0; k < REG_SCORES; ++k) mine += sc[k] >= 0.0f;
+    } else {
+        for (int i0 = lo; i0 < hi; i0 += 8) {                // 8 independent loads in flight per trip
+            float v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = i0 + k < hi ? score[i0 + k] : -1.0f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) mine += v[k] >= 0.0f;
+        }
     }
     int n, base;
     {   // block exclusive scan of the per-thread counts
@@ -295,19 +340,25 @@ __global__ __launch_bounds__(PP_THREADS) void nms_kernel(NmsArgs a, int dbg_stop
     }
     if (dbg_stop == 1) return;
     const bool lds_sort = n <= SORT_LDS_MAX;
+    auto put_key = [&](int o, float v, int anchor) {
+        unsigned long long key = ((unsigned long long)__float_as_uint(v) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)anchor);
+        if (lds_sort) skeys[o] = key; else gkeys[o] = key;
+    };
     if (mine) {
         int o = base;
-        for (int i0 = lo; i0 < hi; i0 += 8) {
-            float v[8];
+        if (in_regs) {
 #pragma unroll
-            for (int k = 0; k < 8; ++k) v[k] = i0 + k < hi ? score[i0 + k] : -1.0f;
+            for (int k = 0; k < REG_SCORES; ++k)
+                if (sc[k] >= 0.0f) put_key(o++, sc[k], lo + k);
+        } else {
+            for (int i0 = lo; i0 < hi; i0 += 8) {
+                float v[8];
 #pragma unroll
-            for (int k = 0; k < 8; ++k)
-                if (v[k] >= 0.0f) {
-                    unsigned long long key = ((unsigned long long)__float_as_uint(v[k]) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)(i0 + k));
-                    if (lds_sort) skeys[o] = key; else gkeys[o] = key;
-                    ++o;
-                }
+                for (int k = 0; k < 8; ++k) v[k] = i0 + k < hi ? score[i0 + k] : -1.0f;
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    if (v[k] >= 0.0f) put_key(o++, v[k], i0 + k);
+            }
         }
     }
     __syncthreads();
@@ -327,6 +378,7 @@ __global__ __launch_bounds__(PP_THREADS) void nms_kernel(NmsArgs a, int dbg_stop
         const int E = (n + PP_THREADS - 1) / PP_THREADS;     // keys per thread actually in use (uniform)
         auto rank_loop = [&](auto ne) {
             constexpr int NE = decltype(ne)::value;
+#pragma unroll 4
             for (int j = 0; j < (npad >> 1); ++j) {
                 ulonglong2 kk = k2[j];
 #pragma unroll
@@ -385,8 +437,8 @@ __global__ __launch_bounds__(PP_THREADS) void nms_kernel(NmsArgs a, int dbg_stop
 
     // ---- 3. greedy suppression ----
     const double thr = (double)a.iou;
-    const int kept = lds_box ? greedy_nms<true>(lbox, gsbox, n, a.max_det, thr, removed, sel)
-                             : greedy_nms<false>(lbox, gsbox, n, a.max_det, thr, removed, sel);
+    const int kept = lds_box ? greedy_nms<true>(lbox, gsbox, n, a.max_det, thr, removed, rowmask, sel)
+                             : greedy_nms<false>(lbox, gsbox, n, a.max_det, thr, removed, rowmask, sel);
     __syncthreads();
     if (dbg_stop == 5) return;
 
@@ -411,7 +463,7 @@ __global__ __launch_bounds__(PP_THREADS) void nms_kernel(NmsArgs a, int dbg_stop
 }
 
 int launch_nms(const NmsArgs &a, hipStream_t s) {
-    size_t smem = (size_t)SORT_LDS_MAX * 8 + (size_t)SBOX_LDS_MAX * 16 + (size_t)((MAX_NMS + 63) / 64) * 8 + (size_t)a.max_det * 4 + 16;
+    size_t smem = (size_t)SORT_LDS_MAX * 8 + (size_t)SBOX_LDS_MAX * 16 + (size_t)((MAX_NMS + 63) / 64) * 8 + 64 * 8 + (size_t)a.max_det * 4 + 16;
     RT_CHECK(smem <= 150 * 1024, RTMODT_E_INVALID, "nms: max_det %d too large", a.max_det);
     RT_HIP(hipFuncSetAttribute((const void *)nms_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     static const int dbg_stop = getenv("RTMODT_NMS_STOP") ? atoi(getenv("RTMODT_NMS_STOP")) : 0;   // timing-only builds of the phases

@@ -243,6 +243,12 @@ class Detector:
         _ffi.check(_ffi.lib().rtmodt_detector_profile(self.model.handle, iters, cap, names, ms, fl, C.byref(n)))
         return [(names[i].decode(), float(ms[i]), int(fl[i])) for i in range(min(n.value, cap))]
 
+    def stage_times(self):
+        """Device ms of the last fetched batch: (preprocess, inference, nms) -- HIP events."""
+        a, b, c = C.c_float(), C.c_float(), C.c_float()
+        _ffi.check(_ffi.lib().rtmodt_detector_stage_times(self.model.handle, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
+
     def last_timing(self):
         a, b = C.c_float(), C.c_float()
         _ffi.check(_ffi.lib().rtmodt_detector_last_timing(self.model.handle, C.byref(a), C.byref(b)))

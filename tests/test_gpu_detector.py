@@ -321,3 +321,27 @@ def test_reference_constructor_behaviour(pkg, wdir, tmp_path):
     with pytest.raises(pkg._ffi.RtmodtError) as e:
         pkg.Detector(str(bad), input_size=(160, 160))
     assert e.value.code == pkg._ffi.E_IO
+
+
+def test_pipeline_loop_and_stage_profiler(pkg, wdir):
+    """the reference's per-frame loop with the sync-bracketed stage profiler,
+    including the sub-stages (preprocess / nms) the reference names but never measures."""
+    from oracle import tracker_oracle as T
+    det, _ = make_detector(pkg, wdir, "s", 320)
+    trk = pkg.MultiObjectTracker("bytetrack")
+    frames = pkg.synth.frames(6, 320, 320, seed=12)
+    prof = pkg.profiling.LatencyProfiler(gpu_sync=True, warmup_frames=10, log_interval=20)
+    assert prof.gpu_sync is True
+    out = pkg.pipeline.run(pkg.pipeline.SyntheticSource(frames), det, trk, prof, max_frames=50)
+    for st in ("decode", "preprocess", "inference", "nms", "tracking", "total"):
+        assert out[f"{st}_mean_ms"] > 0 and out[f"{st}_p50_ms"] > 0 and out[f"{st}_p99_ms"] >= out[f"{st}_p50_ms"], st
+    parts = sum(out[f"{s}_mean_ms"] for s in ("decode", "preprocess", "inference", "nms", "tracking"))
+    assert abs(parts - out["total_mean_ms"]) < 1e-6 * max(1.0, parts)
+    assert out["fps_mean"] > 0 and out["last_tracks"] == 0               # facade returns [] like the reference
+    # the loop fed the tracker exactly the detector's detections: replay them through the oracle
+    orc = T.TrackerOracle()
+    for i in range(50):
+        d = det.detect(frames[i % 6])
+        orc.update(d.xyxy, d.confidence, d.class_id)
+    assert np.array_equal(T.state_digest(trk._core.snapshot()), T.state_digest(orc.snapshot()))
+    det.close()
