@@ -216,5 +216,138 @@ def from_state_dict(sd: dict, scale: str = "s", nc: int = 80, reg_max: int = 16)
     return out
 
 
+# ---------------------------------------------------------------------------------------
+# Reading an Ultralytics checkpoint without Ultralytics
+# ---------------------------------------------------------------------------------------
+class _Inert:
+    """Stand-in for every class the restricted unpickler does not know (``ultralytics.*``,
+    ``torch.nn.*`` modules, loss objects, ...): holds whatever state the pickle restores,
+    runs no code of the original class."""
+
+    def __init__(self, *a, **k):
+        self._args = a
+
+    def __setstate__(self, state):
+        if isinstance(state, dict):
+            self.__dict__.update(state)
+        else:
+            self.__dict__["_state"] = state
+
+    def __call__(self, *a, **k):                     # objects rebuilt through REDUCE with odd callables
+        return _Inert()
+
+
+_STORAGE_DTYPES = {"FloatStorage": np.float32, "HalfStorage": np.float16, "DoubleStorage": np.float64,
+                   "LongStorage": np.int64, "IntStorage": np.int32, "ShortStorage": np.int16, "CharStorage": np.int8,
+                   "ByteStorage": np.uint8, "BoolStorage": np.bool_, "BFloat16Storage": "bf16"}
+
+
+def read_pt(path: str) -> dict:
+    """``state_dict``-like ``{dotted.name: np.ndarray}`` of the ``model`` (or ``ema``) entry of a
+    ``torch.save`` zip checkpoint, obtained with a RESTRICTED unpickler: only tensors are
+    materialised, every unknown class becomes an inert container, no code from the
+    checkpoint's classes (and no ``ultralytics`` import) ever runs.  This replaces
+    ``YOLO(path)`` at src/detection/detector.py:84."""
+    import collections
+    import pickle
+    import zipfile
+
+    zf = zipfile.ZipFile(path)
+    names = zf.namelist()
+    pkl = next(n for n in names if n.endswith("data.pkl"))
+    root = pkl[: -len("data.pkl")]
+
+    class _StorageType:
+        def __init__(self, name):
+            self.dtype = _STORAGE_DTYPES[name]
+
+    def _rebuild_tensor_v2(storage, offset, size, stride, *unused):
+        arr, dt = storage
+        if len(size) == 0:
+            return arr[offset:offset + 1].reshape(())
+        a = np.lib.stride_tricks.as_strided(arr[offset:], shape=tuple(size), strides=tuple(s * arr.itemsize for s in stride))
+        a = np.array(a)                                   # own, contiguous copy
+        if dt == "bf16":
+            a = (a.astype(np.uint32) << 16).view(np.float32)
+        return a
+
+    def _rebuild_parameter(data, requires_grad=False, backward_hooks=None, *a):
+        return data
+
+    class U(pickle.Unpickler):
+        def find_class(self, module, name):
+            if module == "collections" and name == "OrderedDict":
+                return collections.OrderedDict
+            if module == "torch._utils" and name in ("_rebuild_tensor_v2", "_rebuild_tensor"):
+                return _rebuild_tensor_v2
+            if module == "torch._utils" and name in ("_rebuild_parameter", "_rebuild_parameter_with_state"):
+                return _rebuild_parameter
+            if module in ("torch", "torch.storage") and name in _STORAGE_DTYPES:
+                return _StorageType(name)
+            if module == "torch" and name == "Size":
+                return tuple
+            if module == "builtins" and name in ("set", "frozenset", "list", "dict", "tuple", "int", "float", "bool", "str", "slice", "range", "complex", "bytes", "bytearray"):
+                return getattr(__import__("builtins"), name)
+            return type(name, (_Inert,), {"__module__": module})     # inert: never the real class
+
+        def persistent_load(self, pid):
+            # ('storage', storage_type, key, location, numel)
+            kind, stype, key = pid[0], pid[1], pid[2]
+            assert kind == "storage"
+            dt = stype.dtype if isinstance(stype, _StorageType) else np.float32
+            raw = zf.read(f"{root}data/{key}")
+            arr = np.frombuffer(raw, dtype=np.uint16 if dt == "bf16" else dt)
+            return (arr, dt)
+
+    ckpt = U(zf.open(pkl)).load()
+    model = ckpt
+    if isinstance(ckpt, dict):
+        model = ckpt.get("ema") or ckpt.get("model") or ckpt
+    out = {}
+
+    def walk(obj, prefix):
+        d = getattr(obj, "__dict__", None)
+        if isinstance(obj, dict) and not d:               # a plain state_dict
+            for k, v in obj.items():
+                if isinstance(v, np.ndarray):
+                    out[prefix + str(k)] = v
+            return
+        if not d:
+            return
+        for group in ("_parameters", "_buffers"):
+            for k, v in (d.get(group) or {}).items():
+                if isinstance(v, np.ndarray):
+                    out[prefix + k] = v
+        for k, v in (d.get("_modules") or {}).items():
+            walk(v, prefix + k + ".")
+
+    walk(model, "")
+    if not out:
+        raise ValueError(f"{path}: no tensors found (not a torch zip checkpoint of a module or state_dict?)")
+    return out
+
+
+def infer_scale(sd: dict) -> str:
+    """Model scale from the stem / backbone widths of a state_dict."""
+    c1 = int(np.asarray(sd["model.0.conv.weight"]).shape[0])
+    n_c2f = len([k for k in sd if k.startswith("model.2.m.") and k.endswith(".cv1.conv.weight")])
+    for s in "nsmlx":
+        from .yolo_spec import repeats, width
+        if width(64, s) == c1 and repeats(3, s) == n_c2f:
+            return s
+    raise ValueError(f"cannot infer YOLOv8 scale from stem width {c1} / {n_c2f} bottlenecks")
+
+
+def convert_pt(pt_path: str, out_path: str, scale: str | None = None) -> tuple:
+    """``.pt`` -> ``RTMODTW1``: restricted read, BN folding, NHWC weight order, fp16.  Returns (scale, nc)."""
+    sd = read_pt(pt_path)
+    sd = {k: np.asarray(v, dtype=np.float32) if np.asarray(v).dtype.kind == "f" else np.asarray(v) for k, v in sd.items()}
+    scale = scale or infer_scale(sd)
+    nc = int(sd["model.22.cv3.0.2.weight"].shape[0])
+    fused = from_state_dict(sd, scale, nc)
+    save(out_path, fused, scale, nc)
+    return scale, nc
+
+
 def spec(scale="s", nc=80, reg_max=16) -> list[ConvSpec]:
     return conv_table(scale, nc, reg_max)
