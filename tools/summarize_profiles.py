@@ -1,0 +1,91 @@
+#!/usr/bin/env python3
+"""Distil gpurun_out/r01/* (raw rocprofv3 output of `bench.py`) into the small files committed
+under profiles/r01/ and profiles/traffic_current.json.
+    python tools/summarize_profiles.py [gpurun_out/r01] [profiles/r01]
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+src = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/r01"
+dst = sys.argv[2] if len(sys.argv) > 2 else "profiles/r01"
+os.makedirs(dst, exist_ok=True)
+
+
+def one(pattern):
+    g = glob.glob(os.path.join(src, pattern))
+    return g[0] if g else None
+
+
+for name in ("bench_default.json", "bench_host_frames.json", "bench_streams16.json", "bench_streams32.json", "stats_bench.json",
+             "pipeline_640.json", "pipeline_1080p.json", "layers.txt"):
+    p = os.path.join(src, name)
+    if os.path.exists(p):
+        shutil.copy(p, os.path.join(dst, name))
+st = one("stats/*/*_kernel_stats.csv")
+if st:
+    shutil.copy(st, os.path.join(dst, "kernel_stats.csv"))
+
+
+def per_step(dirname, counters, steps=10):
+    f = one(f"{dirname}/*/*_counter_collection.csv")
+    if not f:
+        return None
+    per = collections.defaultdict(dict)
+    for r in csv.DictReader(open(f)):
+        d = per[r["Dispatch_Id"]]
+        d["name"] = r["Kernel_Name"]
+        d[r["Counter_Name"]] = float(r["Counter_Value"])
+        d["dur"] = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+    ids = sorted(per, key=int)
+    lb = [i for i in ids if "letterbox" in per[i]["name"]]
+    a, b = int(lb[-steps - 1]), int(lb[-1])
+    sel = [per[i] for i in ids if a <= int(i) < b]
+    agg = collections.defaultdict(lambda: collections.defaultdict(float))
+    for d in sel:
+        k = d["name"].replace("void rtmodt::", "").replace("rtmodt::", "")
+        k = k.split("(")[0] if "<" in k else k[:48]
+        agg[k]["calls"] += 1.0 / steps
+        agg[k]["us"] += d["dur"] / 1e3 / steps
+        for c in counters:
+            agg[k][c] += d.get(c, 0.0) / steps
+    return agg
+
+
+rows = []
+fetch = per_step("pmc_fetch", ["FETCH_SIZE"])
+write = per_step("pmc_write", ["WRITE_SIZE"])
+sq = per_step("pmc_sq", ["SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY",
+                         "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_INSTS_VALU_MFMA_MOPS_F16", "SQ_INSTS_MFMA"])
+post = ("nms_kernel", "tracker_update", "__amd_rocclr")
+if fetch and write:
+    F = sum(v["FETCH_SIZE"] for k, v in fetch.items() if not k.startswith(post))
+    W = sum(v["WRITE_SIZE"] for k, v in write.items() if not k.startswith(post))
+    hbm = int((2 * F + W) * 1024)
+    json.dump({"workload_key": "s-640-8", "hbm_bytes_per_step": hbm, "fetch_size_kb_per_step": round(F, 1),
+               "write_size_kb_per_step": round(W, 1),
+               "source": "profiles/r01/pmc_per_kernel.csv: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over "
+                         "`bench.py --steps 20`; forward-pass launches of the last 10 steps; bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 "
+                         "(gfx950: FETCH_SIZE counts half of a wide coalesced read, MI355X_MICROARCH.md section HBM)"},
+              open("profiles/traffic_current.json", "w"), indent=1)
+    with open(os.path.join(dst, "pmc_per_kernel.csv"), "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["kernel", "launches_per_step", "us_per_step", "FETCH_SIZE_KB_per_step", "WRITE_SIZE_KB_per_step",
+                    "wave_wait_any_pct", "wave_wait_inst_pct", "wave_active_pct", "mfma_busy_over_sq_busy", "MFMA_MOPS_F16_per_step"])
+        for k in sorted(fetch, key=lambda k: -fetch[k]["us"]):
+            s = sq.get(k, {}) if sq else {}
+            wc = s.get("SQ_WAVE_CYCLES", 0) or 1
+            w.writerow([k, round(fetch[k]["calls"], 2), round(fetch[k]["us"], 2), round(fetch[k]["FETCH_SIZE"], 1),
+                        round(write.get(k, {}).get("WRITE_SIZE", 0), 1),
+                        round(100 * s.get("SQ_WAIT_ANY", 0) / wc, 1), round(100 * s.get("SQ_WAIT_INST_ANY", 0) / wc, 1),
+                        round(100 * s.get("SQ_ACTIVE_INST_ANY", 0) / wc, 1),
+                        round(s.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / (s.get("SQ_BUSY_CYCLES", 0) or 1), 3),
+                        round(s.get("SQ_INSTS_VALU_MFMA_MOPS_F16", 0))])
+    print("HBM bytes per step", hbm / 1e6, "MB  (FETCH", F / 1024, "MB raw, WRITE", W / 1024, "MB)")
+if os.path.exists(os.path.join(src, "bench_default.json")):
+    b = json.load(open(os.path.join(src, "bench_default.json")))
+    print("bench:", b["value"], "fps;", b["roofline"]["achieved"], "TFLOP/s;", b.get("latency_single_stream_ms"), b.get("cpu_baseline"))
