@@ -46,6 +46,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend: nccl (= RCCL, default) or gloo (rehearsal on a 1-GPU box)")
+    ap.add_argument("--one-device", action="store_true", help="rehearsal only: every rank uses cuda:0")
     ap.add_argument("--host-frames", action="store_true", help="feed host (pageable) frames: PCIe-inclusive rate, never the headline value")
     return ap.parse_args()
 
@@ -91,14 +93,14 @@ def main():
     args = parse()
     import rtmodt_amd  # noqa: F401
     pkg = sys.modules["rtmodt_amd"]
-    sync = pkg.streams.NodeSync(backend="nccl")          # RCCL; no process group when WORLD_SIZE == 1
+    sync = pkg.streams.NodeSync(backend=args.backend)    # RCCL; no process group when WORLD_SIZE == 1
     rank, local_rank, world = sync.rank, sync.local_rank, sync.world
     if args.gpus != world and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
     from importlib import import_module
     core_cls = import_module(pkg.__name__ + ".tracking.tracker")._ByteTrackCore
-    dev = local_rank
+    dev = 0 if args.one_device else local_rank
     S, R, size = args.streams, args.ring, args.size
 
     # ---- synthetic weights (seeded; same file on every rank) ----
@@ -178,6 +180,7 @@ def main():
     n_det, n_tracks_node = sync.sum_stats([n_det, n_tracks])
 
     if rank != 0:
+        sync.barrier()                               # wait for rank 0's extra (untimed) measurements, then leave together
         sync.close()
         return
 
@@ -246,6 +249,7 @@ def main():
             weights = pkg.weights.load(wpath)[0]
         res["cpu_baseline"] = cpu_baseline(pkg, weights, args)
     print(json.dumps(res), flush=True)
+    sync.barrier()
     sync.close()
 
 

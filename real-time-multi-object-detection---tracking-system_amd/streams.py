@@ -57,6 +57,7 @@ class NodeSync:
 
     @property
     def device(self):
+        """Where the tiny reduce tensors live: the rank's GPU for RCCL, host memory for gloo."""
         return f"cuda:{self.local_rank}" if self.backend == "nccl" else "cpu"
 
     def barrier(self) -> None:
