@@ -1,0 +1,283 @@
+// bottleneck.hip -- a whole YOLOv8 Bottleneck (Conv3x3+SiLU -> Conv3x3+SiLU [+ x]) in ONE launch,
+// the intermediate activation never leaving the CU ("C2f bottleneck pairs kept in LDS").
+//
+// Replaces two conv launches of the C2f modules ultralytics builds for the reference's
+// `YOLO.predict` (/root/reference/src/detection/detector.py:100-111; SURVEY.md App. A:
+// Bottleneck(c, c, shortcut) = Conv(c,c,3) -> Conv(c,c,3), + x iff shortcut).
+//
+// One 512-thread workgroup (8 wave64s, 2 per SIMD) owns a TH x TW tile of output pixels of one
+// image:
+//   0. the (TH+4) x (TW+4) input patch (2-pixel halo) is DMA'd into LDS once -- all 9 taps of
+//      the first conv read it from there (9x less global->LDS traffic than an implicit GEMM
+//      that refetches per tap); out-of-tensor pixels are fetched from a zero page;
+//   1. conv1 as an implicit GEMM over the (TH+2) x (TW+2) halo-1 region, weights streamed
+//      tap by tap through a 2-stage LDS ring; epilogue = bias + SiLU -> fp16 -> LDS (zero
+//      where the position lies outside the image: that IS conv2's zero padding);
+//   2. conv2 over the TH x TW tile from that LDS image; epilogue = bias + SiLU (+ residual)
+//      -> NHWC global store.
+// Channel counts 32 / 64 / 128 (the P2 / P3 / P4 bottlenecks of YOLOv8 n..m); LDS images are
+// [64-channel plane][pixel][128 B] (or [pixel][64 B] for c = 32) with the same XOR swizzle as
+// conv.hip, so every fragment read is a conflict-free ds_read_b128.
+#include <algorithm>
+
+#include "kernels.h"
+
+namespace rtmodt {
+
+namespace {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float silu_b(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+
+__device__ __forceinline__ void dma16(const f16 *src, unsigned char *dst) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                     (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+}
+
+struct BneckArgs {
+    const f16 *in, *w1, *w2, *res, *zeros;
+    const float *b1, *b2;
+    f16 *out;
+    int B, H, W;
+    int in_Hp, in_Wp, in_cs;                 // input tensor has a 1-pixel border
+    int out_Hp, out_Wp, out_cs, out_pad;
+    int res_Hp, res_Wp, res_cs, res_pad;
+    int kp;                                  // weight row stride (= 9 * CH)
+    int tiles_x, tiles_y;
+};
+
+constexpr int BN_THREADS = 512, BN_WAVES = 8;
+
+template <int CH, int TH, int TW>
+struct BneckGeom {
+    static constexpr int CW = CH < 64 ? CH : 64;          // channels per LDS plane
+    static constexpr int CB = CW * 2;                     // bytes per pixel row in a plane
+    static constexpr int NCH = CH / CW;                   // planes
+    static constexpr int RPP = CB == 128 ? 8 : 16;        // rows (pixels / couts) per 1-KiB DMA piece
+    static constexpr int SUB = CW / 32;                   // MFMA k-substeps per (tap, plane)
+    static constexpr int NT = CH / 16;                    // cout tiles
+    static constexpr int PW = TW + 4, PH = TH + 4;        // input patch
+    static constexpr int P_PIX = PW * PH, P_ROWS = (P_PIX + RPP - 1) / RPP * RPP;
+    static constexpr int IW = TW + 2, IH = TH + 2;        // intermediate (halo 1)
+    static constexpr int M1 = IW * IH, M1T = (M1 + 15) / 16, T_ROWS = M1T * 16;
+    static constexpr int M2 = TW * TH, M2T = M2 / 16;
+    static constexpr int TM1 = (M1T + BN_WAVES - 1) / BN_WAVES, TM2 = (M2T + BN_WAVES - 1) / BN_WAVES;
+    static constexpr int W_PIECES = CH / RPP;             // DMA pieces per (tap, plane) of weights
+    static constexpr int W_STEP = CH * CB;                // bytes of one weight stage
+    static constexpr int PATCH_BYTES = NCH * P_ROWS * CB, T_BYTES = NCH * T_ROWS * CB;
+    static constexpr int LDS_BYTES = PATCH_BYTES + T_BYTES + 2 * W_STEP;
+    static_assert(M2 % 16 == 0, "tile must hold whole 16-pixel MFMA tiles");
+};
+
+// byte offset of 16-byte chunk c16 of row R inside a piece-structured, swizzled plane
+template <int CB>
+__device__ __forceinline__ int plane_off(int R, int c16) {
+    if (CB == 128) return (R >> 3) * 1024 + (R & 7) * 128 + ((c16 ^ ((R >> 1) & 7)) << 4);
+    return (R >> 4) * 1024 + (R & 15) * 64 + ((c16 ^ (((R >> 3) & 1) * 3)) << 4);
+}
+
+// One conv of the pair as an implicit GEMM from an LDS image.  src: planes [NCH][rows][CB];
+// SW = row width of that image; my_pb[i] = LDS pixel index (tap 0,0) of this lane's row in the
+// wave's i-th m-tile.  Weights stream through wring (2 stages), one (tap, plane) per step.
+template <typename G, int TM, int SW, int SRC_ROWS>
+__device__ __forceinline__ void gemm_from_lds(const unsigned char *src, unsigned char *wring, const f16 *w, int kp, const int (&my_pb)[TM],
+                                              floatx4 (&acc)[TM][G::NT], int lane, int wave) {
+    constexpr int CB = G::CB, NCH = G::NCH, RPP = G::RPP, SUB = G::SUB, NT = G::NT;
+    constexpr int STEPS = 9 * NCH;
+    const int r = lane & 15, q = lane >> 4;
+    const int ld_row = CB == 128 ? lane >> 3 : lane >> 2, ld_slot = CB == 128 ? lane & 7 : lane & 3;
+    auto issue = [&](int step) {
+        const int tap = step / NCH, plane = step - tap * NCH;
+        unsigned char *dst = wring + (step & 1) * G::W_STEP;
+        for (int pc = wave; pc < G::W_PIECES; pc += BN_WAVES) {
+            int row = pc * RPP + ld_row;
+            int c16 = CB == 128 ? (ld_slot ^ ((row >> 1) & 7)) : (ld_slot ^ (((row >> 3) & 1) * 3));
+            dma16(w + ((long)row * kp + tap * (NCH * G::CW) + plane * G::CW + c16 * 8), dst + pc * 1024);
+        }
+    };
+    issue(0);
+    for (int step = 0; step < STEPS; ++step) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                       // weights of `step` landed; everyone left step-1
+        asm volatile("" ::: "memory");
+        if (step + 1 < STEPS) issue(step + 1);
+        const int tap = step / NCH, plane = step - tap * NCH;
+        const int kh = tap / 3, kw = tap - kh * 3;
+        const int toff = kh * SW + kw;
+        const unsigned char *splane = src + plane * (SRC_ROWS * CB);
+        const unsigned char *wst = wring + (step & 1) * G::W_STEP;
+#pragma unroll
+        for (int kk = 0; kk < SUB; ++kk) {
+            half8 fa[TM], fb[NT];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[i] = *(const half8 *)(splane + plane_off<CB>(my_pb[i] + toff, kk * 4 + q));
+#pragma unroll
+            for (int u = 0; u < NT; ++u) fb[u] = *(const half8 *)(wst + plane_off<CB>(u * 16 + r, kk * 4 + q));
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int u = 0; u < NT; ++u) acc[i][u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[u], fa[i], acc[i][u], 0, 0, 0);
+        }
+    }
+}
+
+template <int CH, int TH, int TW>
+__global__ __launch_bounds__(BN_THREADS) void bottleneck_fused(BneckArgs p) {
+    using G = BneckGeom<CH, TH, TW>;
+    constexpr int CB = G::CB, NCH = G::NCH, RPP = G::RPP, NT = G::NT;
+    extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
+    unsigned char *patch = lds;
+    unsigned char *tbuf = lds + G::PATCH_BYTES;
+    unsigned char *wring = tbuf + G::T_BYTES;
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r = lane & 15, q = lane >> 4;
+    const int tx = blockIdx.x % p.tiles_x, ty = (blockIdx.x / p.tiles_x) % p.tiles_y, b = blockIdx.x / (p.tiles_x * p.tiles_y);
+    const int x0 = tx * TW, y0 = ty * TH;
+
+    // ---- 0. input patch -> LDS (2-pixel halo; outside the bordered tensor: zero page) ----
+    {
+        const int ld_row = CB == 128 ? lane >> 3 : lane >> 2, ld_slot = CB == 128 ? lane & 7 : lane & 3;
+        constexpr int PIECES = NCH * (G::P_ROWS / RPP);
+        for (int pc = wave; pc < PIECES; pc += BN_WAVES) {
+            const int plane = pc / (G::P_ROWS / RPP), pp = pc - plane * (G::P_ROWS / RPP);
+            const int pix = pp * RPP + ld_row;
+            const int py = pix / G::PW, px = pix - py * G::PW;
+            const int gy = y0 - 2 + py, gx = x0 - 2 + px;
+            const int c16 = CB == 128 ? (ld_slot ^ ((pix >> 1) & 7)) : (ld_slot ^ (((pix >> 3) & 1) * 3));
+            const bool ok = pix < G::P_PIX && gy >= -1 && gy <= p.H && gx >= -1 && gx <= p.W;
+            const f16 *srcp = ok ? p.in + (((long)(b * p.in_Hp + gy + 1) * p.in_Wp + gx + 1) * p.in_cs + plane * G::CW + c16 * 8) : p.zeros;
+            dma16(srcp, patch + plane * (G::P_ROWS * CB) + pp * 1024);
+        }
+    }
+
+    // ---- 1. conv1 over the halo-1 region ----
+    {
+        int pb[G::TM1];
+        int mrow[G::TM1];
+#pragma unroll
+        for (int i = 0; i < G::TM1; ++i) {
+            int t = wave + BN_WAVES * i;
+            int m = t * 16 + r;
+            mrow[i] = t < G::M1T ? m : -1;
+            m = m < G::M1 ? m : G::M1 - 1;                      // padding rows of the last tile re-read a valid pixel
+            int iy = m / G::IW, ix = m - iy * G::IW;
+            pb[i] = iy * G::PW + ix;
+        }
+        floatx4 acc[G::TM1][NT];
+#pragma unroll
+        for (int i = 0; i < G::TM1; ++i)
+#pragma unroll
+            for (int u = 0; u < NT; ++u) acc[i][u] = *(const floatx4 *)(p.b1 + u * 16 + q * 4);   // bias as the initial accumulator
+        gemm_from_lds<G, G::TM1, G::PW, G::P_ROWS>(patch, wring, p.w1, p.kp, pb, acc, lane, wave);
+        // epilogue 1: SiLU -> fp16 -> tbuf; positions outside the image are conv2's zero padding
+#pragma unroll
+        for (int i = 0; i < G::TM1; ++i) {
+            const int m = mrow[i];
+            if (m < 0 || m >= G::M1) continue;
+            const int iy = m / G::IW, ix = m - iy * G::IW;
+            const int gy = y0 - 1 + iy, gx = x0 - 1 + ix;
+            const bool inside = gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+#pragma unroll
+            for (int u = 0; u < NT; ++u) {
+                const int n = u * 16 + q * 4;
+                half4 h = {(f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f};
+                if (inside) h = half4{(f16)silu_b(acc[i][u][0]), (f16)silu_b(acc[i][u][1]), (f16)silu_b(acc[i][u][2]), (f16)silu_b(acc[i][u][3])};
+                const int plane = n / G::CW, cn = n - plane * G::CW;
+                *(half4 *)(tbuf + plane * (G::T_ROWS * CB) + plane_off<CB>(m, cn >> 3) + (cn & 7) * 2) = h;
+            }
+        }
+    }
+    __syncthreads();                                            // tbuf complete; weight ring free again
+
+    // ---- 2. conv2 over the tile ----
+    {
+        int pb[G::TM2];
+        int mrow[G::TM2];
+#pragma unroll
+        for (int i = 0; i < G::TM2; ++i) {
+            int t = wave + BN_WAVES * i;
+            int m = t * 16 + r;
+            mrow[i] = t < G::M2T ? m : -1;
+            m = m < G::M2 ? m : G::M2 - 1;
+            int oy = m / TW, ox = m - oy * TW;
+            pb[i] = oy * G::IW + ox;
+        }
+        floatx4 acc[G::TM2][NT];
+#pragma unroll
+        for (int i = 0; i < G::TM2; ++i)
+#pragma unroll
+            for (int u = 0; u < NT; ++u) acc[i][u] = *(const floatx4 *)(p.b2 + u * 16 + q * 4);
+        gemm_from_lds<G, G::TM2, G::IW, G::T_ROWS>(tbuf, wring, p.w2, p.kp, pb, acc, lane, wave);
+#pragma unroll
+        for (int i = 0; i < G::TM2; ++i) {
+            const int m = mrow[i];
+            if (m < 0) continue;
+            const int oy = m / TW, ox = m - oy * TW;
+            const int gy = y0 + oy, gx = x0 + ox;
+            if (gy >= p.H || gx >= p.W) continue;
+            const long opix = ((long)(b * p.out_Hp + gy + p.out_pad) * p.out_Wp + gx + p.out_pad) * p.out_cs;
+            const long rpix = p.res ? ((long)(b * p.res_Hp + gy + p.res_pad) * p.res_Wp + gx + p.res_pad) * p.res_cs : 0;
+#pragma unroll
+            for (int u = 0; u < NT; ++u) {
+                const int n = u * 16 + q * 4;
+                floatx4 v = acc[i][u];
+                v[0] = silu_b(v[0]); v[1] = silu_b(v[1]); v[2] = silu_b(v[2]); v[3] = silu_b(v[3]);
+                if (p.res) {
+                    half4 rv = *(const half4 *)(p.res + rpix + n);
+                    v[0] += (float)rv[0]; v[1] += (float)rv[1]; v[2] += (float)rv[2]; v[3] += (float)rv[3];
+                }
+                *(half4 *)(p.out + opix + n) = half4{(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
+            }
+        }
+    }
+}
+
+template <int CH, int TH, int TW>
+int launch_one(const BneckArgs &a0, int H, int W, int B, hipStream_t s) {
+    using G = BneckGeom<CH, TH, TW>;
+    BneckArgs a = a0;
+    a.tiles_x = cdiv(W, TW); a.tiles_y = cdiv(H, TH);
+    static size_t attr = 0;
+    if ((size_t)G::LDS_BYTES > attr) {
+        RT_HIP(hipFuncSetAttribute((const void *)bottleneck_fused<CH, TH, TW>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES));
+        attr = G::LDS_BYTES;
+    }
+    hipLaunchKernelGGL((bottleneck_fused<CH, TH, TW>), dim3(a.tiles_x * a.tiles_y * B), dim3(BN_THREADS), G::LDS_BYTES, s, a);
+    RT_HIP(hipGetLastError());
+    return RTMODT_OK;
+}
+
+}  // namespace
+
+bool bottleneck_supported(int c) { return c == 32 || c == 64 || c == 128; }
+
+int launch_bottleneck(const BottleneckLaunch &l, hipStream_t s) {
+    const TensorView &in = l.in, &out = l.out, &res = l.res;
+    RT_CHECK(bottleneck_supported(l.c), RTMODT_E_UNSUPPORTED, "launch_bottleneck: %d channels", l.c);
+    RT_CHECK(in.pad == 1 && in.c == l.c && out.c == l.c && in.H == out.H && in.W == out.W && l.kp == 9 * l.c, RTMODT_E_INVALID,
+             "launch_bottleneck: shapes");
+    RT_CHECK(in.coff % 8 == 0 && in.C % 8 == 0 && out.coff % 4 == 0 && out.C % 4 == 0 && l.zeros, RTMODT_E_INVALID, "launch_bottleneck: alignment");
+    BneckArgs a{};
+    a.in = in.base + in.coff; a.w1 = l.w1; a.w2 = l.w2; a.b1 = l.b1; a.b2 = l.b2; a.zeros = l.zeros;
+    a.out = out.base + out.coff;
+    a.res = res.base ? res.base + res.coff : nullptr;
+    a.B = l.B; a.H = in.H; a.W = in.W;
+    a.in_Hp = in.H + 2; a.in_Wp = in.W + 2; a.in_cs = in.C;
+    a.out_Hp = out.H + 2 * out.pad; a.out_Wp = out.W + 2 * out.pad; a.out_cs = out.C; a.out_pad = out.pad;
+    a.res_Hp = res.H + 2 * res.pad; a.res_Wp = res.W + 2 * res.pad; a.res_cs = res.C; a.res_pad = res.pad;
+    a.kp = l.kp;
+    if (a.res) RT_CHECK(res.H == out.H && res.W == out.W && res.c == l.c && res.coff % 4 == 0, RTMODT_E_INVALID, "launch_bottleneck: residual shape");
+    switch (l.c) {
+        case 32: return launch_one<32, 16, 16>(a, in.H, in.W, l.B, s);
+        case 64: return launch_one<64, 16, 16>(a, in.H, in.W, l.B, s);
+        case 128: return launch_one<128, 8, 16>(a, in.H, in.W, l.B, s);
+    }
+    return fail(RTMODT_E_UNSUPPORTED, "launch_bottleneck: %d channels", l.c);
+}
+
+}  // namespace rtmodt

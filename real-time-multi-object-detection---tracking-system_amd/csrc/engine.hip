@@ -137,7 +137,7 @@ static void build_resize_tables(int dst, int src, std::vector<int32_t> &ofs, std
 // ------------------------------------------------------------------ graph description
 struct Tensor { f16 *ptr = nullptr; int H, W, C, pad; size_t per_image; };
 
-enum OpKind { OP_STEM, OP_CONV, OP_POOL, OP_UP, OP_GROUP };
+enum OpKind { OP_STEM, OP_CONV, OP_POOL, OP_UP, OP_GROUP, OP_BNECK };
 
 struct Op {
     OpKind kind;
@@ -145,6 +145,10 @@ struct Op {
     ConvLaunch conv;                 // OP_CONV
     std::vector<ConvLaunch> group;   // OP_GROUP: independent convs issued as one launch
     int group_tile = TILE_64x64;
+    // OP_BNECK: a Bottleneck either as ONE fused launch (`bneck`) or as its two convs (`group[0]`, `group[1]`
+    // with their own tiles); the autotuner keeps whichever is faster on this device and batch
+    BottleneckLaunch bneck;
+    bool fused = true;
     TensorView v[4];                 // STEM: in,out; POOL: y,p1,p2,p3; UP: in,out
     const f16 *stem_w = nullptr; const float *stem_b = nullptr;
     int64_t flops = 0;               // per frame
@@ -180,6 +184,7 @@ struct rtmodt_detector {
     std::map<std::string, TensorView> layer_out;     // fused conv name -> output view
     std::vector<void *> dev_allocs;                   // weights etc.
     int img_t = -1;
+    f16 *d_zeros = nullptr;                           // 256 zero bytes (DMA source for out-of-tensor halo pixels)
     int head_t[3] = {-1, -1, -1};
     int64_t flops_per_frame = 0;
     // frames
@@ -261,7 +266,10 @@ static Op sub_batch(const Op &op, int b0, int nb) {
     };
     o.B = nb;
     if (o.kind == OP_CONV) { shift(o.conv.in); shift(o.conv.out); shift(o.conv.res); shift(o.conv.out2); o.conv.B = nb; }
-    else if (o.kind == OP_GROUP) for (auto &c : o.group) { shift(c.in); shift(c.out); shift(c.res); c.B = nb; }
+    else if (o.kind == OP_GROUP || o.kind == OP_BNECK) {
+        for (auto &c : o.group) { shift(c.in); shift(c.out); shift(c.res); c.B = nb; }
+        if (o.kind == OP_BNECK) { shift(o.bneck.in); shift(o.bneck.out); shift(o.bneck.res); o.bneck.B = nb; }
+    }
     else for (auto &v : o.v) shift(v);
     return o;
 }
@@ -367,8 +375,25 @@ static int build_graph(rtmodt_detector *d, WeightFile &wf) {
         for (int j = 0; j < n; ++j) {
             int tmp = T(in.H, in.W, c, 1);
             std::string m = i + ".m." + std::to_string(j);
-            conv(m + ".cv1", V(cat, (1 + j) * c, c), V(tmp));
             TensorView r = V(cat, (1 + j) * c, c);
+            static const bool no_fuse = getenv("RTMODT_NO_BNECK_FUSE") != nullptr;
+            if (bottleneck_supported(c) && !no_fuse && rc == RTMODT_OK) {
+                std::vector<Op> pair;
+                rc = make_conv(d, wf, {m + ".cv1"}, m + ".cv1", V(cat, (1 + j) * c, c), V(tmp), nullptr, 0, &pair);
+                if (rc == RTMODT_OK) rc = make_conv(d, wf, {m + ".cv2"}, m + ".cv2", V(tmp), V(cat, (2 + j) * c, c), shortcut ? &r : nullptr, 0, &pair);
+                if (rc != RTMODT_OK) continue;
+                Op op; op.kind = OP_BNECK; op.name = m + " (cv1+cv2)";
+                op.group = {pair[0].conv, pair[1].conv};
+                op.flops = pair[0].flops + pair[1].flops;
+                BottleneckLaunch &b = op.bneck;
+                b.in = V(cat, (1 + j) * c, c); b.out = V(cat, (2 + j) * c, c); if (shortcut) b.res = r;
+                b.w1 = pair[0].conv.wt; b.b1 = pair[0].conv.bias; b.w2 = pair[1].conv.wt; b.b2 = pair[1].conv.bias;
+                b.zeros = d->d_zeros; b.B = d->B; b.c = c; b.kp = pair[0].conv.kp;
+                if (const char *e = getenv("RTMODT_BNECK")) op.fused = atoi(e) != 0;
+                d->ops.push_back(op);
+                continue;
+            }
+            conv(m + ".cv1", V(cat, (1 + j) * c, c), V(tmp));
             conv(m + ".cv2", V(tmp), V(cat, (2 + j) * c, c), shortcut ? &r : nullptr);
         }
         conv(i + ".cv2", V(cat, 0, (2 + n) * c), out);
@@ -510,8 +535,9 @@ static int build_graph(rtmodt_detector *d, WeightFile &wf) {
             rebase(op.conv.in); rebase(op.conv.out);
             if (op.conv.res.c) rebase(op.conv.res);
             if (op.conv.out2.c) rebase(op.conv.out2);
-        } else if (op.kind == OP_GROUP) {
+        } else if (op.kind == OP_GROUP || op.kind == OP_BNECK) {
             for (auto &c : op.group) { rebase(c.in); rebase(c.out); if (c.res.c) rebase(c.res); }
+            if (op.kind == OP_BNECK) { rebase(op.bneck.in); rebase(op.bneck.out); if (op.bneck.res.c) rebase(op.bneck.res); }
         } else {
             for (auto &v : op.v) if (v.c) rebase(v);
         }
@@ -536,6 +562,10 @@ static int run_op_on(const Op &op, hipStream_t s) {
         case OP_STEM: return launch_stem(op.v[0], op.v[1], op.stem_w, op.stem_b, op.B, op.v[1].c, s);
         case OP_CONV: return launch_conv(op.conv, s);
         case OP_GROUP: return launch_conv_group(op.group.data(), (int)op.group.size(), op.group_tile, s);
+        case OP_BNECK:
+            if (op.fused) return launch_bottleneck(op.bneck, s);
+            RT_TRY(launch_conv(op.group[0], s));
+            return launch_conv(op.group[1], s);
         case OP_POOL: return launch_sppf_pool(op.v[0], op.v[1], op.v[2], op.v[3], op.B, s);
         case OP_UP: return launch_upsample2(op.v[0], op.v[1], op.B, s);
     }
@@ -567,43 +597,64 @@ static int forward_eager(rtmodt_detector *d) {
 // Times every tile configuration of every MFMA conv on the device it will run on (HIP events,
 // best of a few launches) and keeps the fastest: the GEMM shapes of this net are small and
 // skinny, so the best tile depends on how M x N fills 256 CUs, not on a rule.
+// best-of-3 time (ms per launch) of `launch` issued 4 times back to back on the detector's stream
+template <typename F>
+static int time_launch(rtmodt_detector *d, hipEvent_t e0, hipEvent_t e1, F &&launch, float &ms_out) {
+    for (int w = 0; w < 2; ++w) RT_TRY(launch());
+    float ms_min = 1e30f;
+    for (int rep = 0; rep < 3; ++rep) {
+        RT_HIP(hipEventRecord(e0, d->stream));
+        for (int k = 0; k < 4; ++k) RT_TRY(launch());
+        RT_HIP(hipEventRecord(e1, d->stream));
+        RT_HIP(hipEventSynchronize(e1));
+        float ms = 0;
+        RT_HIP(hipEventElapsedTime(&ms, e0, e1));
+        ms_min = std::min(ms_min, ms);
+    }
+    ms_out = ms_min * 0.25f;
+    return RTMODT_OK;
+}
+
+// fastest tile for one conv (or one group of convs sharing a tile); returns its time
+static int tune_conv(rtmodt_detector *d, hipEvent_t e0, hipEvent_t e1, const std::string &name, ConvLaunch *c, int n, int &tile_io,
+                     float &best_ms) {
+    bool cin64 = true, rows_ok = true;
+    for (int i = 0; i < n; ++i) {
+        cin64 = cin64 && c[i].cin % 64 == 0 && c[i].kp % 64 == 0;
+        rows_ok = rows_ok && c[i].ks == 3 && c[i].stride == 1 && c[i].in.pad == 1 && c[i].cin % 32 == 0;
+    }
+    best_ms = 1e30f;
+    int best_tile = tile_io;
+    for (int t = 0; t < TILE_COUNT; ++t) {
+        if (tile_needs_cin64(t) && !cin64) continue;
+        if (tile_is_rows(t) && !rows_ok) continue;
+        float ms;
+        RT_TRY(time_launch(d, e0, e1, [&]() { return launch_conv_group(c, n, t, d->stream); }, ms));
+        if (getenv("RTMODT_TUNE_LOG")) fprintf(stderr, "[tune] %-28s %-16s %8.2f us\n", name.c_str(), tile_name(t), ms * 1e3f);
+        if (ms < best_ms) { best_ms = ms; best_tile = t; }
+    }
+    tile_io = best_tile;
+    return RTMODT_OK;
+}
+
 static int autotune_ops(rtmodt_detector *d, std::vector<Op> &ops) {
     hipEvent_t e0, e1;
     RT_HIP(hipEventCreate(&e0)); RT_HIP(hipEventCreate(&e1));
     for (auto &op : ops) {
-        if (op.kind != OP_CONV && op.kind != OP_GROUP) continue;
-        const bool grp = op.kind == OP_GROUP;
-        bool cin64 = true, rows_ok = true;
-        auto check = [&](const ConvLaunch &c) {
-            cin64 = cin64 && c.cin % 64 == 0 && c.kp % 64 == 0;
-            rows_ok = rows_ok && c.ks == 3 && c.stride == 1 && c.in.pad == 1 && c.cin % 32 == 0;
-        };
-        if (grp) { for (auto &c : op.group) check(c); } else check(op.conv);
-        auto launch = [&](int t) -> int {
-            if (grp) return launch_conv_group(op.group.data(), (int)op.group.size(), t, d->stream);
-            op.conv.tile = t;
-            return launch_conv(op.conv, d->stream);
-        };
-        float best = 1e30f;
-        int best_tile = grp ? op.group_tile : op.conv.tile;
-        for (int t = 0; t < TILE_COUNT; ++t) {
-            if (tile_needs_cin64(t) && !cin64) continue;
-            if (tile_is_rows(t) && !rows_ok) continue;
-            for (int w = 0; w < 2; ++w) RT_TRY(launch(t));
-            float ms_min = 1e30f;
-            for (int rep = 0; rep < 3; ++rep) {
-                RT_HIP(hipEventRecord(e0, d->stream));
-                for (int k = 0; k < 4; ++k) RT_TRY(launch(t));
-                RT_HIP(hipEventRecord(e1, d->stream));
-                RT_HIP(hipEventSynchronize(e1));
-                float ms = 0;
-                RT_HIP(hipEventElapsedTime(&ms, e0, e1));
-                ms_min = std::min(ms_min, ms);
-            }
-            if (getenv("RTMODT_TUNE_LOG")) fprintf(stderr, "[tune] %-28s %-16s %8.2f us\n", op.name.c_str(), tile_name(t), ms_min * 250.0f);
-            if (ms_min < best) { best = ms_min; best_tile = t; }
+        float ms;
+        if (op.kind == OP_CONV) {
+            RT_TRY(tune_conv(d, e0, e1, op.name, &op.conv, 1, op.conv.tile, ms));
+        } else if (op.kind == OP_GROUP) {
+            RT_TRY(tune_conv(d, e0, e1, op.name, op.group.data(), (int)op.group.size(), op.group_tile, ms));
+        } else if (op.kind == OP_BNECK) {
+            float ms1, ms2, msf;
+            RT_TRY(tune_conv(d, e0, e1, op.group[0].in.c ? op.name + ".cv1" : op.name, &op.group[0], 1, op.group[0].tile, ms1));
+            RT_TRY(tune_conv(d, e0, e1, op.name + ".cv2", &op.group[1], 1, op.group[1].tile, ms2));
+            RT_TRY(time_launch(d, e0, e1, [&]() { return launch_bottleneck(op.bneck, d->stream); }, msf));
+            if (getenv("RTMODT_TUNE_LOG")) fprintf(stderr, "[tune] %-28s fused %8.2f us vs two launches %8.2f us\n", op.name.c_str(), msf * 1e3f, (ms1 + ms2) * 1e3f);
+            op.fused = msf < ms1 + ms2;
+            if (const char *e = getenv("RTMODT_BNECK")) op.fused = atoi(e) != 0;      // A/B and test hook
         }
-        if (grp) op.group_tile = best_tile; else op.conv.tile = best_tile;
     }
     hipEventDestroy(e0); hipEventDestroy(e1);
     return RTMODT_OK;
@@ -614,9 +665,9 @@ static int autotune_tiles(rtmodt_detector *d) {
     if (d->n_chains > 1) {
         RT_TRY(autotune_ops(d, d->chain_ops[0]));          // the sub-batch GEMMs have their own best tiles
         for (int c = 1; c < d->n_chains; ++c)
-            for (size_t i = 0; i < d->ops.size(); ++i) { d->chain_ops[c][i].conv.tile = d->chain_ops[0][i].conv.tile; d->chain_ops[c][i].group_tile = d->chain_ops[0][i].group_tile; }
+            for (size_t i = 0; i < d->ops.size(); ++i) { d->chain_ops[c][i].conv.tile = d->chain_ops[0][i].conv.tile; d->chain_ops[c][i].group_tile = d->chain_ops[0][i].group_tile; d->chain_ops[c][i].fused = d->chain_ops[0][i].fused; for (size_t g = 0; g < d->chain_ops[c][i].group.size(); ++g) d->chain_ops[c][i].group[g].tile = d->chain_ops[0][i].group[g].tile; }
     } else {
-        for (size_t i = 0; i < d->ops.size(); ++i) { d->chain_ops[0][i].conv.tile = d->ops[i].conv.tile; d->chain_ops[0][i].group_tile = d->ops[i].group_tile; }
+        for (size_t i = 0; i < d->ops.size(); ++i) { d->chain_ops[0][i].conv.tile = d->ops[i].conv.tile; d->chain_ops[0][i].group_tile = d->ops[i].group_tile; d->chain_ops[0][i].fused = d->ops[i].fused; for (size_t g = 0; g < d->ops[i].group.size(); ++g) d->chain_ops[0][i].group[g].tile = d->ops[i].group[g].tile; }
     }
     // the tuning launches left stale activations; run one clean pass
     RT_TRY(forward_eager(d));
@@ -789,7 +840,7 @@ void rtmodt_detector_destroy(rtmodt_detector *d) {
     for (auto st : d->aux_streams) hipStreamDestroy(st);
     for (auto e : d->aux_events) hipEventDestroy(e);
     for (void *p : d->dev_allocs) hipFree(p);
-    hipFree(d->arena); hipFree(d->stage); hipFree(d->d_tab);
+    hipFree(d->arena); hipFree(d->stage); hipFree(d->d_tab); hipFree(d->d_zeros);
     hipFree(d->d_pred);
     hipFree(d->d_keys); hipFree(d->d_sbox); hipFree(d->d_sidx);
     for (auto &sl : d->slots) {
@@ -826,6 +877,8 @@ static int detector_create_impl(const rtmodt_det_cfg *cfg, rtmodt_detector *d) {
     RT_HIP(hipSetDevice(d->device));
     RT_HIP(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking));
     RT_HIP(hipStreamCreateWithFlags(&d->post_stream, hipStreamNonBlocking));
+    RT_HIP(hipMalloc((void **)&d->d_zeros, 256));
+    RT_HIP(hipMemset(d->d_zeros, 0, 256));
     RT_TRY(build_graph(d, wf));
 
     int msw = cfg->max_src_w > 0 ? cfg->max_src_w : d->in_w, msh = cfg->max_src_h > 0 ? cfg->max_src_h : d->in_h;
@@ -989,7 +1042,7 @@ int rtmodt_detector_info(rtmodt_detector *d, int32_t *scale_id, int32_t *nc, int
     if (n_anchors) *n_anchors = d->n_anchors;
     if (n_convs) {
         int c = 0;
-        for (auto &op : d->ops) c += op.kind == OP_GROUP ? (int)op.group.size() : (op.kind == OP_CONV || op.kind == OP_STEM);
+        for (auto &op : d->ops) c += (op.kind == OP_GROUP || op.kind == OP_BNECK) ? (int)op.group.size() : (op.kind == OP_CONV || op.kind == OP_STEM);
         *n_convs = c;
     }
     if (conv_flops_per_frame) *conv_flops_per_frame = d->flops_per_frame;
@@ -1045,6 +1098,10 @@ int rtmodt_detector_debug_layer(rtmodt_detector *d, const char *name, int img, u
     auto it = d->layer_out.find(name);
     RT_CHECK(it != d->layer_out.end(), RTMODT_E_INVALID, "no fused conv named %s", name);
     const TensorView &v = it->second;
+    for (auto &op : d->ops)                               // the first conv of a fused Bottleneck never leaves the CU
+        if (op.kind == OP_BNECK && op.fused && op.name == std::string(name).substr(0, std::string(name).rfind('.')) + " (cv1+cv2)" &&
+            std::string(name).size() > 4 && std::string(name).compare(std::string(name).size() - 4, 4, ".cv1") == 0)
+            return fail(RTMODT_E_UNSUPPORTED, "%s is the LDS-resident intermediate of a fused Bottleneck launch", name);
     if (hwc) { hwc[0] = v.H; hwc[1] = v.W; hwc[2] = v.c; }
     if (!out) return RTMODT_OK;
     RT_HIP(hipSetDevice(d->device));
@@ -1082,6 +1139,9 @@ int rtmodt_detector_profile(rtmodt_detector *d, int iters, int max_entries, cons
         if (op.kind == OP_CONV) {
             snprintf(buf, sizeof(buf), "%s [M=%d N=%d K=%d k%d s%d tile %s]", op.name.c_str(), d->B * op.conv.out.H * op.conv.out.W,
                      op.conv.cout, op.conv.ks * op.conv.ks * op.conv.cin, op.conv.ks, op.conv.stride, tile_name(op.conv.tile));
+        } else if (op.kind == OP_BNECK) {
+            if (op.fused) snprintf(buf, sizeof(buf), "%s [fused bottleneck, c=%d, %dx%d]", op.name.c_str(), op.bneck.c, op.bneck.in.H, op.bneck.in.W);
+            else snprintf(buf, sizeof(buf), "%s [two launches: %s, %s]", op.name.c_str(), tile_name(op.group[0].tile), tile_name(op.group[1].tile));
         } else if (op.kind == OP_GROUP) {
             snprintf(buf, sizeof(buf), "%s [group of %zu, tile %s]", op.name.c_str(), op.group.size(), tile_name(op.group_tile));
         } else {

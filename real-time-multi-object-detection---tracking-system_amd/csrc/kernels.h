@@ -52,6 +52,18 @@ int launch_conv(const ConvLaunch &c, hipStream_t s);
 // n (<= 6) independent convolutions sharing one tile configuration, in ONE launch
 int launch_conv_group(const ConvLaunch *c, int n, int tile, hipStream_t s);
 
+// A whole Bottleneck (conv3x3+SiLU -> conv3x3+SiLU [+ residual]) in one launch, intermediate kept in LDS
+// (bottleneck.hip).  c in {32, 64, 128}; w1/w2 in the conv layout above with kp == 9*c.
+struct BottleneckLaunch {
+    TensorView in, out, res;      // res.base == nullptr -> no shortcut
+    const f16 *w1 = nullptr, *w2 = nullptr;
+    const float *b1 = nullptr, *b2 = nullptr;
+    const f16 *zeros = nullptr;   // >= 16 bytes of zeros in device memory
+    int B = 1, c = 0, kp = 0;
+};
+bool bottleneck_supported(int c);
+int launch_bottleneck(const BottleneckLaunch &l, hipStream_t s);
+
 // stem: 3x3 stride-2 conv on the 4-channel (RGB0) padded fp16 image, cout in {16,32,48,64,80};
 // wm = [cout][64] fp16 in the k' = kh*16 + kw*4 + c order (zero where kw == 3, c == 3 or k' >= 48)
 int launch_stem(const TensorView &img4, const TensorView &out, const f16 *wm, const float *bias, int B,

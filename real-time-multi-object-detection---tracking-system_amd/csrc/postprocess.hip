@@ -465,7 +465,11 @@ __global__ __launch_bounds__(PP_THREADS) void nms_kernel(NmsArgs a, int dbg_stop
 int launch_nms(const NmsArgs &a, hipStream_t s) {
     size_t smem = (size_t)SORT_LDS_MAX * 8 + (size_t)SBOX_LDS_MAX * 16 + (size_t)((MAX_NMS + 63) / 64) * 8 + 64 * 8 + (size_t)a.max_det * 4 + 16;
     RT_CHECK(smem <= 150 * 1024, RTMODT_E_INVALID, "nms: max_det %d too large", a.max_det);
-    RT_HIP(hipFuncSetAttribute((const void *)nms_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    static size_t attr_bytes = 0;                          // raise the dynamic-LDS limit once per size, not per launch
+    if (smem > attr_bytes) {
+        RT_HIP(hipFuncSetAttribute((const void *)nms_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        attr_bytes = smem;
+    }
     static const int dbg_stop = getenv("RTMODT_NMS_STOP") ? atoi(getenv("RTMODT_NMS_STOP")) : 0;   // timing-only builds of the phases
     hipLaunchKernelGGL(nms_kernel, dim3(a.B), dim3(PP_THREADS), smem, s, a, dbg_stop);
     RT_HIP(hipGetLastError());

@@ -286,7 +286,11 @@ int launch_tracker_update(const TrackerArgs &a, hipStream_t s) {
     size_t smem = tracker_smem_bytes(a.max_tracks, a.max_dets);
     RT_CHECK(smem <= 150 * 1024, RTMODT_E_INVALID, "tracker: max_tracks %d / max_dets %d need %zu B of LDS (> 160 KiB)", a.max_tracks,
              a.max_dets, smem);
-    RT_HIP(hipFuncSetAttribute((const void *)tracker_update, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    static size_t attr_bytes = 0;
+    if (smem > attr_bytes) {
+        RT_HIP(hipFuncSetAttribute((const void *)tracker_update, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        attr_bytes = smem;
+    }
     hipLaunchKernelGGL(tracker_update, dim3(a.n_streams), dim3(TRK_THREADS), smem, s, a);
     RT_HIP(hipGetLastError());
     return RTMODT_OK;

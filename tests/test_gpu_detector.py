@@ -90,17 +90,30 @@ def test_nms_empty_and_single(pkg):
 
 
 # ------------------------------------------------------------------ forward pass, layer by layer
+def fetch_layers(pkg, det, names, img=0):
+    """Every fused conv's output as the engine stored it; the first conv of a Bottleneck that runs
+    as ONE fused launch has no global image (it lives in LDS) and is skipped -- the oracle then
+    recomputes it from the forced input, so the pair is still checked end to end."""
+    out = {}
+    for n in names:
+        try:
+            out[n] = det.debug_layer(n, img).astype(np.float32)
+        except pkg._ffi.RtmodtError as e:
+            assert e.code == pkg._ffi.E_UNSUPPORTED and n.endswith(".cv1"), (n, str(e))
+    return out
+
+
 def layer_check(pkg, det, w, frame, scale, size):
     d = det.detect(frame)
     inp, heads, pred = det.debug_fetch(0)
     ref_in = Y.preprocess(frame, size, size).astype(np.float16)
     assert np.array_equal(inp.view(np.uint16), ref_in.view(np.uint16))
     names = [c.name for c in pkg.weights.spec(scale)]
-    gpu = {n: det.debug_layer(n).astype(np.float32) for n in names}
+    gpu = fetch_layers(pkg, det, names)
     taps = {}
     Y.forward(inp.astype(np.float32), w, scale, taps=taps, force=gpu)
     worst = ("", 0.0)
-    for n in names:
+    for n in gpu:
         ref, got = taps[n], gpu[n]
         assert ref.shape == got.shape, n
         tol = 2e-3 * np.abs(ref).max() + 2e-3
@@ -159,13 +172,40 @@ def test_tap_reuse_conv_tiles(pkg, wdir, monkeypatch, tile):
     names = [c.name for c in pkg.weights.spec("s")]
     for img in (0, 1):
         inp, _, _ = det.debug_fetch(img, want_heads=False, want_pred=False)
-        gpu = {n: det.debug_layer(n, img).astype(np.float32) for n in names}
+        gpu = fetch_layers(pkg, det, names, img)
         taps = {}
         Y.forward(inp.astype(np.float32), w, "s", taps=taps, force=gpu)
-        for n in names:
+        for n in gpu:
             tol = 2e-3 * np.abs(taps[n]).max() + 2e-3
             err = float(np.abs(taps[n] - gpu[n]).max())
             assert err <= tol, f"tile {tile} img {img} layer {n}: max err {err:.4g} > tol {tol:.4g}"
+    det.close()
+
+
+@pytest.mark.parametrize("scale,size,batch", [("s", 320, 2), ("s", 640, 1), ("n", 320, 3), ("s", 288, 1)])
+def test_fused_bottleneck_kernel(pkg, wdir, monkeypatch, scale, size, batch):
+    """bottleneck_fused (conv3x3 -> conv3x3 [+x] with the intermediate in LDS) forced on for every
+    Bottleneck it supports (c in 32/64/128); sizes that are not multiples of the 16x16 / 8x16
+    tiles exercise the partial-tile and zero-padding paths (288 -> 72/36/18-pixel maps)."""
+    monkeypatch.setenv("RTMODT_BNECK", "1")
+    monkeypatch.setenv("RTMODT_TILE_3X3S1", "0")
+    det, w = make_detector(pkg, wdir, scale, size, autotune=False, batch=batch)
+    frames = list(pkg.synth.frames(batch, size, size, seed=41))
+    det.detect_batch(frames)
+    names = [c.name for c in pkg.weights.spec(scale)]
+    n_fused = 0
+    for img in range(batch):
+        inp, _, _ = det.debug_fetch(img, want_heads=False, want_pred=False)
+        gpu = fetch_layers(pkg, det, names, img)
+        n_fused = len(names) - len(gpu)
+        taps = {}
+        Y.forward(inp.astype(np.float32), w, scale, taps=taps, force=gpu)
+        for n in gpu:
+            # the pair's intermediate is fp16 in LDS on the engine, fp32 in the oracle: one extra rounding
+            tol = (4e-3 if ".m." in n and n.endswith(".cv2") else 2e-3) * np.abs(taps[n]).max() + 2e-3
+            err = float(np.abs(taps[n] - gpu[n]).max())
+            assert err <= tol, f"img {img} layer {n}: max err {err:.4g} > tol {tol:.4g}"
+    assert n_fused >= (4 if scale == "s" else 2), n_fused
     det.close()
 
 
