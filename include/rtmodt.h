@@ -34,7 +34,8 @@ extern "C" {
 #define RTMODT_MEM_DEVICE 1
 
 #define RTMODT_ASSIGN_GREEDY 0  /* tracker.py:182-194 (the branch taken when `lap` is absent) */
-#define RTMODT_ASSIGN_LAPJV 1   /* tracker.py:168-181 (lap.lapjv); not built yet -> RTMODT_E_UNSUPPORTED */
+#define RTMODT_ASSIGN_LAPJV 1   /* tracker.py:168-181 (the branch taken when `lap` is importable): exact optimal assignment
+                                 * under cost_limit = 1 - match_thresh; PARITY UNPINNED (no `lap` to run against) */
 
 typedef struct rtmodt_detector rtmodt_detector;
 typedef struct rtmodt_tracker rtmodt_tracker;
@@ -131,6 +132,10 @@ int rtmodt_preprocess(int device, const uint8_t *bgr, int h, int w, int stride_b
 int rtmodt_tracker_create(int device, float track_thresh, int track_buffer, float match_thresh,
                           int assign_mode, int max_tracks, int max_dets, int n_streams, rtmodt_tracker **out);
 void rtmodt_tracker_destroy(rtmodt_tracker *trk);
+/* RTMODT_ASSIGN_LAPJV only: the reference evaluates `cost_limit = 1 - thresh` in Python doubles
+ * (tracker.py:170); match_thresh above is a float, so a caller that wants the identical limit
+ * passes it here.  Default: 1.0 - (double)match_thresh. */
+int rtmodt_tracker_set_cost_limit(rtmodt_tracker *trk, double cost_limit);
 
 /* One frame for one stream (tracker.py:58-141).  *n_active_out = tracks with
  * time_since_update == 0 after the update -- always 0, as in the reference (SURVEY finding 4). */
@@ -154,6 +159,12 @@ int rtmodt_iou_matrix(int device, const float *a, int m, const float *b, int n, 
  * row_to_col[m] (-1 = unmatched), col_used[n]. */
 int rtmodt_assign_greedy(int device, const float *iou, int m, int n, float thresh, int32_t *row_to_col,
                          int32_t *col_used);
+/* _linear_assignment lap.lapjv branch (tracker.py:168-181) alone: the optimal assignment of
+ * cost = 1 - iou (float32) extended with cost_limit, i.e. the maximum-gain matching over pairs
+ * with cost < cost_limit.  RTMODT_E_CAPACITY when more than 256 rows / 256 columns / 2048 pairs
+ * are contested (share a row or column with another candidate pair). */
+int rtmodt_assign_lapjv(int device, const float *iou, int m, int n, double cost_limit, int32_t *row_to_col,
+                        int32_t *col_used);
 
 #ifdef __cplusplus
 }

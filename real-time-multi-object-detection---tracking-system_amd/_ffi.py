@@ -81,6 +81,7 @@ def lib() -> C.CDLL:
         "rtmodt_preprocess": (C.c_int, [C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
         "rtmodt_tracker_create": (C.c_int, [C.c_int, f32, C.c_int, f32, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]),
         "rtmodt_tracker_destroy": (None, [vp]),
+        "rtmodt_tracker_set_cost_limit": (C.c_int, [vp, C.c_double]),
         "rtmodt_tracker_update": (C.c_int, [vp, C.c_int, vp, vp, vp, C.c_int, C.POINTER(i32)]),
         "rtmodt_tracker_update_batch": (C.c_int, [vp, vp, vp, vp, vp, vp]),
         "rtmodt_tracker_update_from_detector": (C.c_int, [vp, vp]),
@@ -88,6 +89,7 @@ def lib() -> C.CDLL:
         "rtmodt_tracker_reset": (C.c_int, [vp, C.c_int]),
         "rtmodt_iou_matrix": (C.c_int, [C.c_int, vp, C.c_int, vp, C.c_int, vp]),
         "rtmodt_assign_greedy": (C.c_int, [C.c_int, vp, C.c_int, C.c_int, f32, vp, vp]),
+        "rtmodt_assign_lapjv": (C.c_int, [C.c_int, vp, C.c_int, C.c_int, C.c_double, vp, vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)          # AttributeError here == header/library drift
@@ -134,6 +136,17 @@ def assign_greedy(iou: np.ndarray, thresh: float, device: int = 0):
     r2c = np.empty(m, np.int32)
     used = np.empty(n, np.int32)
     check(lib().rtmodt_assign_greedy(device, ptr(iou), m, n, float(thresh), ptr(r2c), ptr(used)))
+    mr = [int(i) for i in range(m) if r2c[i] >= 0]
+    return mr, [int(r2c[i]) for i in mr], [int(i) for i in range(m) if r2c[i] < 0], [int(j) for j in range(n) if not used[j]]
+
+
+def assign_lapjv(iou: np.ndarray, thresh: float, device: int = 0):
+    """tracker.py:168-181: ``lap.lapjv(1 - iou, extend_cost=True, cost_limit=1 - thresh)`` -> the four lists."""
+    iou = np.ascontiguousarray(iou, np.float32)
+    m, n = iou.shape
+    r2c = np.empty(m, np.int32)
+    used = np.empty(n, np.int32)
+    check(lib().rtmodt_assign_lapjv(device, ptr(iou), m, n, float(1 - thresh), ptr(r2c), ptr(used)))
     mr = [int(i) for i in range(m) if r2c[i] >= 0]
     return mr, [int(r2c[i]) for i in mr], [int(i) for i in range(m) if r2c[i] < 0], [int(j) for j in range(n) if not used[j]]
 

@@ -130,6 +130,8 @@ struct TrackerState {          // one stream; device pointers; double-buffered (
 struct TrackerArgs {
     int n_streams, stream_base, max_tracks, max_dets;   // grid = n_streams workgroups, stream index = stream_base + blockIdx.x
     float track_thresh, match_thresh; int track_buffer;
+    int assign_mode;           // RTMODT_ASSIGN_GREEDY | RTMODT_ASSIGN_LAPJV
+    double cost_limit;         // lapjv: 1 - match_thresh evaluated in double (tracker.py:170)
     TrackerState *states;      // device array [n_streams]
     int64_t *meta;             // device [n_streams][8]: {cur, n_tracks, err, n_active, next_id, 0, 0, 0}
     // detections: [n_streams][det_stride] boxes / conf / cls ; counts [n_streams]
@@ -139,6 +141,8 @@ int launch_tracker_update(const TrackerArgs &a, hipStream_t s);
 int launch_iou_matrix(const float4 *a, int m, const float4 *b, int n, float *out, hipStream_t s);
 int launch_assign_greedy(const float *iou, int m, int n, float thresh, int32_t *row_to_col, int32_t *col_used,
                          hipStream_t s);
+int launch_assign_lapjv(const float *iou, int m, int n, double cost_limit, int32_t *row_to_col, int32_t *col_used, int32_t *err,
+                        hipStream_t s);
 
 // device-resident results of a detector's last enqueue_batch (engine.hip), consumed by the tracker
 struct DetOutputs { const float4 *box; const float *conf; const int32_t *cls; const int32_t *n; int stride, count, device; hipStream_t stream; };

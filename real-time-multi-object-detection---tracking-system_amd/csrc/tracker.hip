@@ -10,6 +10,9 @@
 //                         order-free form: row i is matched iff it is the SMALLEST row among
 //                         those whose first-arg-max column is j and whose value >= thresh
 //                         (oracle/tracker_oracle.py:assign_greedy_parallel proves the equivalence)
+//   assoc_lap          <- _linear_assignment  tracker.py:168-181  lap.lapjv branch (PARITY UNPINNED:
+//                         `lap` is not installed anywhere this runs; restated from its published
+//                         algorithm, see the comment at assoc_lap)
 //   tracker_update     <- _ByteTrackCore.update tracker.py:58-141, _age_tracks :144-148
 //
 // Build with -ffp-contract=off: every float op below must round separately, exactly like
@@ -101,6 +104,221 @@ __device__ __forceinline__ void assoc_pass(const AssocSmem &s, const int *rows, 
     __syncthreads();
 }
 
+
+// ---------------------------------------------------------------------------------------
+// assoc_lap: the `lap.lapjv(1 - iou, extend_cost=True, cost_limit=1 - thresh)` branch
+// (tracker.py:168-181).  lap embeds the M x N cost in an (M+N)^2 matrix whose off-diagonal
+// blocks are cost_limit/2 and whose lower-right block is 0, so matching (i, j) costs c_ij while
+// leaving both unmatched costs cost_limit: the optimum is the MAXIMUM-GAIN matching of the
+// bipartite graph of pairs with gain cost_limit - c_ij > 0 (c_ij = double(float32(1 - iou))).
+// At match_thresh 0.8 that graph is almost a perfect set of isolated edges, so:
+//   1. every lane group scans a row, counts its candidate columns (row degree) and bumps the
+//      column degrees (LDS atomics);
+//   2. an edge whose row AND column have degree 1 is a connected component by itself and is
+//      matched outright (its gain is positive);
+//   3. the remaining "contested" rows/columns (<= LAP_ROWS / LAP_COLS, <= LAP_EDGES edges) are
+//      compacted into LDS and solved EXACTLY by one lane with the shortest-augmenting-path
+//      (Hungarian / Jonker-Volgenant) method on the sparse graph: every row has a private dummy
+//      column of cost 0 (= stay unmatched), real edges cost c_ij - cost_limit < 0, potentials in
+//      double.  Only the source row's edges can have negative reduced cost, so the Dijkstra
+//      scan is valid; only touched columns are ever visited or reset.
+// A scene denser than the LDS budget raises the sticky error 2 (host: RTMODT_E_CAPACITY).
+// Output convention = assoc_pass: row r matched iff row_best[r] >= 0 && col_winner[row_best[r]] == r.
+// ---------------------------------------------------------------------------------------
+constexpr int LAP_ROWS = 256, LAP_COLS = 256, LAP_EDGES = 2048;
+struct LapSmem {
+    int *colmap;                   // [n_cols capacity] column -> local index among contested columns (-1 none, -2 marked)
+    double *ecost, *u, *v, *minv;  // [LAP_EDGES], [LAP_ROWS], [LAP_COLS], [LAP_COLS]
+    int *hrow, *hcol, *estart, *ecol;         // [LAP_ROWS], [LAP_COLS], [LAP_ROWS + 1], [LAP_EDGES]
+    int *p, *rm, *wayrow, *touched, *usedl;   // col -> row, row -> col, col -> row it was reached from, lists
+    unsigned char *used;           // [LAP_COLS]
+};
+static size_t lap_smem_bytes(int Nc) {
+    return (size_t)LAP_EDGES * 12 + (size_t)LAP_ROWS * (8 + 4 + 4 + 4) + (size_t)LAP_COLS * (8 + 8 + 4 + 4 + 4 + 4 + 4 + 1) + (size_t)Nc * 4 + 64;
+}
+__device__ __forceinline__ LapSmem lap_carve(unsigned char *base, int Nc) {     // base 8-byte aligned
+    LapSmem L;
+    L.ecost = (double *)base;
+    L.u = L.ecost + LAP_EDGES;
+    L.v = L.u + LAP_ROWS;
+    L.minv = L.v + LAP_COLS;
+    L.colmap = (int *)(L.minv + LAP_COLS);
+    L.hrow = L.colmap + Nc;
+    L.hcol = L.hrow + LAP_ROWS;
+    L.estart = L.hcol + LAP_COLS;
+    L.ecol = L.estart + LAP_ROWS + 1;
+    L.p = L.ecol + LAP_EDGES;
+    L.rm = L.p + LAP_COLS;
+    L.wayrow = L.rm + LAP_ROWS;
+    L.touched = L.wayrow + LAP_COLS;
+    L.usedl = L.touched + LAP_COLS;
+    L.used = (unsigned char *)(L.usedl + LAP_COLS);
+    return L;
+}
+
+// exact sparse assignment of the contested sub-problem, run by ONE lane
+__device__ void lap_solve(const LapSmem &L, int nhr) {
+    const double INF = __builtin_huge_val();
+    for (int h0 = 0; h0 < nhr; ++h0) {
+        int nt = 0, nu = 0, i0 = h0, jend = -1, drow = -1;
+        double dmin = INF;
+        bool to_dummy = false;
+        while (true) {
+            const double ui = L.u[i0];
+            for (int e = L.estart[i0]; e < L.estart[i0 + 1]; ++e) {          // relax the real edges of row i0
+                const int j = L.ecol[e];
+                if (L.used[j]) continue;
+                const double cur = L.ecost[e] - ui - L.v[j];
+                if (L.minv[j] == INF) L.touched[nt++] = j;
+                if (cur < L.minv[j]) { L.minv[j] = cur; L.wayrow[j] = i0; }
+            }
+            if (0.0 - ui < dmin) { dmin = 0.0 - ui; drow = i0; }             // ... and its dummy edge
+            double delta = dmin;
+            int j1 = -1;
+            for (int t = 0; t < nt; ++t) {
+                const int j = L.touched[t];
+                if (!L.used[j] && L.minv[j] < delta) { delta = L.minv[j]; j1 = j; }
+            }
+            L.u[h0] += delta;
+            for (int t = 0; t < nu; ++t) { const int j = L.usedl[t]; L.u[L.p[j]] += delta; L.v[j] -= delta; }
+            for (int t = 0; t < nt; ++t) { const int j = L.touched[t]; if (!L.used[j]) L.minv[j] -= delta; }
+            dmin -= delta;
+            if (j1 < 0) { to_dummy = true; break; }
+            if (L.p[j1] < 0) { jend = j1; break; }
+            L.used[j1] = 1;
+            L.usedl[nu++] = j1;
+            i0 = L.p[j1];
+        }
+        if (to_dummy) {                                   // row drow gives up its column; shift the path back to h0
+            int i = drow, jfree = L.rm[i];
+            L.rm[i] = -1;
+            while (i != h0) {
+                const int j = jfree, ip = L.wayrow[j];
+                jfree = L.rm[ip];
+                L.p[j] = ip;
+                L.rm[ip] = j;
+                i = ip;
+            }
+        } else {
+            int j = jend;
+            while (true) {
+                const int ip = L.wayrow[j], jn = L.rm[ip];
+                L.p[j] = ip;
+                L.rm[ip] = j;
+                if (ip == h0) break;
+                j = jn;
+            }
+        }
+        for (int t = 0; t < nt; ++t) { const int j = L.touched[t]; L.minv[j] = INF; L.used[j] = 0; }
+    }
+}
+
+// val(r, c): IoU (float32) of row r and column c of this pass
+template <typename F>
+__device__ __forceinline__ void assoc_lap(F val, int n_rows, int n_cols, double limit, int *row_best, int *col_winner, int *rowcand,
+                                          const LapSmem &L, int *wsum, int *err) {
+    const int tid = threadIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int c = tid; c < n_cols; c += TRK_THREADS) { col_winner[c] = 0; L.colmap[c] = -1; }
+    __syncthreads();
+    // ---- 1. degrees ----
+    int R = 64;
+    while (R > 1 && (n_rows * R > TRK_THREADS || (R >> 1) >= n_cols)) R >>= 1;
+    const int groups = TRK_THREADS / R;
+    const int gid = threadIdx.x / R, sub = threadIdx.x & (R - 1);
+    for (int r = gid; r < n_rows; r += groups) {
+        int deg = 0, last = -1;
+        for (int c = sub; c < n_cols; c += R) {
+            const float v = val(r, c);
+            if ((double)(1.0f - v) < limit) { ++deg; last = c; atomicAdd(&col_winner[c], 1); }
+        }
+        for (int d = R >> 1; d >= 1; d >>= 1) {
+            deg += __shfl_xor(deg, d);
+            last = max(last, __shfl_xor(last, d));
+        }
+        if (sub == 0) { row_best[r] = deg; rowcand[r] = last; }
+    }
+    __syncthreads();
+    // ---- 2. isolated edges vs contested rows (ascending) ----
+    int nhr = 0;
+    for (int base = 0; base < n_rows; base += TRK_THREADS) {
+        const int r = base + tid;
+        bool hard = false;
+        if (r < n_rows) {
+            const int deg = row_best[r];
+            hard = deg >= 2 || (deg == 1 && col_winner[rowcand[r]] != 1);
+            if (deg != 1 || hard) rowcand[r] = -1;          // rowcand >= 0 from here on == isolated edge
+        }
+        int tot;
+        const int pos = block_scan_flag(hard, wsum, tot);
+        if (hard && nhr + pos < LAP_ROWS) L.hrow[nhr + pos] = r;
+        nhr += tot;
+    }
+    bool dense = nhr > LAP_ROWS;
+    if (dense) nhr = 0;
+    if (tid == 0) {
+        int e = 0;
+        for (int h = 0; h < nhr; ++h) { L.estart[h] = e; e += row_best[L.hrow[h]]; }
+        L.estart[nhr] = e;
+    }
+    __syncthreads();
+    int ne = L.estart[nhr];
+    if (ne > LAP_EDGES) { dense = true; nhr = 0; ne = 0; }
+    // ---- 3. edges of the contested rows, columns ascending: one wave per row ----
+    for (int h = wave; h < nhr; h += TRK_WAVES) {
+        const int r = L.hrow[h];
+        int e0 = L.estart[h];
+        for (int cb = 0; cb < n_cols; cb += 64) {
+            const int c = cb + lane;
+            bool f = false;
+            double cost = 0.0;
+            if (c < n_cols) { cost = (double)(1.0f - val(r, c)); f = cost < limit; }
+            const unsigned long long m = __ballot(f);
+            if (f) {
+                const int e = e0 + __popcll(m & ((1ull << lane) - 1ull));
+                L.ecol[e] = c;
+                L.ecost[e] = cost - limit;
+                L.colmap[c] = -2;
+            }
+            e0 += __popcll(m);
+        }
+    }
+    __syncthreads();
+    int nhc = 0;
+    for (int base = 0; base < n_cols; base += TRK_THREADS) {
+        const int c = base + tid;
+        const bool f = c < n_cols && L.colmap[c] == -2;
+        int tot;
+        const int pos = block_scan_flag(f, wsum, tot);
+        if (f && nhc + pos < LAP_COLS) { L.colmap[c] = nhc + pos; L.hcol[nhc + pos] = c; }
+        nhc += tot;
+    }
+    if (nhc > LAP_COLS) { dense = true; nhr = 0; ne = 0; nhc = 0; }
+    __syncthreads();
+    for (int e = tid; e < ne; e += TRK_THREADS) L.ecol[e] = L.colmap[L.ecol[e]];
+    for (int h = tid; h < nhr; h += TRK_THREADS) { L.u[h] = 0.0; L.rm[h] = -1; }
+    for (int j = tid; j < nhc; j += TRK_THREADS) { L.v[j] = 0.0; L.minv[j] = __builtin_huge_val(); L.p[j] = -1; L.used[j] = 0; }
+    for (int c = tid; c < n_cols; c += TRK_THREADS) col_winner[c] = INT_MAX;
+    __syncthreads();
+    for (int r = tid; r < n_rows; r += TRK_THREADS) {
+        const int c = rowcand[r];
+        row_best[r] = c;
+        if (c >= 0) col_winner[c] = r;
+    }
+    __syncthreads();
+    // ---- 4. the contested sub-problem ----
+    if (tid == 0) {
+        if (dense) *err = 2;
+        lap_solve(L, nhr);
+        for (int h = 0; h < nhr; ++h)
+            if (L.rm[h] >= 0) {
+                const int r = L.hrow[h], c = L.hcol[L.rm[h]];
+                row_best[r] = c;
+                col_winner[c] = r;
+            }
+    }
+    __syncthreads();
+}
+
 __global__ __launch_bounds__(TRK_THREADS) void tracker_update(TrackerArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int sidx = a.stream_base + blockIdx.x;
@@ -118,6 +336,11 @@ __global__ __launch_bounds__(TRK_THREADS) void tracker_update(TrackerArgs a) {
     int *um_t = row_best + Mc;
     int *t_matched = um_t + Mc;
     int *wsum = t_matched + Mc;
+    const bool lapjv = a.assign_mode == RTMODT_ASSIGN_LAPJV;
+    LapSmem lap{};
+    if (lapjv) lap = lap_carve((unsigned char *)(((uintptr_t)(wsum + TRK_WAVES + 1) + 7) & ~(uintptr_t)7), Nc);
+    __shared__ int lap_err;
+    if (threadIdx.x == 0) lap_err = 0;
 
     TrackerState st = a.states[sidx];
     long long *meta = (long long *)a.meta + (size_t)sidx * 8;
@@ -171,7 +394,8 @@ __global__ __launch_bounds__(TRK_THREADS) void tracker_update(TrackerArgs a) {
     // ---- 2. first association: ALL tracks x high detections (tracker.py:91-106) ----
     const bool pass1 = M > 0 && nh > 0;
     if (pass1) {
-        assoc_pass(as, nullptr, M, hi_idx, nh, a.match_thresh);
+        if (lapjv) assoc_lap([&](int r, int c) { return iou_ref(tbox[r], dbox[hi_idx[c]]); }, M, nh, a.cost_limit, row_best, col_winner, t_matched, lap, wsum, &lap_err);
+        else assoc_pass(as, nullptr, M, hi_idx, nh, a.match_thresh);
         for (int i = tid; i < M; i += TRK_THREADS) {
             int c = row_best[i];
             bool matched = c >= 0 && col_winner[c] == i;
@@ -216,7 +440,8 @@ __global__ __launch_bounds__(TRK_THREADS) void tracker_update(TrackerArgs a) {
 
     // ---- 3. second association: unmatched tracks x low detections, SAME threshold (tracker.py:110-123) ----
     if (num > 0 && nl > 0) {
-        assoc_pass(as, um_t, num, lo_idx, nl, a.match_thresh);
+        if (lapjv) assoc_lap([&](int r, int c) { return iou_ref(tbox[um_t[r]], dbox[lo_idx[c]]); }, num, nl, a.cost_limit, row_best, col_winner, t_matched, lap, wsum, &lap_err);
+        else assoc_pass(as, um_t, num, lo_idx, nl, a.match_thresh);
         for (int r = tid; r < num; r += TRK_THREADS) {
             int c = row_best[r];
             if (c >= 0 && col_winner[c] == r) {
@@ -273,6 +498,7 @@ __global__ __launch_bounds__(TRK_THREADS) void tracker_update(TrackerArgs a) {
         meta[0] = nxt;
         meta[1] = kept;
         if (err) meta[2] = 1;
+        else if (lap_err) meta[2] = lap_err;
         meta[3] = active;
         meta[4] = next_id + nsp;
     }
@@ -283,7 +509,7 @@ static size_t tracker_smem_bytes(int Mc, int Nc) {
 }
 
 int launch_tracker_update(const TrackerArgs &a, hipStream_t s) {
-    size_t smem = tracker_smem_bytes(a.max_tracks, a.max_dets);
+    size_t smem = tracker_smem_bytes(a.max_tracks, a.max_dets) + (a.assign_mode == RTMODT_ASSIGN_LAPJV ? lap_smem_bytes(a.max_dets) + 8 : 0);
     RT_CHECK(smem <= 150 * 1024, RTMODT_E_INVALID, "tracker: max_tracks %d / max_dets %d need %zu B of LDS (> 160 KiB)", a.max_tracks,
              a.max_dets, smem);
     static size_t attr_bytes = 0;
@@ -350,6 +576,40 @@ __global__ __launch_bounds__(TRK_THREADS) void assign_greedy_kernel(const float 
 
 int launch_assign_greedy(const float *iou, int m, int n, float thresh, int32_t *row_to_col, int32_t *col_used, hipStream_t s) {
     hipLaunchKernelGGL(assign_greedy_kernel, dim3(1), dim3(TRK_THREADS), 0, s, iou, m, n, thresh, row_to_col, col_used);
+    RT_HIP(hipGetLastError());
+    return RTMODT_OK;
+}
+
+
+// lapjv branch on a caller-supplied matrix: one workgroup; LDS = row_best[m] rowcand[m] col_winner[n] + LapSmem
+__global__ __launch_bounds__(TRK_THREADS) void assign_lapjv_kernel(const float *__restrict__ iou, int m, int n, double limit,
+                                                                   int32_t *__restrict__ row_to_col, int32_t *__restrict__ col_used,
+                                                                   int32_t *__restrict__ err_out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int *row_best = (int *)smem, *rowcand = row_best + m, *col_winner = rowcand + m, *wsum = col_winner + n;
+    LapSmem L = lap_carve((unsigned char *)(((uintptr_t)(wsum + TRK_WAVES + 1) + 7) & ~(uintptr_t)7), n);
+    __shared__ int err;
+    if (threadIdx.x == 0) err = 0;
+    __syncthreads();
+    assoc_lap([&](int r, int c) { return iou[(long)r * n + c]; }, m, n, limit, row_best, col_winner, rowcand, L, wsum, &err);
+    for (int r = threadIdx.x; r < m; r += TRK_THREADS) {
+        const int c = row_best[r];
+        row_to_col[r] = (c >= 0 && col_winner[c] == r) ? c : -1;
+    }
+    for (int c = threadIdx.x; c < n; c += TRK_THREADS) col_used[c] = col_winner[c] != INT_MAX;
+    if (threadIdx.x == 0) *err_out = err;
+}
+
+int launch_assign_lapjv(const float *iou, int m, int n, double cost_limit, int32_t *row_to_col, int32_t *col_used, int32_t *err,
+                        hipStream_t s) {
+    size_t smem = (size_t)(2 * m + n + TRK_WAVES + 1) * 4 + 8 + lap_smem_bytes(n);
+    RT_CHECK(smem <= 150 * 1024, RTMODT_E_INVALID, "assign_lapjv: %d x %d needs %zu B of LDS", m, n, smem);
+    static size_t attr_bytes = 0;
+    if (smem > attr_bytes) {
+        RT_HIP(hipFuncSetAttribute((const void *)assign_lapjv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        attr_bytes = smem;
+    }
+    hipLaunchKernelGGL(assign_lapjv_kernel, dim3(1), dim3(TRK_THREADS), smem, s, iou, m, n, cost_limit, row_to_col, col_used, err);
     RT_HIP(hipGetLastError());
     return RTMODT_OK;
 }

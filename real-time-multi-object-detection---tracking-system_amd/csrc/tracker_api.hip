@@ -15,6 +15,8 @@ struct rtmodt_tracker {
     int S = 1, Mc = 0, Nc = 0;
     float track_thresh = 0.5f, match_thresh = 0.8f;
     int track_buffer = 30;
+    int assign_mode = RTMODT_ASSIGN_GREEDY;
+    double cost_limit = 0.2;
     // device
     char *pool = nullptr;                 // all state arrays
     TrackerState *d_states = nullptr;
@@ -78,13 +80,14 @@ static int tracker_create_impl(rtmodt_tracker *t) {
 int rtmodt_tracker_create(int device, float track_thresh, int track_buffer, float match_thresh, int assign_mode, int max_tracks,
                           int max_dets, int n_streams, rtmodt_tracker **out) {
     RT_CHECK(out, RTMODT_E_INVALID, "null argument");
-    RT_CHECK(assign_mode == RTMODT_ASSIGN_GREEDY, RTMODT_E_UNSUPPORTED,
-             "assign_mode %d: only the greedy branch (tracker.py:182-194) is built; lapjv is not", assign_mode);
+    RT_CHECK(assign_mode == RTMODT_ASSIGN_GREEDY || assign_mode == RTMODT_ASSIGN_LAPJV, RTMODT_E_UNSUPPORTED,
+             "assign_mode %d: 0 (greedy, tracker.py:182-194) or 1 (lapjv, tracker.py:168-181)", assign_mode);
     RT_CHECK(max_tracks >= 1 && max_tracks <= 4096 && max_dets >= 1 && max_dets <= 4096 && n_streams >= 1 && n_streams <= 4096,
              RTMODT_E_INVALID, "max_tracks %d / max_dets %d / n_streams %d out of range", max_tracks, max_dets, n_streams);
     rtmodt_tracker *t = new rtmodt_tracker();
     t->device = device; t->S = n_streams; t->Mc = max_tracks; t->Nc = max_dets;
     t->track_thresh = track_thresh; t->match_thresh = match_thresh; t->track_buffer = track_buffer;
+    t->assign_mode = assign_mode; t->cost_limit = 1.0 - (double)match_thresh;
     int rc = tracker_create_impl(t);
     if (rc != RTMODT_OK) {
         std::string keep = last_error();
@@ -96,13 +99,27 @@ int rtmodt_tracker_create(int device, float track_thresh, int track_buffer, floa
     return RTMODT_OK;
 }
 
+int rtmodt_tracker_set_cost_limit(rtmodt_tracker *t, double cost_limit) {
+    RT_CHECK(t && cost_limit == cost_limit, RTMODT_E_INVALID, "bad argument");
+    t->cost_limit = cost_limit;
+    return RTMODT_OK;
+}
+
 static TrackerArgs make_args(rtmodt_tracker *t) {
     TrackerArgs a{};
     a.n_streams = t->S; a.stream_base = 0; a.max_tracks = t->Mc; a.max_dets = t->Nc;
     a.track_thresh = t->track_thresh; a.match_thresh = t->match_thresh; a.track_buffer = t->track_buffer;
+    a.assign_mode = t->assign_mode; a.cost_limit = t->cost_limit;
     a.states = t->d_states; a.meta = t->d_meta;
     a.det_box = t->d_box; a.det_conf = t->d_conf; a.det_cls = t->d_cls; a.det_n = t->d_n; a.det_stride = t->Nc;
     return a;
+}
+
+static int check_sticky(rtmodt_tracker *t, int s, int64_t err) {
+    RT_CHECK(err != 1, RTMODT_E_CAPACITY, "stream %d: more than max_tracks=%d live tracks", s, t->Mc);
+    RT_CHECK(err != 2, RTMODT_E_CAPACITY, "stream %d: lapjv assignment too dense (more than 256 contested rows/columns or 2048 contested pairs)", s);
+    RT_CHECK(err == 0, RTMODT_E_INVALID, "stream %d: tracker error %lld", s, (long long)err);
+    return RTMODT_OK;
 }
 
 // reads back meta rows [s0, s0+cnt) after the launch; raises the sticky capacity error
@@ -111,7 +128,7 @@ static int finish(rtmodt_tracker *t, int s0, int cnt, int32_t *n_active_out) {
     RT_HIP(hipStreamSynchronize(t->stream));
     for (int s = s0; s < s0 + cnt; ++s) {
         if (n_active_out) n_active_out[s - s0] = (int32_t)t->h_meta[8 * s + 3];
-        RT_CHECK(t->h_meta[8 * s + 2] == 0, RTMODT_E_CAPACITY, "stream %d: more than max_tracks=%d live tracks", s, t->Mc);
+        RT_TRY(check_sticky(t, s, t->h_meta[8 * s + 2]));
     }
     return RTMODT_OK;
 }
@@ -172,7 +189,7 @@ int rtmodt_tracker_state(rtmodt_tracker *t, int stream, int64_t *ids, float *xyx
     RT_HIP(hipDeviceSynchronize());                       // the detector's stream may still be updating us
     int64_t m[8];
     RT_HIP(hipMemcpy(m, t->d_meta + 8 * stream, sizeof(m), hipMemcpyDeviceToHost));
-    RT_CHECK(m[2] == 0, RTMODT_E_CAPACITY, "stream %d: more than max_tracks=%d live tracks", stream, t->Mc);
+    RT_TRY(check_sticky(t, stream, m[2]));
     const int cur = (int)m[0], cnt = (int)m[1];
     const TrackerState &st = t->h_states[stream];
     if (n) *n = cnt;
@@ -234,6 +251,28 @@ int rtmodt_assign_greedy(int device, const float *iou, int m, int n, float thres
     };
     int rc = body();
     hipFree(di); hipFree(dr); hipFree(dc);
+    return rc;
+}
+
+int rtmodt_assign_lapjv(int device, const float *iou, int m, int n, double cost_limit, int32_t *row_to_col, int32_t *col_used) {
+    RT_CHECK(m >= 1 && n >= 1 && m <= 4096 && n <= 4096 && iou && row_to_col && col_used && cost_limit == cost_limit, RTMODT_E_INVALID, "bad argument");
+    RT_HIP(hipSetDevice(device));
+    float *di = nullptr; int32_t *dr = nullptr, *dc = nullptr, *de = nullptr;
+    int32_t err = 0;
+    auto body = [&]() -> int {
+        RT_HIP(hipMalloc((void **)&di, (size_t)m * n * 4)); RT_HIP(hipMalloc((void **)&dr, (size_t)m * 4));
+        RT_HIP(hipMalloc((void **)&dc, (size_t)n * 4)); RT_HIP(hipMalloc((void **)&de, 4));
+        RT_HIP(hipMemcpy(di, iou, (size_t)m * n * 4, hipMemcpyHostToDevice));
+        RT_TRY(launch_assign_lapjv(di, m, n, cost_limit, dr, dc, de, nullptr));
+        RT_HIP(hipDeviceSynchronize());
+        RT_HIP(hipMemcpy(row_to_col, dr, (size_t)m * 4, hipMemcpyDeviceToHost));
+        RT_HIP(hipMemcpy(col_used, dc, (size_t)n * 4, hipMemcpyDeviceToHost));
+        RT_HIP(hipMemcpy(&err, de, 4, hipMemcpyDeviceToHost));
+        RT_CHECK(err == 0, RTMODT_E_CAPACITY, "assign_lapjv: too dense (more than 256 contested rows/columns or 2048 contested pairs)");
+        return RTMODT_OK;
+    };
+    int rc = body();
+    hipFree(di); hipFree(dr); hipFree(dc); hipFree(de);
     return rc;
 }
 

@@ -54,6 +54,9 @@ class _ByteTrackCore:
         _ffi.check(_ffi.lib().rtmodt_tracker_create(self._device, float(track_thresh), int(track_buffer), float(match_thresh),
                                                     int(assign_mode), int(max_tracks), int(max_dets), int(n_streams), C.byref(h)))
         self._h = h
+        self.assign_mode = int(assign_mode)
+        if self.assign_mode == _ffi.ASSIGN_LAPJV:        # tracker.py:170: cost_limit = 1 - thresh in Python doubles
+            _ffi.check(_ffi.lib().rtmodt_tracker_set_cost_limit(self._h, float(1 - match_thresh)))
 
     # -- tracker.py:58-141 -------------------------------------------------------------
     def update(self, xyxy: np.ndarray, confidence: np.ndarray, class_id: np.ndarray, stream: int = 0) -> list:
@@ -131,11 +134,15 @@ class MultiObjectTracker:
     #: "reference" -> tracks with time_since_update == 0 after ageing (always []);
     #: "matched"   -> tracks matched or spawned this frame (time_since_update == 1).
     report = "reference"
+    #: which branch of _linear_assignment (tracker.py:163-194) runs: the reference takes "lapjv" when the
+    #: optional ``lap`` package imports and "greedy" otherwise; "greedy" is the branch pinned by fixtures.
+    assignment = "greedy"
 
     def __init__(self, algorithm: str = "bytetrack", **kwargs) -> None:
         self.algorithm = algorithm.lower()
         if self.algorithm == "bytetrack":
             p = kwargs.get("bytetrack", kwargs)           # flat kwargs or nested dict; unknown keys ignored
+            self.assignment = p.get("assignment", type(self).assignment)
             self._core = _ByteTrackCore(
                 track_thresh=p.get("track_thresh", 0.5),
                 track_buffer=p.get("track_buffer", 30),
@@ -143,6 +150,7 @@ class MultiObjectTracker:
                 device=p.get("device", kwargs.get("device", 0)),
                 max_tracks=p.get("max_tracks", 2048),
                 max_dets=p.get("max_dets", 1024),
+                assign_mode={"greedy": _ffi.ASSIGN_GREEDY, "lapjv": _ffi.ASSIGN_LAPJV}[self.assignment],
             )
         elif self.algorithm == "deepsort":
             raise NotImplementedError("DeepSORT adapter not yet wired. Use bytetrack.")

@@ -122,5 +122,76 @@ def test_capacity_errors(pkg):
         core2.update(xy[0], cf, cl)
     assert e.value.code == pkg._ffi.E_CAPACITY
     with pytest.raises(pkg._ffi.RtmodtError) as e:
-        core_cls(assign_mode=pkg._ffi.ASSIGN_LAPJV)
+        core_cls(assign_mode=7)
     assert e.value.code == pkg._ffi.E_UNSUPPORTED
+
+
+# ------------------------------------------------------------------ lap.lapjv branch (tracker.py:168-181), PARITY UNPINNED
+def contested_boxes(rng, n, size=640.0, dup=0.35):
+    """n track boxes and a detection list in which a share of the tracks has 2-3 near-identical
+    detections and some tracks are near-duplicates of each other: IoU > 0.8 candidate pairs that share
+    rows and columns, i.e. the components the exact solver (not the isolated-edge shortcut) must handle."""
+    wh = rng.uniform(40, 120, size=(n, 2))
+    c = rng.uniform(60, size - 60, size=(n, 2))
+    t = np.concatenate([c - wh / 2, c + wh / 2], axis=1).astype(np.float32)
+    k = int(n * dup)
+    t[n - k:] = t[:k] + rng.normal(0, 1.0, size=(k, 4)).astype(np.float32)          # near-duplicate tracks
+    d = [t + rng.normal(0, 0.8, size=t.shape).astype(np.float32)]
+    for _ in range(2):
+        sel = rng.random(n) < dup
+        d.append(t[sel] + rng.normal(0, 1.2, size=(int(sel.sum()), 4)).astype(np.float32))
+    d = np.concatenate(d).astype(np.float32)
+    return t, d[rng.permutation(len(d))]
+
+
+def gain(iou, mr, mc, thresh):
+    lim = 1 - thresh
+    return sum(lim - float(np.float32(1) - iou[i, j]) for i, j in zip(mr, mc))
+
+
+@pytest.mark.parametrize("case", ["uniform12x9", "contested40", "contested150", "sparse200", "single", "ties"])
+def test_lapjv_assignment_vs_oracle(pkg, case):
+    rng = np.random.default_rng(11)
+    if case == "uniform12x9":
+        mats = [rng.uniform(0.6, 1.0, size=(12, 9)).astype(np.float32) for _ in range(6)]
+    elif case == "single":
+        mats = [np.array([[0.9]], np.float32), np.array([[0.5]], np.float32), np.array([[0.81, 0.95, 0.1]], np.float32),
+                np.array([[0.81], [0.95], [0.1]], np.float32)]
+    elif case == "ties":                                   # float32(0.8) itself: cost 0.19999999 < 1 - 0.8 (double) -> a candidate
+        mats = [np.array([[np.float32(0.8), 0.0], [0.0, np.nextafter(np.float32(0.8), np.float32(0))]], np.float32)]
+    else:
+        n = {"contested40": 40, "contested150": 150, "sparse200": 200}[case]
+        mats = []
+        for _ in range(3):
+            t, d = contested_boxes(rng, n, dup=0.0 if case == "sparse200" else 0.35)
+            mats.append(T.batch_iou(t, d))
+    for iou in mats:
+        ref = T.assign_lapjv(iou, 0.8)
+        got = pkg._ffi.assign_lapjv(iou, 0.8)
+        assert abs(gain(iou, got[0], got[1], 0.8) - gain(iou, ref[0], ref[1], 0.8)) < 1e-12       # both optimal
+        assert got == ref, (case, got[:2], ref[:2])
+
+
+def test_lapjv_tracker_sequence_vs_oracle(pkg):
+    """_ByteTrackCore with the lapjv branch over a crowded sequence (duplicated detections every frame)
+    against the oracle running scipy's exact solver on lap's extended matrix."""
+    rng = np.random.default_rng(5)
+    core = pkg.tracking.tracker._ByteTrackCore(assign_mode=pkg._ffi.ASSIGN_LAPJV)
+    ora = T.TrackerOracle(assign="lapjv")
+    xy, cf, cl = pkg.synth.box_sequence(120, 640, 60, seed=77)
+    for f in range(60):
+        dup = rng.random(120) < 0.3
+        b = np.concatenate([xy[f], xy[f][dup] + rng.normal(0, 1.0, size=(int(dup.sum()), 4)).astype(np.float32)]).astype(np.float32)
+        c = np.concatenate([cf, rng.uniform(0.2, 0.95, size=int(dup.sum())).astype(np.float32)])
+        k = np.concatenate([cl, cl[dup]]).astype(np.int32)
+        core.update(b, c, k)
+        ora.update(b, c, k)
+        assert np.array_equal(T.state_digest(core.snapshot()), T.state_digest(ora.snapshot())), f"frame {f}"
+    core.close()
+
+
+def test_lapjv_too_dense_is_an_error(pkg):
+    iou = np.full((300, 300), 0.95, np.float32)            # one 300 x 300 component: beyond the LDS budget
+    with pytest.raises(pkg._ffi.RtmodtError) as e:
+        pkg._ffi.assign_lapjv(iou, 0.8)
+    assert e.value.code == pkg._ffi.E_CAPACITY

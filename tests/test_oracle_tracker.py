@@ -121,3 +121,35 @@ def test_lapjv_restatement_is_optimal_and_respects_limit():
     assert len(set(mc)) == len(mc)
     assert all(c[i, j] > np.float32(0.8) - 1e-6 for i, j in zip(mr, mc))
     assert sorted(mr + ur) == list(range(12))
+
+
+def _best_matching_bruteforce(iou, thresh):
+    """max over all partial matchings of sum(cost_limit - cost) -- the definition lap's extended matrix encodes"""
+    m, n = iou.shape
+    lim = 1 - thresh
+    g = lim - (np.float32(1) - iou).astype(np.float64)
+    best = [0.0, ()]
+
+    def rec(i, used, tot, pairs):
+        if i == m:
+            if tot > best[0] + 1e-15:
+                best[0], best[1] = tot, pairs
+            return
+        rec(i + 1, used, tot, pairs)
+        for j in range(n):
+            if not used & (1 << j) and g[i, j] > 0:
+                rec(i + 1, used | (1 << j), tot + g[i, j], pairs + ((i, j),))
+
+    rec(0, 0, 0.0, ())
+    return best
+
+
+def test_lapjv_restatement_equals_bruteforce_optimum():
+    rng = np.random.default_rng(3)
+    for _ in range(40):
+        m, n = rng.integers(1, 6, size=2)
+        iou = rng.uniform(0.6, 1.0, size=(m, n)).astype(np.float32)
+        mr, mc, ur, uc = T.assign_lapjv(iou, 0.8)
+        tot, pairs = _best_matching_bruteforce(iou, 0.8)
+        assert tuple(zip(mr, mc)) == pairs
+        assert sorted(mr + ur) == list(range(m)) and sorted(mc + uc) == list(range(n))
