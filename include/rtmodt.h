@@ -67,6 +67,8 @@ typedef struct rtmodt_det_cfg {
     int32_t use_graph;         /* 1: replay the forward pass as one captured hipGraph                      */
     int32_t autotune;          /* 1: time every conv tile configuration at create and keep the fastest      */
     int32_t chains;            /* sub-batches run as separate graphs on separate streams; 0 = 1 (more measured slower) */
+    int32_t rect;              /* 1: minimal-rectangle letterbox of `predict` on a .pt model (LetterBox auto=True): the scale is
+                                * min(S/h, S/w) with S = max(in_w, in_h) and in_w x in_h is the rectangle (1080p: 640 x 384) */
 } rtmodt_det_cfg;
 
 int rtmodt_detector_create(const rtmodt_det_cfg *cfg, rtmodt_detector **out);

@@ -342,9 +342,10 @@ def letterbox(img: np.ndarray, new_h=640, new_w=640, auto=False, stride=32):
     return out, (uw, uh, top, left)
 
 
-def preprocess(frame_bgr: np.ndarray, new_h=640, new_w=640):
-    """BGR uint8 HWC -> letterbox(114) -> RGB -> float32 /255, NHWC."""
-    lb, _ = letterbox(frame_bgr, new_h, new_w)
+def preprocess(frame_bgr: np.ndarray, new_h=640, new_w=640, auto=False):
+    """BGR uint8 HWC -> letterbox(114) -> RGB -> float32 /255, NHWC.  ``auto=True`` is what
+    ``predict`` does for a ``.pt`` model (minimal rectangle: pads taken mod 32, App. B.1)."""
+    lb, _ = letterbox(frame_bgr, new_h, new_w, auto=auto)
     return (lb[..., ::-1].astype(F32) / F32(255)).astype(F32)
 
 
@@ -455,10 +456,13 @@ def scale_boxes(boxes, in_h, in_w, orig_h, orig_w):
 # Detector.detect end to end  (detector.py:98-129)
 # ---------------------------------------------------------------------------
 def detect(frame_bgr, weights, scale="s", input_size=(640, 640), confidence=0.35, iou=0.45,
-           classes=None, max_det=100, agnostic_nms=False, nc=80, return_intermediate=False):
-    """Returns (xyxy (N,4) f32, confidence (N,) f32, class_id (N,) i32) like ``Detector._parse``."""
+           classes=None, max_det=100, agnostic_nms=False, nc=80, return_intermediate=False, rect=False):
+    """Returns (xyxy (N,4) f32, confidence (N,) f32, class_id (N,) i32) like ``Detector._parse``.
+    ``rect=True``: the minimal-rectangle letterbox ``predict`` applies to ``.pt`` models (1080p -> 384x640);
+    the network and ``scale_boxes`` then see the rectangle's shape."""
     in_w, in_h = input_size[0], input_size[0]          # only input_size[0] is used (detector.py:102)
-    x = preprocess(frame_bgr, in_h, in_w)
+    x = preprocess(frame_bgr, in_h, in_w, auto=rect)
+    in_h, in_w = x.shape[:2]
     heads = forward(x, weights, scale, nc)
     pred = decode(heads, nc)
     dets, anchors = non_max_suppression(pred, confidence, iou, classes, agnostic_nms, max_det, nc)

@@ -31,7 +31,7 @@ class DetCfg(C.Structure):
     _fields_ = [("weight_path", C.c_char_p), ("in_w", C.c_int32), ("in_h", C.c_int32), ("conf", C.c_float),
                 ("iou", C.c_float), ("classes", C.POINTER(C.c_int32)), ("n_classes", C.c_int32), ("half", C.c_int32),
                 ("device", C.c_int32), ("max_det", C.c_int32), ("agnostic", C.c_int32), ("batch", C.c_int32),
-                ("max_src_w", C.c_int32), ("max_src_h", C.c_int32), ("use_graph", C.c_int32), ("autotune", C.c_int32), ("chains", C.c_int32)]
+                ("max_src_w", C.c_int32), ("max_src_h", C.c_int32), ("use_graph", C.c_int32), ("autotune", C.c_int32), ("chains", C.c_int32), ("rect", C.c_int32)]
 
 
 _lib = None

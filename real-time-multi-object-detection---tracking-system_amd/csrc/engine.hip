@@ -104,9 +104,12 @@ static inline int round_half_even(double v) { return (int)std::nearbyint(v); }  
 
 struct LbHost { int new_w, new_h, top, left, resize; double gain; int pad_x, pad_y; };
 
-static LbHost letterbox_geometry(int h, int w, int in_h, int in_w) {
+// rect: LetterBox(auto=True) -- new_shape is the SQUARE S x S (S = the longer side of the rectangle the
+// engine was built for), the pads are whatever is left of the rectangle (== the square's pads mod 32)
+static LbHost letterbox_geometry(int h, int w, int in_h, int in_w, bool rect = false) {
     LbHost g;
-    double r = std::min((double)in_h / h, (double)in_w / w);
+    const int S = std::max(in_h, in_w);
+    double r = rect ? std::min((double)S / h, (double)S / w) : std::min((double)in_h / h, (double)in_w / w);
     g.new_w = round_half_even(w * r); g.new_h = round_half_even(h * r);
     double dw = (in_w - g.new_w) / 2.0, dh = (in_h - g.new_h) / 2.0;
     g.top = round_half_even(dh - 0.1); g.left = round_half_even(dw - 0.1);
@@ -168,6 +171,7 @@ struct rtmodt_detector {
     hipStream_t stream = nullptr;
     int scale_id = 1, nc = 80, reg_max = 16;
     int B = 1, in_h = 640, in_w = 640, n_anchors = 0;
+    bool rect = false;
     // arena
     char *arena = nullptr;
     size_t arena_bytes = 0;
@@ -864,7 +868,7 @@ static int detector_create_impl(const rtmodt_det_cfg *cfg, rtmodt_detector *d) {
     }
     d->cfg.classes = nullptr;
     d->device = cfg->device;
-    d->B = cfg->batch; d->in_h = cfg->in_h; d->in_w = cfg->in_w;
+    d->B = cfg->batch; d->in_h = cfg->in_h; d->in_w = cfg->in_w; d->rect = cfg->rect != 0;
     RT_CHECK(cfg->half == 1, RTMODT_E_UNSUPPORTED, "half=0: this engine stores activations in fp16 only");
     RT_CHECK(d->B >= 1 && d->B <= 64, RTMODT_E_INVALID, "batch %d out of range [1,64]", d->B);
     RT_CHECK(d->in_h % 32 == 0 && d->in_w % 32 == 0 && d->in_h >= 32 && d->in_w >= 32 && d->in_h <= 1280 && d->in_w <= 1280,
@@ -957,7 +961,8 @@ int rtmodt_detector_enqueue_batch(rtmodt_detector *d, const uint8_t *const *fram
         for (int i = 0; i < n; ++i) d->fptrs.p[i] = frames[i];
     }
     for (int i = n; i < d->B; ++i) d->fptrs.p[i] = d->fptrs.p[0];
-    LbHost g = letterbox_geometry(h, w, d->in_h, d->in_w);
+    LbHost g = letterbox_geometry(h, w, d->in_h, d->in_w, d->rect);
+    RT_CHECK(g.new_w <= d->in_w && g.new_h <= d->in_h, RTMODT_E_INVALID, "a %dx%d frame does not fit the %dx%d rectangle this detector was built for", w, h, d->in_w, d->in_h);
     if (g.resize && (h != d->tab_h || w != d->tab_w)) {
         std::vector<int32_t> xo, x0, x1, yo, y0, y1;
         build_resize_tables(g.new_w, w, xo, x0, x1);

@@ -94,6 +94,7 @@ class Detector:
         autotune: bool = True,
         chains: int = 0,
         warmup: bool = True,
+        rect: bool = False,
     ) -> None:
         self.input_size = input_size
         self.confidence = confidence
@@ -121,19 +122,17 @@ class Detector:
             log.warning("half=False requested: the native engine stores activations in fp16 (fp32 accumulate) regardless")
 
         side = int(input_size[0])                         # detector.py:102 -- only input_size[0] is used
+        self._side = side
+        #: False -> every frame is letterboxed to side x side (what the reference's preferred TensorRT
+        #: ``.engine`` does); True -> the minimal rectangle ``predict`` uses for a ``.pt`` model
+        #: (LetterBox auto=True, 1080p -> 384x640): one native engine per rectangle, built on first use.
+        self.rect = bool(rect)
         msw, msh = (max_source_size if max_source_size else (max(side, 1920), max(side, 1080)))
         cls_arr = None if classes is None else np.ascontiguousarray(classes, dtype=np.int32)
         self._cls_keepalive = cls_arr
-        cfg = _ffi.DetCfg(chosen.encode(), side, side, float(confidence), float(iou),
-                          None if cls_arr is None else cls_arr.ctypes.data_as(C.POINTER(C.c_int32)),
-                          0 if cls_arr is None else len(cls_arr), 1, self._ordinal, int(max_det), int(bool(agnostic_nms)),
-                          self.batch, int(msw), int(msh), int(bool(use_graph)), int(bool(autotune)), int(chains))
-        h = C.c_void_p()
-        _ffi.check(L.rtmodt_detector_create(C.byref(cfg), C.byref(h)))
-        sid, nc, na, ncv = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
-        fl, ar = C.c_int64(), C.c_int64()
-        _ffi.check(L.rtmodt_detector_info(h, C.byref(sid), C.byref(nc), C.byref(na), C.byref(ncv), C.byref(fl), C.byref(ar)))
-        self.model = _NativeModel(h, chosen, sid.value, nc.value, na.value, ncv.value, fl.value, ar.value)
+        self._create_args = (chosen, cls_arr, int(msw), int(msh), int(bool(use_graph)), int(bool(autotune)), int(chains))
+        self._models = {}
+        self.model = self._model_for(side, side)
         self._xyxy = np.empty((self.batch, max_det, 4), np.float32)
         self._conf = np.empty((self.batch, max_det), np.float32)
         self._cls = np.empty((self.batch, max_det), np.int32)
@@ -141,6 +140,33 @@ class Detector:
         self._in_flight = []                              # frame counts of batches enqueued, not yet fetched
         if warmup:
             self._warmup()
+
+    def _model_for(self, in_h: int, in_w: int) -> "_NativeModel":
+        """The native engine for an ``in_h x in_w`` network input (created and cached on first use)."""
+        m = self._models.get((in_h, in_w))
+        if m is None:
+            chosen, cls_arr, msw, msh, use_graph, autotune, chains = self._create_args
+            cfg = _ffi.DetCfg(chosen.encode(), in_w, in_h, float(self.confidence), float(self.iou),
+                              None if cls_arr is None else cls_arr.ctypes.data_as(C.POINTER(C.c_int32)),
+                              0 if cls_arr is None else len(cls_arr), 1, self._ordinal, int(self.max_det),
+                              int(bool(self.agnostic_nms)), self.batch, msw, msh, use_graph, autotune, chains, int(self.rect))
+            L = _ffi.lib()
+            h = C.c_void_p()
+            _ffi.check(L.rtmodt_detector_create(C.byref(cfg), C.byref(h)))
+            sid, nc, na, ncv = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+            fl, ar = C.c_int64(), C.c_int64()
+            _ffi.check(L.rtmodt_detector_info(h, C.byref(sid), C.byref(nc), C.byref(na), C.byref(ncv), C.byref(fl), C.byref(ar)))
+            m = _NativeModel(h, chosen, sid.value, nc.value, na.value, ncv.value, fl.value, ar.value)
+            m.input_hw = (in_h, in_w)
+            self._models[(in_h, in_w)] = m
+        return m
+
+    @staticmethod
+    def rect_shape(h: int, w: int, imgsz: int, stride: int = 32) -> tuple:
+        """Network input (H, W) that ultralytics' ``LetterBox(auto=True)`` produces for an ``h x w`` frame."""
+        r = min(imgsz / h, imgsz / w)
+        nw, nh = int(round(w * r)), int(round(h * r))
+        return nh + (imgsz - nh) % stride, nw + (imgsz - nw) % stride
 
     # ------------------------------------------------------------------
     def detect(self, frame: np.ndarray) -> Detections:
@@ -175,6 +201,12 @@ class Detector:
                     raise ValueError("frames of one batch must share one H x W x 3 shape")
                 arr[i] = a.ctypes.data
             self._frames_keepalive = keep
+        if self.rect:
+            want = self.rect_shape(int(h), int(w), self._side)
+            if want != self.model.input_hw:
+                if self._in_flight:                       # they live in the other rectangle's engine
+                    raise RuntimeError("fetch() the pending results before enqueueing frames of another size")
+                self.model = self._model_for(*want)
         _ffi.check(_ffi.lib().rtmodt_detector_enqueue_batch(self.model.handle, arr, n, int(h), int(w), int(p), kind))
         self._in_flight.append(n)
 
@@ -191,10 +223,11 @@ class Detector:
         _ffi.check(_ffi.lib().rtmodt_synchronize(self._ordinal))
 
     def close(self) -> None:
-        m = getattr(self, "model", None)
-        if m is not None and m.handle:
-            _ffi.lib().rtmodt_detector_destroy(m.handle)
-            m.handle = None
+        for m in getattr(self, "_models", {}).values():
+            if m.handle:
+                _ffi.lib().rtmodt_detector_destroy(m.handle)
+                m.handle = None
+        self._models = {}
 
     def __del__(self):
         try:
@@ -219,8 +252,8 @@ class Detector:
     # ---- introspection for parity tests / bench (no reference counterpart) -------------
     def debug_fetch(self, img: int = 0, want_input=True, want_heads=True, want_pred=True):
         m = self.model
-        side = int(self.input_size[0])
-        inp = np.empty((side, side, 3), np.float16) if want_input else None
+        ih, iw = m.input_hw
+        inp = np.empty((ih, iw, 3), np.float16) if want_input else None
         heads = np.empty(m.n_anchors * (64 + m.nc), np.float16) if want_heads else None
         pred = np.empty((4 + m.nc, m.n_anchors), np.float32) if want_pred else None
         _ffi.check(_ffi.lib().rtmodt_detector_debug_fetch(m.handle, img, _ffi.ptr(inp), _ffi.ptr(heads), _ffi.ptr(pred)))

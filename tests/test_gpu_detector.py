@@ -385,3 +385,31 @@ def test_pipeline_loop_and_stage_profiler(pkg, wdir):
         orc.update(d.xyxy, d.confidence, d.class_id)
     assert np.array_equal(T.state_digest(trk._core.snapshot()), T.state_digest(orc.snapshot()))
     det.close()
+
+
+# ------------------------------------------------------------------ rect (LetterBox auto=True) mode
+@pytest.mark.parametrize("h,w,shape", [(1080, 1920, (384, 640)), (480, 640, (480, 640)), (720, 405, (640, 384)), (333, 500, (448, 640))])
+def test_rect_letterbox_mode(pkg, wdir, h, w, shape):
+    """`predict` on a .pt model letterboxes to the minimal stride-32 rectangle; Detector(rect=True) builds
+    one engine per rectangle.  Input image bit-exact vs the oracle's auto=True letterbox, detections vs the
+    oracle run on the engine's own head maps (identical NMS survivors), boxes mapped back with the
+    rectangle's gain/pad."""
+    det, wts = make_detector(pkg, wdir, "n", 640, rect=True, autotune=False)
+    assert det.rect_shape(h, w, 640) == shape
+    frame = next(iter(pkg.synth.structured_frames(1, h, w, seed=9)))
+    got = det.detect(frame)
+    assert det.model.input_hw == shape
+    inp, heads, pred = det.debug_fetch(0)
+    want = Y.preprocess(frame, 640, 640, auto=True)
+    assert want.shape[:2] == shape
+    assert np.array_equal(inp.astype(np.float32), want.astype(np.float16).astype(np.float32))
+    dets, anchors = Y.non_max_suppression(pred, det.confidence, det.iou, None, False, det.max_det, 80)
+    xyxy = Y.scale_boxes(dets[:, :4], shape[0], shape[1], h, w) if len(dets) else np.empty((0, 4), np.float32)
+    assert len(got) == len(dets)
+    assert np.array_equal(got.class_id, dets[:, 5].astype(np.int32))
+    assert np.array_equal(got.confidence, dets[:, 4].astype(np.float32))
+    assert np.abs(got.xyxy - xyxy).max(initial=0) <= 1e-3
+    # a second frame size switches engines; the square engine from __init__ is still cached
+    det.detect(np.zeros((640, 640, 3), np.uint8))
+    assert det.model.input_hw == (640, 640) and len(det._models) == (1 if shape == (640, 640) else 2)
+    det.close()
