@@ -39,6 +39,7 @@ extern "C" {
 
 typedef struct rtmodt_detector rtmodt_detector;
 typedef struct rtmodt_tracker rtmodt_tracker;
+typedef struct rtmodt_zones rtmodt_zones;
 
 /* ---- library / device ------------------------------------------------------------- */
 const char *rtmodt_last_error(void);
@@ -167,6 +168,46 @@ int rtmodt_assign_greedy(int device, const float *iou, int m, int n, float thres
  * are contested (share a row or column with another candidate pair). */
 int rtmodt_assign_lapjv(int device, const float *iou, int m, int n, double cost_limit, int32_t *row_to_col,
                         int32_t *col_used);
+
+/* ---- zone events: replaces ZoneEventEngine.process (src/events/zone_engine.py:82-132) -------- */
+/* One polygon zone (zone_engine.py:50-58, :142-151).  `key` = index of the FIRST zone carrying the
+ * same name: the reference keys its occupancy and cooldown dicts by zone name (:98-100, :105), so
+ * same-named zones share their timers; distinct names -> key == own index. */
+typedef struct rtmodt_zone_cfg {
+    const int32_t *polygon_xy;  /* n_points x (x, y), int32 like np.array(cfg["polygon"], dtype=np.int32) (:143) */
+    int32_t n_points;
+    double dwell_time_sec;      /* default 2.0  (:147) */
+    double cooldown_sec;        /* default 10.0 (:148) */
+    int32_t key;
+} rtmodt_zone_cfg;
+/* n_streams independent ledgers (occupancy + cooldown per track id and zone), at most 32 zones /
+ * 2048 polygon points.  max_idle_frames: a track id not passed for more than this many frames loses
+ * its cooldown entries (the reference never drops them, zone_engine.py:76; pass INT64_MAX/2 to
+ * mirror that until the 2 x max_tracks ledger fills -> RTMODT_E_CAPACITY). */
+int rtmodt_zones_create(int device, const rtmodt_zone_cfg *zones, int n_zones, int n_streams, int max_tracks,
+                        int max_events, int64_t max_idle_frames, rtmodt_zones **out);
+void rtmodt_zones_destroy(rtmodt_zones *z);
+/* process(tracks, frame_id) for one stream on a caller-supplied track list (any order, unique ids);
+ * `now` = the reference's time.time() (:84).  Events come back in the reference's order (track
+ * order, then zone order): ev_track = index into the caller's list, ev_zone = zone index,
+ * ev_dwell = now - first_seen (the reference rounds it to 2 decimals when it builds the record,
+ * :113), ev_centroid[2] = int((x1+x2)/2), int((y1+y2)/2) (:91-92).  Outputs sized max_events. */
+int rtmodt_zones_process(rtmodt_zones *z, int stream, const int64_t *track_ids, const float *xyxy,
+                         const int32_t *cls, int n, double now, int64_t frame_id, int32_t *ev_track,
+                         int32_t *ev_zone, double *ev_dwell, int32_t *ev_centroid, int32_t *n_events);
+/* The same for every stream of `trk` at once, straight on its device-resident state and on the
+ * HIP stream its last update ran on (no host round trip for the tracks).  The tracks "passed" are
+ * those with time_since_update == report_tsu after the update (1 = matched or spawned this frame;
+ * 0 = what the reference's tracker returns, i.e. none -- SURVEY finding 4).  Outputs are
+ * [n_streams][max_events] (+ [4] / [2] for xyxy / centroid), n_events[n_streams]. */
+int rtmodt_zones_process_tracker(rtmodt_zones *z, rtmodt_tracker *trk, double now, int64_t frame_id,
+                                 int report_tsu, int64_t *ev_track_id, int32_t *ev_zone, double *ev_dwell,
+                                 float *ev_xyxy, int32_t *ev_centroid, int32_t *ev_cls, int32_t *n_events);
+/* Ledger snapshot of one stream, rows in ascending track id (= _occupancy and _cooldown, :74-76):
+ * occ_mask bit k <=> zone key k is in _occupancy[track]; first_seen / last_alert are
+ * [rows][n_zones] indexed by key (last_alert 0.0 = no entry).  Arrays sized 2 x max_tracks rows. */
+int rtmodt_zones_state(rtmodt_zones *z, int stream, int64_t *ids, uint32_t *occ_mask, double *first_seen,
+                       double *last_alert, int32_t *n);
 
 #ifdef __cplusplus
 }

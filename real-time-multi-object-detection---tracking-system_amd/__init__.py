@@ -15,6 +15,7 @@ library being built):
 * ``synth``              -- deterministic synthetic frames / box sequences
 * ``streams``            -- stream sharding across GPUs + barrier / max-time / stats reduce (RCCL or gloo)
 * ``profiling``          -- ``LatencyProfiler`` (reference: src/profiling/latency_profiler.py:35-143)
+* ``events``             -- ``ZoneEventEngine`` on device-resident tracks (reference: src/events/zone_engine.py:64-157)
 * ``pipeline``           -- the reference's per-frame loop (tools/run_pipeline.py:121-158) around the native classes
 """
 import importlib as _importlib
@@ -26,6 +27,7 @@ _LAZY = {
     "Detections": ".detection.detector",
     "MultiObjectTracker": ".tracking.tracker",
     "Track": ".tracking.tracker",
+    "ZoneEventEngine": ".events.zone_engine",
 }
 
 
@@ -33,6 +35,6 @@ def __getattr__(name):
     if name in _LAZY:
         mod = _importlib.import_module(_LAZY[name], __name__)
         return getattr(mod, name)
-    if name in ("synth", "weights", "_ffi", "detection", "tracking", "yolo_spec", "streams", "profiling", "pipeline"):
+    if name in ("synth", "weights", "_ffi", "detection", "tracking", "yolo_spec", "streams", "profiling", "pipeline", "events"):
         return _importlib.import_module("." + name, __name__)
     raise AttributeError(name)

@@ -34,6 +34,11 @@ class DetCfg(C.Structure):
                 ("max_src_w", C.c_int32), ("max_src_h", C.c_int32), ("use_graph", C.c_int32), ("autotune", C.c_int32), ("chains", C.c_int32), ("rect", C.c_int32)]
 
 
+class ZoneCfg(C.Structure):                          # struct rtmodt_zone_cfg
+    _fields_ = [("polygon_xy", C.POINTER(C.c_int32)), ("n_points", C.c_int32), ("dwell_time_sec", C.c_double),
+                ("cooldown_sec", C.c_double), ("key", C.c_int32)]
+
+
 _lib = None
 
 
@@ -90,6 +95,11 @@ def lib() -> C.CDLL:
         "rtmodt_iou_matrix": (C.c_int, [C.c_int, vp, C.c_int, vp, C.c_int, vp]),
         "rtmodt_assign_greedy": (C.c_int, [C.c_int, vp, C.c_int, C.c_int, f32, vp, vp]),
         "rtmodt_assign_lapjv": (C.c_int, [C.c_int, vp, C.c_int, C.c_int, C.c_double, vp, vp]),
+        "rtmodt_zones_create": (C.c_int, [C.c_int, C.POINTER(ZoneCfg), C.c_int, C.c_int, C.c_int, C.c_int, i64, C.POINTER(vp)]),
+        "rtmodt_zones_destroy": (None, [vp]),
+        "rtmodt_zones_process": (C.c_int, [vp, C.c_int, vp, vp, vp, C.c_int, C.c_double, i64, vp, vp, vp, vp, C.POINTER(i32)]),
+        "rtmodt_zones_process_tracker": (C.c_int, [vp, vp, C.c_double, i64, C.c_int, vp, vp, vp, vp, vp, vp, vp]),
+        "rtmodt_zones_state": (C.c_int, [vp, C.c_int, vp, vp, vp, vp, C.POINTER(i32)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)          # AttributeError here == header/library drift

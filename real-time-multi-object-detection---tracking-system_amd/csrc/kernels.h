@@ -144,6 +144,12 @@ int launch_assign_greedy(const float *iou, int m, int n, float thresh, int32_t *
 int launch_assign_lapjv(const float *iou, int m, int n, double cost_limit, int32_t *row_to_col, int32_t *col_used, int32_t *err,
                         hipStream_t s);
 
+// the tracker's device-resident state (tracker_api.hip), consumed by the zone engine (zones.hip):
+// states[n_streams], meta[n_streams][8] = {cur, n_tracks, err, n_active, next_id, ...}; `stream` is the HIP stream
+// the tracker's most recent update was launched on
+struct TrackerDeviceView { const TrackerState *states; const int64_t *meta; int n_streams, max_tracks, device; hipStream_t stream; };
+int tracker_device_view(rtmodt_tracker *trk, TrackerDeviceView *out);
+
 // device-resident results of a detector's last enqueue_batch (engine.hip), consumed by the tracker
 struct DetOutputs { const float4 *box; const float *conf; const int32_t *cls; const int32_t *n; int stride, count, device; hipStream_t stream; };
 int detector_outputs(rtmodt_detector *det, DetOutputs *out);

@@ -12,6 +12,7 @@ using namespace rtmodt;
 struct rtmodt_tracker {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t last_stream = nullptr;    // where the most recent update ran (own stream, or the detector's)
     int S = 1, Mc = 0, Nc = 0;
     float track_thresh = 0.5f, match_thresh = 0.8f;
     int track_buffer = 30;
@@ -30,6 +31,14 @@ struct rtmodt_tracker {
 
 static int64_t init_meta_row[8] = {0, 0, 0, 0, 1, 0, 0, 0};   // cur, n_tracks, err, n_active, next_id (tracker.py:55)
 
+namespace rtmodt {
+int tracker_device_view(rtmodt_tracker *t, TrackerDeviceView *out) {
+    RT_CHECK(t && out, RTMODT_E_INVALID, "null argument");
+    *out = TrackerDeviceView{t->d_states, t->d_meta, t->S, t->Mc, t->device, t->last_stream};
+    return RTMODT_OK;
+}
+}  // namespace rtmodt
+
 extern "C" {
 
 void rtmodt_tracker_destroy(rtmodt_tracker *t) {
@@ -46,6 +55,7 @@ void rtmodt_tracker_destroy(rtmodt_tracker *t) {
 static int tracker_create_impl(rtmodt_tracker *t) {
     RT_HIP(hipSetDevice(t->device));
     RT_HIP(hipStreamCreateWithFlags(&t->stream, hipStreamNonBlocking));
+    t->last_stream = t->stream;
     const size_t per_buf = (size_t)t->Mc * (8 + 16 + 4 + 4 + 4 + 4);
     const size_t total = per_buf * 2 * t->S;
     RT_HIP(hipMalloc((void **)&t->pool, total));
@@ -149,6 +159,7 @@ int rtmodt_tracker_update(rtmodt_tracker *t, int stream, const float *xyxy, cons
     TrackerArgs a = make_args(t);
     a.n_streams = 1; a.stream_base = stream;
     RT_TRY(launch_tracker_update(a, t->stream));
+    t->last_stream = t->stream;
     return finish(t, stream, 1, n_active_out);
 }
 
@@ -165,6 +176,7 @@ int rtmodt_tracker_update_batch(rtmodt_tracker *t, const float *xyxy, const floa
     RT_HIP(hipMemcpyAsync(t->d_cls, cls, (size_t)t->S * t->Nc * 4, hipMemcpyHostToDevice, t->stream));
     RT_HIP(hipMemcpyAsync(t->d_n, t->h_n, (size_t)t->S * 4, hipMemcpyHostToDevice, t->stream));
     RT_TRY(launch_tracker_update(make_args(t), t->stream));
+    t->last_stream = t->stream;
     return finish(t, 0, t->S, n_active_out);
 }
 
@@ -179,6 +191,7 @@ int rtmodt_tracker_update_from_detector(rtmodt_tracker *t, rtmodt_detector *det)
     TrackerArgs a = make_args(t);
     a.n_streams = o.count;
     a.det_box = o.box; a.det_conf = o.conf; a.det_cls = o.cls; a.det_n = o.n; a.det_stride = o.stride;
+    t->last_stream = o.stream;
     return launch_tracker_update(a, o.stream);          // same HIP stream as the detector: ordered, no host sync
 }
 

@@ -33,11 +33,12 @@ class SyntheticSource:
 
 
 def run(source, detector, tracker, profiler: Optional[LatencyProfiler] = None, max_frames: int = 200,
-        device_stages: bool = True) -> dict:
+        device_stages: bool = True, event_engine=None) -> dict:
     """Runs ``max_frames`` iterations of the reference loop; returns ``profiler.summary(p50=True)``
     plus the last frame's detections and tracks."""
     profiler = profiler or LatencyProfiler(gpu_sync=True, warmup_frames=50, log_interval=100)
     detections = tracks = None
+    n_events = 0
     for _ in range(max_frames):
         profiler.tick("decode")
         ok, frame, fid = source.read()
@@ -57,9 +58,14 @@ def run(source, detector, tracker, profiler: Optional[LatencyProfiler] = None, m
         profiler.tick("tracking")
         tracks = tracker.update(detections)
         profiler.tock("tracking")
+        if event_engine is not None:                       # tools/run_pipeline.py:141-146
+            profiler.tick("events")
+            n_events += len(event_engine.process(tracks, fid))
+            profiler.tock("events")
         profiler.end_frame()
     out = profiler.summary(p50=True)
     out["frames"] = max_frames
     out["last_detections"] = 0 if detections is None else len(detections)
     out["last_tracks"] = 0 if tracks is None else len(tracks)
+    out["events"] = n_events
     return out
