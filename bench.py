@@ -48,7 +48,8 @@ def parse():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend: nccl (= RCCL, default) or gloo (rehearsal on a 1-GPU box)")
     ap.add_argument("--one-device", action="store_true", help="rehearsal only: every rank uses cuda:0")
-    ap.add_argument("--host-frames", action="store_true", help="feed host (pageable) frames: PCIe-inclusive rate, never the headline value")
+    ap.add_argument("--host-frames", action="store_true", help="feed frames from (page-locked) host memory: PCIe-inclusive rate, never the headline value")
+    ap.add_argument("--pageable", action="store_true", help="with --host-frames: ordinary pageable NumPy frames instead of the pinned ring")
     return ap.parse_args()
 
 
@@ -130,6 +131,9 @@ def main():
     host_ring = None
     if args.host_frames:
         host_ring = [[pkg.synth.frames(1, size, size, seed=1234 + gid + 1000 * r)[0] for gid in my_streams] for r in range(4)]
+        if not args.pageable:                           # what a capture thread would write into: page-locked ring slots
+            pinned = pkg.pipeline.PinnedFrameRing(4 * S, size, size, device=dev)
+            host_ring = [[pinned.write(r * S + s, host_ring[r][s]) for s in range(S)] for r in range(4)]
 
     def submit(t):
         if host_ring is not None:
@@ -204,7 +208,7 @@ def main():
                      "flops_per_step": int(flops_step), "forward_ms_per_step": round(fwd_ms_step, 4),
                      "device_ms_per_step": round(tot_ms / args.steps, 4)},
         "detections_per_frame": round(n_det / frames_total, 2), "live_tracks_node": n_tracks_node,
-        "frames_source": "host memory (PCIe-inclusive, NOT the headline metric)" if args.host_frames else "HBM-resident ring",
+        "frames_source": ("pageable" if args.pageable else "page-locked") + " host memory (PCIe-inclusive, NOT the headline metric)" if args.host_frames else "HBM-resident ring",
     }
 
     tpath = os.path.join(ROOT, "profiles", "traffic_current.json")

@@ -48,6 +48,12 @@ int rtmodt_device_count(int *count);
 int rtmodt_synchronize(int device);                 /* replaces torch.cuda.synchronize() (latency_profiler.py:63,69) */
 int rtmodt_device_alloc(int device, size_t bytes, void **out);
 int rtmodt_device_free(int device, void *ptr);
+/* Page-locked host memory for the frame source (the ring RTSPReader.read() copies out of,
+ * src/ingestion/rtsp_reader.py:74-79): enqueue_batch copies host frames on its own HIP stream into a
+ * per-slot staging area, so frames that live in such memory upload underneath the previous
+ * batch's forward pass; pageable frames still work but their copy blocks the calling thread. */
+int rtmodt_host_alloc(int device, size_t bytes, void **out);
+int rtmodt_host_free(int device, void *ptr);
 int rtmodt_memcpy_h2d(int device, void *dst_device, const void *src_host, size_t bytes);
 int rtmodt_memcpy_d2h(int device, void *dst_host, const void *src_device, size_t bytes);
 

@@ -65,6 +65,8 @@ def lib() -> C.CDLL:
         "rtmodt_synchronize": (C.c_int, [C.c_int]),
         "rtmodt_device_alloc": (C.c_int, [C.c_int, C.c_size_t, C.POINTER(vp)]),
         "rtmodt_device_free": (C.c_int, [C.c_int, vp]),
+        "rtmodt_host_alloc": (C.c_int, [C.c_int, C.c_size_t, C.POINTER(vp)]),
+        "rtmodt_host_free": (C.c_int, [C.c_int, vp]),
         "rtmodt_memcpy_h2d": (C.c_int, [C.c_int, vp, vp, C.c_size_t]),
         "rtmodt_memcpy_d2h": (C.c_int, [C.c_int, vp, vp, C.c_size_t]),
         "rtmodt_detector_create": (C.c_int, [C.POINTER(DetCfg), C.POINTER(vp)]),
@@ -201,6 +203,32 @@ class DeviceBuffer:
     def free(self):
         if self.ptr:
             lib().rtmodt_device_free(self.device, C.c_void_p(self.ptr))
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class PinnedArray:
+    """A NumPy view over page-locked host memory owned by the library: frames written here (by a decoder,
+    a capture thread, ...) reach the GPU by asynchronous DMA underneath the previous batch's compute."""
+
+    def __init__(self, shape, dtype=np.uint8, device: int = 0):
+        self.device = device
+        self.nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        p = C.c_void_p()
+        check(lib().rtmodt_host_alloc(device, max(self.nbytes, 1), C.byref(p)))
+        self.ptr = p.value
+        buf = (C.c_uint8 * self.nbytes).from_address(self.ptr)
+        self.array = np.frombuffer(buf, dtype=dtype).reshape(shape)
+
+    def free(self):
+        if self.ptr:
+            self.array = None
+            lib().rtmodt_host_free(self.device, C.c_void_p(self.ptr))
             self.ptr = None
 
     def __del__(self):

@@ -192,7 +192,10 @@ struct rtmodt_detector {
     int head_t[3] = {-1, -1, -1};
     int64_t flops_per_frame = 0;
     // frames
-    uint8_t *stage = nullptr; size_t stage_per = 0;
+    // host frames land in a per-ring-slot staging area through their own copy stream: the H2D of batch
+    // t+1 runs under the forward pass of batch t when the caller's frames are in pinned memory
+    uint8_t *stage = nullptr; size_t stage_per = 0;      // [RING_SLOTS][B][stage_per]
+    hipStream_t copy_stream = nullptr;
     FramePtrs fptrs{};
     int tab_h = -1, tab_w = -1;
     int32_t *d_tab = nullptr; size_t tab_cap = 0;
@@ -211,6 +214,8 @@ struct rtmodt_detector {
         float *o_xyxy = nullptr, *o_conf = nullptr; int32_t *o_cls = nullptr, *o_anchor = nullptr, *o_n = nullptr;   // device
         float *h_xyxy = nullptr, *h_conf = nullptr; int32_t *h_cls = nullptr, *h_n = nullptr;                        // pinned host
         hipEvent_t ev0 = nullptr, evp = nullptr, ev1 = nullptr, ev2 = nullptr, done = nullptr, decoded = nullptr;   // evp: letterbox done
+        hipEvent_t copied = nullptr;       // this slot's frames have arrived in its staging area
+        bool staged = false;               // the staging area has been read by a letterbox launch (evp is meaningful)
         int n = 0;
     };
     static constexpr int RING_SLOTS = 2;
@@ -814,6 +819,18 @@ int rtmodt_device_alloc(int device, size_t bytes, void **out) {
     RT_HIP(hipMalloc(out, bytes));
     return RTMODT_OK;
 }
+// page-locked host memory for the frame source: an H2D copy from it is a real asynchronous DMA
+int rtmodt_host_alloc(int device, size_t bytes, void **out) {
+    RT_CHECK(out && bytes > 0, RTMODT_E_INVALID, "bad argument");
+    RT_HIP(hipSetDevice(device));
+    RT_HIP(hipHostMalloc(out, bytes, hipHostMallocDefault));
+    return RTMODT_OK;
+}
+int rtmodt_host_free(int device, void *ptr) {
+    RT_HIP(hipSetDevice(device));
+    RT_HIP(hipHostFree(ptr));
+    return RTMODT_OK;
+}
 int rtmodt_device_free(int device, void *ptr) {
     RT_HIP(hipSetDevice(device));
     RT_HIP(hipFree(ptr));
@@ -841,6 +858,7 @@ void rtmodt_detector_destroy(rtmodt_detector *d) {
     for (auto e : d->chain_fork) hipEventDestroy(e);
     for (auto e : d->chain_join) hipEventDestroy(e);
     if (d->post_stream) hipStreamDestroy(d->post_stream);
+    if (d->copy_stream) hipStreamDestroy(d->copy_stream);
     for (auto st : d->aux_streams) hipStreamDestroy(st);
     for (auto e : d->aux_events) hipEventDestroy(e);
     for (void *p : d->dev_allocs) hipFree(p);
@@ -850,7 +868,7 @@ void rtmodt_detector_destroy(rtmodt_detector *d) {
     for (auto &sl : d->slots) {
         hipFree(sl.o_xyxy); hipFree(sl.o_conf); hipFree(sl.o_cls); hipFree(sl.o_anchor); hipFree(sl.o_n);
         hipHostFree(sl.h_xyxy); hipHostFree(sl.h_conf); hipHostFree(sl.h_cls); hipHostFree(sl.h_n);
-        for (hipEvent_t e : {sl.ev0, sl.evp, sl.ev1, sl.ev2, sl.done, sl.decoded}) if (e) hipEventDestroy(e);
+        for (hipEvent_t e : {sl.ev0, sl.evp, sl.ev1, sl.ev2, sl.done, sl.decoded, sl.copied}) if (e) hipEventDestroy(e);
     }
     if (d->stream) hipStreamDestroy(d->stream);
     delete d;
@@ -888,7 +906,8 @@ static int detector_create_impl(const rtmodt_det_cfg *cfg, rtmodt_detector *d) {
     int msw = cfg->max_src_w > 0 ? cfg->max_src_w : d->in_w, msh = cfg->max_src_h > 0 ? cfg->max_src_h : d->in_h;
     d->cfg.max_src_w = msw; d->cfg.max_src_h = msh;
     d->stage_per = align_up((size_t)msw * msh * 3 + 64, 256);
-    RT_HIP(hipMalloc((void **)&d->stage, d->stage_per * d->B));
+    RT_HIP(hipMalloc((void **)&d->stage, d->stage_per * d->B * rtmodt_detector::RING_SLOTS));
+    RT_HIP(hipStreamCreateWithFlags(&d->copy_stream, hipStreamNonBlocking));
     d->tab_cap = (size_t)(d->in_w + d->in_h) * 3;
     RT_HIP(hipMalloc((void **)&d->d_tab, d->tab_cap * sizeof(int32_t)));
 
@@ -916,6 +935,7 @@ static int detector_create_impl(const rtmodt_det_cfg *cfg, rtmodt_detector *d) {
         RT_HIP(hipEventCreate(&sl.ev0)); RT_HIP(hipEventCreate(&sl.evp)); RT_HIP(hipEventCreate(&sl.ev1)); RT_HIP(hipEventCreate(&sl.ev2));
         RT_HIP(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
         RT_HIP(hipEventCreateWithFlags(&sl.decoded, hipEventDisableTiming));
+        RT_HIP(hipEventCreateWithFlags(&sl.copied, hipEventDisableTiming));
     }
 
     // one eager pass (also sets kernel attributes) before capturing the graph
@@ -953,10 +973,15 @@ int rtmodt_detector_enqueue_batch(rtmodt_detector *d, const uint8_t *const *fram
     if (mem_kind == RTMODT_MEM_HOST) {
         RT_CHECK((size_t)h * stride_bytes <= d->stage_per, RTMODT_E_CAPACITY, "frame %dx%d exceeds max_src %dx%d", w, h, d->cfg.max_src_w,
                  d->cfg.max_src_h);
+        uint8_t *area = d->stage + d->stage_per * d->B * d->head;
+        if (sl.staged) RT_HIP(hipStreamWaitEvent(d->copy_stream, sl.evp, 0));    // the letterbox that last read this area is done
         for (int i = 0; i < n; ++i) {
-            RT_HIP(hipMemcpyAsync(d->stage + d->stage_per * i, frames[i], (size_t)h * stride_bytes, hipMemcpyHostToDevice, d->stream));
-            d->fptrs.p[i] = d->stage + d->stage_per * i;
+            RT_HIP(hipMemcpyAsync(area + d->stage_per * i, frames[i], (size_t)h * stride_bytes, hipMemcpyHostToDevice, d->copy_stream));
+            d->fptrs.p[i] = area + d->stage_per * i;
         }
+        RT_HIP(hipEventRecord(sl.copied, d->copy_stream));
+        RT_HIP(hipStreamWaitEvent(d->stream, sl.copied, 0));
+        sl.staged = true;
     } else {
         for (int i = 0; i < n; ++i) d->fptrs.p[i] = frames[i];
     }

@@ -32,6 +32,28 @@ class SyntheticSource:
         return True, f, self._i
 
 
+class PinnedFrameRing:
+    """The frame ring between a decoder and the detector: ``slots`` page-locked H x W x 3
+    uint8 images.  ``write(i, frame)`` is what a capture thread does with a decoded frame; ``frame(i)`` is the
+    view handed to ``Detector.enqueue`` -- its upload is then a true asynchronous DMA on the engine's copy stream."""
+
+    def __init__(self, slots: int, height: int, width: int, device=0):
+        from . import _ffi
+        self._mem = _ffi.PinnedArray((slots, height, width, 3), np.uint8, _ffi.device_ordinal(device))
+        self.slots = slots
+
+    def write(self, i: int, frame: np.ndarray) -> np.ndarray:
+        dst = self._mem.array[i % self.slots]
+        np.copyto(dst, frame)
+        return dst
+
+    def frame(self, i: int) -> np.ndarray:
+        return self._mem.array[i % self.slots]
+
+    def close(self) -> None:
+        self._mem.free()
+
+
 def run(source, detector, tracker, profiler: Optional[LatencyProfiler] = None, max_frames: int = 200,
         device_stages: bool = True, event_engine=None) -> dict:
     """Runs ``max_frames`` iterations of the reference loop; returns ``profiler.summary(p50=True)``
