@@ -870,10 +870,38 @@ int launch_conv(const ConvLaunch &c, hipStream_t s) { return launch_conv_group(&
 // pixels (2ox + 2(q&1), +1) of input row 2oy + 2kk + (q>>1): 16 contiguous bytes.
 // One wave owns 16 consecutive output pixels of a row per iteration; weights live in VGPRs.
 // ---------------------------------------------------------------------------------------
+
+// Stem epilogue: the 16 pixels x 16 NT channels a wave just computed are one contiguous run of the NHWC
+// output (the stem's output tensor has exactly 16 NT channels per pixel), so they leave as ONE 16-byte
+// store per lane (whole cache lines) after a transpose through a padded LDS tile, instead of NT
+// 8-byte stores with 32-byte segments.  `tile`: this wave's 16 x (32 NT + 8) bytes.
+template <int NT>
+__device__ __forceinline__ void stem_store(unsigned char *tile, const floatx4 *acc, f16 *__restrict__ orow, int lane) {
+    constexpr int ROW = 32 * NT + 8;                       // bytes per pixel in LDS (+8: conflict-free b64 writes)
+    const int p = lane & 15, q = lane >> 4;
+#pragma unroll
+    for (int u = 0; u < NT; ++u) {
+        half4 h = {(f16)silu_f(acc[u][0]), (f16)silu_f(acc[u][1]), (f16)silu_f(acc[u][2]), (f16)silu_f(acc[u][3])};
+        *(half4 *)(tile + p * ROW + u * 32 + q * 8) = h;
+    }
+    __builtin_amdgcn_wave_barrier();
+    constexpr int CH16 = 2 * NT;                           // 16-byte chunks per pixel
+#pragma unroll
+    for (int i = 0; i < (16 * CH16 + 63) / 64; ++i) {
+        const int idx = i * 64 + lane;
+        if (16 * CH16 % 64 == 0 || idx < 16 * CH16) {
+            const int px = idx / CH16, c = idx - px * CH16;
+            *(half8 *)(orow + px * (16 * NT) + c * 8) = *(const half8 *)(tile + px * ROW + c * 16);
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
 template <int NT>
 __global__ __launch_bounds__(256) void stem_mfma(const f16 *__restrict__ img, int Hp, int Wp, f16 *__restrict__ out, int Ho, int Wo,
                                                  int oHp, int oWp, int ocs, int opad, const f16 *__restrict__ wm,
                                                  const float *__restrict__ bias, int groups) {
+    __shared__ __attribute__((aligned(16))) unsigned char otile[4 * 16 * (32 * NT + 8)];
     const int lane = threadIdx.x & 63;
     const int p = lane & 15, q = lane >> 4;
     half8 wf[NT][2];
@@ -895,13 +923,21 @@ __global__ __launch_bounds__(256) void stem_mfma(const f16 *__restrict__ img, in
         const f16 *base = img + ((long)(b * Hp + 2 * oy) * Wp + 2 * ox + 2 * (q & 1)) * 4;
         half8 a0 = *(const half8 *)(base + (long)kh0 * Wp * 4);
         half8 a1 = *(const half8 *)(base + (long)kh1 * Wp * 4);
-        f16 *o = out + ((long)(b * oHp + oy + opad) * oWp + ox + opad) * ocs + q * 4;
+        floatx4 acc[NT];
 #pragma unroll
         for (int u = 0; u < NT; ++u) {
-            floatx4 acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[u][0], a0, bv[u], 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[u][1], a1, acc, 0, 0, 0);
-            half4 h = {(f16)silu_f(acc[0]), (f16)silu_f(acc[1]), (f16)silu_f(acc[2]), (f16)silu_f(acc[3])};
-            *(half4 *)(o + u * 16) = h;
+            acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[u][0], a0, bv[u], 0, 0, 0);
+            acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[u][1], a1, acc[u], 0, 0, 0);
+        }
+        if (ocs == 16 * NT) {
+            stem_store<NT>(otile + (threadIdx.x >> 6) * (16 * (32 * NT + 8)), acc, out + ((long)(b * oHp + oy + opad) * oWp + gx * 16 + opad) * ocs, lane);
+        } else {
+            f16 *o = out + ((long)(b * oHp + oy + opad) * oWp + ox + opad) * ocs + q * 4;
+#pragma unroll
+            for (int u = 0; u < NT; ++u) {
+                half4 h = {(f16)silu_f(acc[u][0]), (f16)silu_f(acc[u][1]), (f16)silu_f(acc[u][2]), (f16)silu_f(acc[u][3])};
+                *(half4 *)(o + u * 16) = h;
+            }
         }
     }
 }
@@ -931,6 +967,142 @@ int launch_stem(const TensorView &img4, const TensorView &out, const f16 *wm, co
 // SPPF pools.  MaxPool(5,1,2) chained three times == windows 5 / 9 / 13 clipped to the image
 // (-inf padding).  One workgroup per (image, 8-channel chunk): the HxW x 8ch tile sits in
 // LDS, row maxima for the three radii are formed once, then column maxima.
+
+// ---------------------------------------------------------------------------------------
+// stem_fused: letterbox + BGR->RGB + /255 + .half() (preprocess.hip) folded into the stem conv for
+// frames that need no resize (source size == letterboxed size; pads allowed).  One workgroup owns
+// one output row: the three letterboxed input rows it needs are assembled in LDS as BGR bytes --
+// source bytes fetched with coalesced aligned dword pairs and byte-shifted into place, 114 where the
+// canvas has no image -- and every MFMA fragment (two adjacent input pixels of one row) is then six
+// LDS byte reads through a 256-entry fp16 table of c/255 (built on the host with IEEE division, so the
+// values equal the letterbox kernel's bit for bit); zeros outside the canvas are the conv's padding.
+// Saves the 4-channel fp16 image's round trip through HBM and one launch per step.
+// ---------------------------------------------------------------------------------------
+struct StemSrc { FramePtrs frames; int pitch, top, left, new_h, new_w, in_h, in_w, frame0, frame_bytes; };
+
+template <int NT>
+__global__ __launch_bounds__(256) void stem_fused(StemSrc src, const f16 *__restrict__ lut_g, f16 *__restrict__ out, int Ho, int Wo,
+                                                  int oHp, int oWp, int ocs, int opad, const f16 *__restrict__ wm,
+                                                  const float *__restrict__ bias, int rowb) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char fsm[];
+    unsigned char *rows = fsm;                             // [3][rowb] letterboxed BGR bytes of input rows 2oy-1 .. 2oy+1
+    f16 *lut = (f16 *)(fsm + 3 * rowb);                    // [256]
+    half4 *pix = (half4 *)(lut + 256);                     // [3][in_w + 2] (R,G,B,0) with one zero pixel either side
+    unsigned char *otile = (unsigned char *)(pix + 3 * (src.in_w + 2));   // [4 waves][16 x (32 NT + 8)]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int p = lane & 15, q = lane >> 4;
+    const int b = blockIdx.x / Ho, oy = blockIdx.x - b * Ho;
+    lut[threadIdx.x] = lut_g[threadIdx.x];
+    // ---- assemble the three rows ----
+    const uint8_t *f = src.frames.p[src.frame0 + b];
+    const int ndw = rowb >> 2;
+    for (int i = threadIdx.x; i < 3 * ndw; i += 256) {
+        const int r = i / ndw, dwi = i - r * ndw;
+        const int y = 2 * oy - 1 + r, sy = y - src.top;
+        unsigned v = 0x72727272u;                          // 114 everywhere the canvas has no image
+        if (y >= 0 && y < src.in_h && sy >= 0 && sy < src.new_h) {
+            // canvas bytes [4 dwi, 4 dwi + 4) <- source row bytes [4 dwi - 3 left, ...) where inside [0, 3 new_w)
+            const int s0 = 4 * dwi - 3 * src.left;
+            if (s0 > -4 && s0 < 3 * src.new_w) {
+                const long rowoff = (long)sy * src.pitch;
+                const uintptr_t a = (uintptr_t)(f + rowoff + s0);
+                const uintptr_t al = a & ~(uintptr_t)3;
+                const int sh = (int)(a & 3) * 8;
+                const uintptr_t fend = ((uintptr_t)f + src.frame_bytes + 3) & ~(uintptr_t)3;   // dwords that hold frame bytes
+                const uintptr_t fbeg = (uintptr_t)f & ~(uintptr_t)3;
+                unsigned lo = al >= fbeg && al < fend ? *(const unsigned *)al : 0u;
+                unsigned hi = (sh != 0 && al + 4 < fend && al + 4 >= fbeg) ? *(const unsigned *)(al + 4) : 0u;
+                unsigned w = sh ? (lo >> sh) | (hi << (32 - sh)) : lo;
+                // bytes of this dword that fall outside the source row keep 114
+                unsigned m = 0u;
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (s0 + k >= 0 && s0 + k < 3 * src.new_w) m |= 0xFFu << (8 * k);
+                v = (w & m) | (v & ~m);
+            }
+        }
+        *(unsigned *)(rows + r * rowb + 4 * dwi) = v;
+    }
+    half8 wf[NT][2];
+#pragma unroll
+    for (int u = 0; u < NT; ++u)
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) wf[u][kk] = *(const half8 *)(wm + (u * 16 + p) * 64 + kk * 32 + q * 8);
+    floatx4 bv[NT];
+#pragma unroll
+    for (int u = 0; u < NT; ++u) bv[u] = *(const floatx4 *)(bias + u * 16 + q * 4);
+    __syncthreads();
+    // ---- bytes -> (R, G, B, 0) fp16 pixels; canvas column x sits at index x + 1, zeros outside the canvas ----
+    const int pw = src.in_w + 2;
+    for (int i = threadIdx.x; i < 3 * pw; i += 256) {
+        const int r = i / pw, x = i - r * pw - 1;
+        const int y = 2 * oy - 1 + r;
+        half4 h = {(f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f};
+        if (x >= 0 && x < src.in_w && y >= 0 && y < src.in_h) {
+            const unsigned char *rp = rows + r * rowb + 3 * x;
+            h[0] = lut[rp[2]]; h[1] = lut[rp[1]]; h[2] = lut[rp[0]];
+        }
+        pix[i] = h;
+    }
+    __syncthreads();
+
+    auto pair = [&](int r, int x0) -> half8 {              // pixels (x0, x0 + 1) of canvas row 2oy - 1 + r as {R,G,B,0,R,G,B,0}
+        if (r < 0) return half8{(f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f};
+        const half4 lo = pix[r * pw + x0 + 1], hi = pix[r * pw + x0 + 2];
+        return half8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    };
+    const int gpr = Wo >> 4;
+    for (int gx = wave; gx < gpr; gx += 4) {
+        const int ox = gx * 16 + p;
+        const int x0 = 2 * ox + 2 * (q & 1) - 1;
+        half8 a0 = pair(q >> 1, x0);                         // kernel rows 0 / 1
+        half8 a1 = pair((q >> 1) ? -1 : 2, x0);              // kernel row 2; k' >= 48 meets zero weights
+        floatx4 acc[NT];
+#pragma unroll
+        for (int u = 0; u < NT; ++u) {
+            acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[u][0], a0, bv[u], 0, 0, 0);
+            acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[u][1], a1, acc[u], 0, 0, 0);
+        }
+        if (ocs == 16 * NT) {
+            stem_store<NT>(otile + wave * (16 * (32 * NT + 8)), acc, out + ((long)(b * oHp + oy + opad) * oWp + gx * 16 + opad) * ocs, lane);
+        } else {
+            f16 *o = out + ((long)(b * oHp + oy + opad) * oWp + ox + opad) * ocs + q * 4;
+#pragma unroll
+            for (int u = 0; u < NT; ++u) {
+                half4 h = {(f16)silu_f(acc[u][0]), (f16)silu_f(acc[u][1]), (f16)silu_f(acc[u][2]), (f16)silu_f(acc[u][3])};
+                *(half4 *)(o + u * 16) = h;
+            }
+        }
+    }
+}
+
+int launch_stem_fused(const FramePtrs &frames, int frame0, int pitch, const LetterboxGeom &g, int in_h, int in_w, const f16 *lut,
+                      const TensorView &out, const f16 *wm, const float *bias, int B, int cout, hipStream_t s) {
+    RT_CHECK(!g.resize, RTMODT_E_INVALID, "launch_stem_fused: frames that need a resize go through the letterbox kernel");
+    int Ho = (in_h - 1) / 2 + 1, Wo = (in_w - 1) / 2 + 1;
+    RT_CHECK(Ho == out.H && Wo == out.W && out.c == cout && out.coff == 0 && out.C % 4 == 0, RTMODT_E_INVALID, "launch_stem_fused: output shape");
+    RT_CHECK(Wo % 16 == 0 && in_w % 2 == 0 && cout % 16 == 0 && cout <= 80, RTMODT_E_UNSUPPORTED, "launch_stem_fused: Wo %d / cout %d", Wo, cout);
+    RT_CHECK(frame0 >= 0 && frame0 + B <= 64, RTMODT_E_INVALID, "launch_stem_fused: frames %d..%d", frame0, frame0 + B);
+    RT_CHECK((long)g.src_h * pitch < (1L << 31), RTMODT_E_INVALID, "launch_stem_fused: frame too large");
+    StemSrc src{frames, pitch, g.top, g.left, g.new_h, g.new_w, in_h, in_w, frame0, (g.src_h - 1) * pitch + 3 * g.src_w};
+    const int rowb = (int)align_up((size_t)3 * in_w, 16);
+    const int nt = cout / 16;
+    const size_t smem = (size_t)3 * rowb + 512 + (size_t)3 * (in_w + 2) * 8 + (size_t)4 * 16 * (32 * nt + 8);
+    dim3 grid(B * Ho);
+#define STEMF_CASE(NTILES)                                                                                             \
+    case NTILES:                                                                                                       \
+        hipLaunchKernelGGL((stem_fused<NTILES>), grid, dim3(256), smem, s, src, lut, out.base, Ho, Wo, out.H + 2 * out.pad, \
+                           out.W + 2 * out.pad, out.C, out.pad, wm, bias, rowb);                                        \
+        break;
+    switch (nt) {
+        STEMF_CASE(1) STEMF_CASE(2) STEMF_CASE(3) STEMF_CASE(4) STEMF_CASE(5)
+        default: return fail(RTMODT_E_UNSUPPORTED, "launch_stem_fused: cout %d", cout);
+    }
+#undef STEMF_CASE
+    RT_HIP(hipGetLastError());
+    return RTMODT_OK;
+}
+
 // ---------------------------------------------------------------------------------------
 __device__ __forceinline__ half8 hmax8(half8 a, half8 b) {
     half8 o;

@@ -197,6 +197,11 @@ struct rtmodt_detector {
     uint8_t *stage = nullptr; size_t stage_per = 0;      // [RING_SLOTS][B][stage_per]
     hipStream_t copy_stream = nullptr;
     FramePtrs fptrs{};
+    // letterbox folded into the stem conv whenever the frames need no resize (conv.hip: stem_fused); the stem is
+    // launched by enqueue_batch itself, never from the captured graph (its frame pointers change every batch)
+    f16 *lut255 = nullptr;                           // c / 255 as fp16, c = 0..255
+    bool stem_fuse = true, last_fused = false;
+    LetterboxGeom last_lg{}; int last_pitch = 0;
     int tab_h = -1, tab_w = -1;
     int32_t *d_tab = nullptr; size_t tab_cap = 0;
     ResizeTables tabs{};
@@ -598,9 +603,27 @@ static int run_decode(rtmodt_detector *d) {
     return launch_decode(a, d->stream);
 }
 
+// the stem conv of every chain, on the main stream: straight from the frames' bytes (fused) or from the
+// letterboxed image tensor
+static int run_stems(rtmodt_detector *d, bool fused) {
+    for (int c = 0; c < d->n_chains; ++c) {
+        const Op &op = d->chain_ops[c][0];
+        RT_CHECK(op.kind == OP_STEM, RTMODT_E_INVALID, "op 0 is not the stem");
+        if (fused) RT_TRY(launch_stem_fused(d->fptrs, c * op.B, d->last_pitch, d->last_lg, d->in_h, d->in_w, d->lut255, op.v[1], op.stem_w,
+                                            op.stem_b, op.B, op.v[1].c, d->stream));
+        else RT_TRY(run_op_on(op, d->stream));
+    }
+    return RTMODT_OK;
+}
+// every launch after the stem, eagerly, on the main stream
 static int forward_eager(rtmodt_detector *d) {
-    for (auto &op : d->ops) RT_TRY(run_op(d, op));
+    for (auto &op : d->ops) if (op.kind != OP_STEM) RT_TRY(run_op(d, op));
     return run_decode(d);
+}
+// start-up / autotune: the whole net on whatever the image tensor holds
+static int forward_eager_all(rtmodt_detector *d) {
+    for (auto &op : d->ops) if (op.kind == OP_STEM) RT_TRY(run_op(d, op));
+    return forward_eager(d);
 }
 
 // Times every tile configuration of every MFMA conv on the device it will run on (HIP events,
@@ -679,7 +702,7 @@ static int autotune_tiles(rtmodt_detector *d) {
         for (size_t i = 0; i < d->ops.size(); ++i) { d->chain_ops[0][i].conv.tile = d->ops[i].conv.tile; d->chain_ops[0][i].group_tile = d->ops[i].group_tile; d->chain_ops[0][i].fused = d->ops[i].fused; for (size_t g = 0; g < d->ops[i].group.size(); ++g) d->chain_ops[0][i].group[g].tile = d->ops[i].group[g].tile; }
     }
     // the tuning launches left stale activations; run one clean pass
-    RT_TRY(forward_eager(d));
+    RT_TRY(forward_eager_all(d));
     RT_HIP(hipStreamSynchronize(d->stream));
     return RTMODT_OK;
 }
@@ -709,7 +732,7 @@ static int capture_chain(rtmodt_detector *d, int c) {
     bool forked0 = false, forked1 = false;
     auto body = [&]() -> int {
         for (auto &op : ops) {
-            if (op.head_level >= 0) continue;
+            if (op.head_level >= 0 || op.kind == OP_STEM) continue;   // the stem is launched by enqueue_batch (fresh frame pointers)
             RT_TRY(run_op_on(op, main));
             if (op.name == "15.cv2" && has_level(0)) { RT_TRY(fork(main, h0)); RT_TRY(run_head(0, h0)); forked0 = true; }
             if (op.name == "18.cv2" && has_level(1)) { RT_TRY(fork(main, h1)); RT_TRY(run_head(1, h1)); forked1 = true; }
@@ -862,7 +885,7 @@ void rtmodt_detector_destroy(rtmodt_detector *d) {
     for (auto st : d->aux_streams) hipStreamDestroy(st);
     for (auto e : d->aux_events) hipEventDestroy(e);
     for (void *p : d->dev_allocs) hipFree(p);
-    hipFree(d->arena); hipFree(d->stage); hipFree(d->d_tab); hipFree(d->d_zeros);
+    hipFree(d->arena); hipFree(d->stage); hipFree(d->d_tab); hipFree(d->d_zeros); hipFree(d->lut255);
     hipFree(d->d_pred);
     hipFree(d->d_keys); hipFree(d->d_sbox); hipFree(d->d_sidx);
     for (auto &sl : d->slots) {
@@ -938,8 +961,15 @@ static int detector_create_impl(const rtmodt_det_cfg *cfg, rtmodt_detector *d) {
         RT_HIP(hipEventCreateWithFlags(&sl.copied, hipEventDisableTiming));
     }
 
+    {   // c / 255 in fp16 exactly as the letterbox kernel computes it (IEEE float division, then round to half)
+        f16 lut[256];
+        for (int c = 0; c < 256; ++c) lut[c] = (f16)((float)c / 255.0f);
+        RT_HIP(hipMalloc((void **)&d->lut255, sizeof(lut)));
+        RT_HIP(hipMemcpy(d->lut255, lut, sizeof(lut), hipMemcpyHostToDevice));
+        if (const char *e = getenv("RTMODT_STEM_FUSE")) d->stem_fuse = atoi(e) != 0;      // A/B and test hook
+    }
     // one eager pass (also sets kernel attributes) before capturing the graph
-    RT_TRY(forward_eager(d));
+    RT_TRY(forward_eager_all(d));
     RT_HIP(hipStreamSynchronize(d->stream));
     if (cfg->autotune) RT_TRY(autotune_tiles(d));
     if (cfg->use_graph) RT_TRY(capture_graph(d));
@@ -1007,9 +1037,12 @@ int rtmodt_detector_enqueue_batch(rtmodt_detector *d, const uint8_t *const *fram
     LetterboxGeom lg{h, w, g.new_w, g.new_h, g.top, g.left, g.resize};
     TensorView img; img.base = d->tensors[d->img_t].ptr; img.H = d->in_h; img.W = d->in_w; img.C = 4; img.pad = 1; img.c = 4;
     d->cur_dense = d->head;                            // ring slot == dense set == graph
+    d->last_lg = lg; d->last_pitch = stride_bytes;
+    d->last_fused = d->stem_fuse && !g.resize;
     RT_HIP(hipEventRecord(sl.ev0, d->stream));
-    RT_TRY(launch_letterbox(d->fptrs, stride_bytes, lg, d->tabs, img, d->B, d->stream));
-    RT_HIP(hipEventRecord(sl.evp, d->stream));
+    if (!d->last_fused) RT_TRY(launch_letterbox(d->fptrs, stride_bytes, lg, d->tabs, img, d->B, d->stream));
+    RT_TRY(run_stems(d, d->last_fused));
+    RT_HIP(hipEventRecord(sl.evp, d->stream));              // the frames have been consumed (letterbox [+ stem])
     if (!d->graph_execs.empty() && !d->want_pred) RT_TRY(forward_graphs(d));
     else RT_TRY(forward_eager(d));
     RT_HIP(hipEventRecord(sl.ev1, d->stream));
@@ -1097,6 +1130,11 @@ int rtmodt_detector_debug_fetch(rtmodt_detector *d, int img, uint16_t *input_f16
     RT_HIP(hipDeviceSynchronize());
     if (d->newest >= 0) d->cur_dense = d->newest;
     if (input_f16) {
+        if (d->last_fused) {                               // the fused stem never wrote the image tensor: letterbox the same frames now
+            TensorView iv; iv.base = d->tensors[d->img_t].ptr; iv.H = d->in_h; iv.W = d->in_w; iv.C = 4; iv.pad = 1; iv.c = 4;
+            RT_TRY(launch_letterbox(d->fptrs, d->last_pitch, d->last_lg, d->tabs, iv, d->B, d->stream));
+            RT_HIP(hipStreamSynchronize(d->stream));
+        }
         TensorView v; const Tensor &t = d->tensors[d->img_t];
         v.base = t.ptr; v.H = t.H; v.W = t.W; v.C = 4; v.pad = 1; v.coff = 0; v.c = 3;
         RT_TRY(fetch_view(d, v, img, input_f16));
@@ -1150,7 +1188,10 @@ int rtmodt_detector_profile(rtmodt_detector *d, int iters, int max_entries, cons
     for (int it = 0; it < iters; ++it) {
         RT_HIP(hipEventRecord(ev[0], d->stream));
         for (int i = 0; i < n - 1; ++i) {
-            RT_TRY(run_op(d, d->ops[i]));
+            if (d->ops[i].kind == OP_STEM && d->last_fused)
+                RT_TRY(launch_stem_fused(d->fptrs, 0, d->last_pitch, d->last_lg, d->in_h, d->in_w, d->lut255, d->ops[i].v[1], d->ops[i].stem_w,
+                                         d->ops[i].stem_b, d->B, d->ops[i].v[1].c, d->stream));
+            else RT_TRY(run_op(d, d->ops[i]));
             RT_HIP(hipEventRecord(ev[i + 1], d->stream));
         }
         RT_TRY(run_decode(d));
@@ -1174,6 +1215,8 @@ int rtmodt_detector_profile(rtmodt_detector *d, int iters, int max_entries, cons
             else snprintf(buf, sizeof(buf), "%s [two launches: %s, %s]", op.name.c_str(), tile_name(op.group[0].tile), tile_name(op.group[1].tile));
         } else if (op.kind == OP_GROUP) {
             snprintf(buf, sizeof(buf), "%s [group of %zu, tile %s]", op.name.c_str(), op.group.size(), tile_name(op.group_tile));
+        } else if (op.kind == OP_STEM && d->last_fused) {
+            snprintf(buf, sizeof(buf), "%s [letterbox + stem fused]", op.name.c_str());
         } else {
             snprintf(buf, sizeof(buf), "%s", op.name.c_str());
         }

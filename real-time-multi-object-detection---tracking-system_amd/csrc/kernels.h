@@ -68,6 +68,12 @@ int launch_bottleneck(const BottleneckLaunch &l, hipStream_t s);
 // wm = [cout][64] fp16 in the k' = kh*16 + kw*4 + c order (zero where kw == 3, c == 3 or k' >= 48)
 int launch_stem(const TensorView &img4, const TensorView &out, const f16 *wm, const float *bias, int B,
                 int cout, hipStream_t s);
+// the same conv reading the BGR uint8 frames themselves (letterbox folded in); only for frames that need no
+// resize.  lut: 256 fp16 values c/255.  Frames frame0 .. frame0+B-1 of `frames`.
+struct FramePtrs;
+struct LetterboxGeom;
+int launch_stem_fused(const FramePtrs &frames, int frame0, int pitch, const LetterboxGeom &g, int in_h, int in_w, const f16 *lut,
+                      const TensorView &out, const f16 *wm, const float *bias, int B, int cout, hipStream_t s);
 // SPPF: y -> (max5(y), max5(max5(y)), max5^3(y)) written to three channel slices of the same tensor
 int launch_sppf_pool(const TensorView &y, const TensorView &p1, const TensorView &p2, const TensorView &p3, int B,
                      hipStream_t s);

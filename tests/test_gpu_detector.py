@@ -413,3 +413,32 @@ def test_rect_letterbox_mode(pkg, wdir, h, w, shape):
     det.detect(np.zeros((640, 640, 3), np.uint8))
     assert det.model.input_hw == (640, 640) and len(det._models) == (1 if shape == (640, 640) else 2)
     det.close()
+
+
+@pytest.mark.parametrize("h,w", [(640, 640), (480, 640), (640, 512), (636, 640)])
+def test_letterbox_fused_into_stem_is_bit_identical(pkg, wdir, monkeypatch, h, w):
+    """Frames that need no resize skip the letterbox kernel: the stem conv builds its MFMA fragments from the BGR
+    bytes (114 padding, zero canvas border, c/255 table).  Its output must equal the two-kernel path bit for bit;
+    batch of 3 device-resident frames whose row pitch is wider than the image."""
+    pitch = 3 * (w + 5)
+    wide = pkg.synth.structured_frames(3, h, w + 5, seed=h + w)
+    buf = pkg._ffi.DeviceBuffer(wide.nbytes)
+    buf.upload(wide)
+    ptrs = [buf.ptr + i * h * pitch for i in range(3)]
+    outs = {}
+    for fuse in ("0", "1"):
+        monkeypatch.setenv("RTMODT_STEM_FUSE", fuse)
+        det, _ = make_detector(pkg, wdir, "s", 640, autotune=False, batch=3)
+        det.enqueue(ptrs, height=h, width=w, pitch=pitch)
+        dets = det.fetch()
+        prof = [n for n, _, _ in det.profile(1)]
+        assert ("fused" in prof[0]) == (fuse == "1"), prof[0]
+        outs[fuse] = ([det.debug_layer("0", i) for i in range(3)], [det.debug_fetch(i, want_heads=False, want_pred=False)[0] for i in range(3)], dets)
+        det.close()
+    for i in range(3):
+        assert np.array_equal(outs["0"][0][i].view(np.uint16), outs["1"][0][i].view(np.uint16)), f"stem output, image {i}"
+        assert np.array_equal(outs["0"][1][i].view(np.uint16), outs["1"][1][i].view(np.uint16)), f"input image, image {i}"
+        assert np.array_equal(outs["0"][2][i].xyxy, outs["1"][2][i].xyxy)
+    want = Y.preprocess(wide[1][:, :w], 640, 640)
+    assert np.array_equal(outs["1"][1][1].astype(np.float32), want.astype(np.float16).astype(np.float32))
+    buf.free()
