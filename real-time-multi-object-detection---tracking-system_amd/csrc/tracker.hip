@@ -255,6 +255,7 @@ __device__ __forceinline__ void assoc_lap(F val, int n_rows, int n_cols, double 
     }
     bool dense = nhr > LAP_ROWS;
     if (dense) nhr = 0;
+    __syncthreads();                                       // hrow[] is written after the scan's own barriers
     if (tid == 0) {
         int e = 0;
         for (int h = 0; h < nhr; ++h) { L.estart[h] = e; e += row_best[L.hrow[h]]; }

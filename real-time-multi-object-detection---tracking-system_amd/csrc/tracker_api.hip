@@ -27,6 +27,7 @@ struct rtmodt_tracker {
     // pinned host
     int64_t *h_meta = nullptr;
     int32_t *h_n = nullptr;
+    char *h_state = nullptr;              // one stream's state arrays (rtmodt_tracker_state): 40 bytes per track
 };
 
 static int64_t init_meta_row[8] = {0, 0, 0, 0, 1, 0, 0, 0};   // cur, n_tracks, err, n_active, next_id (tracker.py:55)
@@ -47,7 +48,7 @@ void rtmodt_tracker_destroy(rtmodt_tracker *t) {
     if (t->stream) hipStreamSynchronize(t->stream);
     hipFree(t->pool); hipFree(t->d_states); hipFree(t->d_meta);
     hipFree(t->d_box); hipFree(t->d_conf); hipFree(t->d_cls); hipFree(t->d_n);
-    hipHostFree(t->h_meta); hipHostFree(t->h_n);
+    hipHostFree(t->h_meta); hipHostFree(t->h_n); hipHostFree(t->h_state);
     if (t->stream) hipStreamDestroy(t->stream);
     delete t;
 }
@@ -77,6 +78,7 @@ static int tracker_create_impl(rtmodt_tracker *t) {
     RT_HIP(hipMalloc((void **)&t->d_meta, sizeof(int64_t) * 8 * t->S));
     RT_HIP(hipHostMalloc((void **)&t->h_meta, sizeof(int64_t) * 8 * t->S, hipHostMallocDefault));
     RT_HIP(hipHostMalloc((void **)&t->h_n, sizeof(int32_t) * t->S, hipHostMallocDefault));
+    RT_HIP(hipHostMalloc((void **)&t->h_state, (size_t)t->Mc * 40, hipHostMallocDefault));
     RT_HIP(hipMalloc((void **)&t->d_box, sizeof(float4) * t->Nc * t->S));
     RT_HIP(hipMalloc((void **)&t->d_conf, sizeof(float) * t->Nc * t->S));
     RT_HIP(hipMalloc((void **)&t->d_cls, sizeof(int32_t) * t->Nc * t->S));
@@ -199,21 +201,34 @@ int rtmodt_tracker_state(rtmodt_tracker *t, int stream, int64_t *ids, float *xyx
                          int32_t *tsu, int32_t *n, int64_t *next_id) {
     RT_CHECK(t && stream >= 0 && stream < t->S, RTMODT_E_INVALID, "bad argument");
     RT_HIP(hipSetDevice(t->device));
-    RT_HIP(hipDeviceSynchronize());                       // the detector's stream may still be updating us
-    int64_t m[8];
-    RT_HIP(hipMemcpy(m, t->d_meta + 8 * stream, sizeof(m), hipMemcpyDeviceToHost));
+    // ordered behind the most recent update (own stream, or the detector's): meta first, then the arrays of the
+    // buffer it names, all through pinned memory -- two stream syncs instead of a device sync and seven blocking copies
+    hipStream_t q = t->last_stream;
+    int64_t *m = t->h_meta + 8 * stream;
+    RT_HIP(hipMemcpyAsync(m, t->d_meta + 8 * stream, sizeof(int64_t) * 8, hipMemcpyDeviceToHost, q));
+    RT_HIP(hipStreamSynchronize(q));
     RT_TRY(check_sticky(t, stream, m[2]));
     const int cur = (int)m[0], cnt = (int)m[1];
     const TrackerState &st = t->h_states[stream];
     if (n) *n = cnt;
     if (next_id) *next_id = m[4];
     if (cnt) {
-        if (ids) RT_HIP(hipMemcpy(ids, st.ids[cur], (size_t)cnt * 8, hipMemcpyDeviceToHost));
-        if (xyxy) RT_HIP(hipMemcpy(xyxy, st.box[cur], (size_t)cnt * 16, hipMemcpyDeviceToHost));
-        if (conf) RT_HIP(hipMemcpy(conf, st.conf[cur], (size_t)cnt * 4, hipMemcpyDeviceToHost));
-        if (cls) RT_HIP(hipMemcpy(cls, st.cls[cur], (size_t)cnt * 4, hipMemcpyDeviceToHost));
-        if (age) RT_HIP(hipMemcpy(age, st.age[cur], (size_t)cnt * 4, hipMemcpyDeviceToHost));
-        if (tsu) RT_HIP(hipMemcpy(tsu, st.tsu[cur], (size_t)cnt * 4, hipMemcpyDeviceToHost));
+        char *h = t->h_state;
+        const size_t M = (size_t)t->Mc;
+        char *h_ids = h, *h_box = h + M * 8, *h_conf = h + M * 24, *h_cls = h + M * 28, *h_age = h + M * 32, *h_tsu = h + M * 36;
+        if (ids) RT_HIP(hipMemcpyAsync(h_ids, st.ids[cur], (size_t)cnt * 8, hipMemcpyDeviceToHost, q));
+        if (xyxy) RT_HIP(hipMemcpyAsync(h_box, st.box[cur], (size_t)cnt * 16, hipMemcpyDeviceToHost, q));
+        if (conf) RT_HIP(hipMemcpyAsync(h_conf, st.conf[cur], (size_t)cnt * 4, hipMemcpyDeviceToHost, q));
+        if (cls) RT_HIP(hipMemcpyAsync(h_cls, st.cls[cur], (size_t)cnt * 4, hipMemcpyDeviceToHost, q));
+        if (age) RT_HIP(hipMemcpyAsync(h_age, st.age[cur], (size_t)cnt * 4, hipMemcpyDeviceToHost, q));
+        if (tsu) RT_HIP(hipMemcpyAsync(h_tsu, st.tsu[cur], (size_t)cnt * 4, hipMemcpyDeviceToHost, q));
+        RT_HIP(hipStreamSynchronize(q));
+        if (ids) memcpy(ids, h_ids, (size_t)cnt * 8);
+        if (xyxy) memcpy(xyxy, h_box, (size_t)cnt * 16);
+        if (conf) memcpy(conf, h_conf, (size_t)cnt * 4);
+        if (cls) memcpy(cls, h_cls, (size_t)cnt * 4);
+        if (age) memcpy(age, h_age, (size_t)cnt * 4);
+        if (tsu) memcpy(tsu, h_tsu, (size_t)cnt * 4);
     }
     return RTMODT_OK;
 }

@@ -164,7 +164,9 @@ class MultiObjectTracker:
         """``detections`` is duck-typed on ``.xyxy / .confidence / .class_id`` (tracker.py:234-238)."""
         raw = self._core.update(detections.xyxy, detections.confidence, detections.class_id)
         if self.report == "matched":
-            raw = [t for t in self._core.tracks(0) if t["time_since_update"] == 1]
+            st = self._core.snapshot(0)
+            raw = [{"track_id": int(st["ids"][i]), "xyxy": st["xyxy"][i], "confidence": float(st["conf"][i]), "class_id": int(st["cls"][i]),
+                    "age": int(st["age"][i]), "time_since_update": 1} for i in np.nonzero(st["tsu"] == 1)[0]]
         out = []
         for r in raw:
             tid = r["track_id"]

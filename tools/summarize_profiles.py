@@ -21,8 +21,9 @@ def one(pattern):
     return g[0] if g else None
 
 
-for name in ("bench_default.json", "bench_host_frames.json", "bench_streams16.json", "bench_streams32.json", "stats_bench.json",
-             "pipeline_640.json", "pipeline_1080p.json", "layers.txt"):
+for name in ("bench_default.json", "bench_host_frames.json", "bench_host_frames_pageable.json", "bench_streams16.json",
+             "bench_streams32.json", "stats_bench.json", "pipeline_640.json", "pipeline_1080p.json", "layers.txt", "step_gaps.txt",
+             "bandwidth_probe.txt", "tracker_modes.json"):
     p = os.path.join(src, name)
     if os.path.exists(p):
         shutil.copy(p, os.path.join(dst, name))
@@ -42,7 +43,7 @@ def per_step(dirname, counters, steps=10):
         d[r["Counter_Name"]] = float(r["Counter_Value"])
         d["dur"] = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
     ids = sorted(per, key=int)
-    lb = [i for i in ids if "letterbox" in per[i]["name"]]
+    lb = [i for i in ids if "letterbox" in per[i]["name"] or "stem_fused" in per[i]["name"]]      # first launch of a step
     a, b = int(lb[-steps - 1]), int(lb[-1])
     sel = [per[i] for i in ids if a <= int(i) < b]
     agg = collections.defaultdict(lambda: collections.defaultdict(float))

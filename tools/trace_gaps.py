@@ -14,7 +14,7 @@ rows = []
 for r in csv.DictReader(open(path)):
     rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r.get("Queue_Id", ""), r.get("Stream_Id", "")))
 rows.sort()
-lb = [i for i, r in enumerate(rows) if "letterbox" in r[2]]
+lb = [i for i, r in enumerate(rows) if "letterbox" in r[2] or "stem_fused" in r[2]]      # first launch of a step
 lb = lb[-steps - 1:]
 span = busy = 0
 gaps = []
@@ -31,7 +31,8 @@ for a, b in zip(lb[:-1], lb[1:]):
     prev_end = None
     for s, e, name, _, _ in ks:
         busy += e - s
-        k = name.replace("void rtmodt::", "").replace("rtmodt::", "").split("(")[0][:60]
+        k = name.replace("void rtmodt::", "").replace("rtmodt::", "")
+        k = (k.split("(")[0] if "<" in k.split("(")[0] or not k.startswith("_Z") else k)[:60]
         per[k][0] += 1
         per[k][1] += (e - s) / 1e3
         if prev_end is not None:
