@@ -669,16 +669,56 @@ static int tune_conv(rtmodt_detector *d, hipEvent_t e0, hipEvent_t e1, const std
     return RTMODT_OK;
 }
 
+// RTMODT_TUNE_CACHE=<file>: the tuner's decisions, one line per launch ("<key>\t<tile> <tile2> <fused>"), keyed by the
+// launch's name and GEMM shape.  A process that finds its key there skips the timing runs -- start-up drops from
+// seconds to milliseconds, and a profiler run replays exactly the configuration the bench measured.
+static std::string tune_key(const rtmodt_detector *d, const Op &op) {
+    char buf[256];
+    const ConvLaunch &c = op.kind == OP_CONV ? op.conv : op.group[0];
+    snprintf(buf, sizeof(buf), "%s|B%d|%dx%d|%d>%d|k%ds%d|n%zu", op.name.c_str(), op.B, c.in.H, c.in.W, c.cin, c.cout, c.ks, c.stride,
+             op.kind == OP_CONV ? (size_t)1 : op.group.size());
+    for (char *p = buf; *p; ++p) if (*p == ' ' || *p == '\t') *p = '_';
+    (void)d;
+    return buf;
+}
+struct TuneRec { int t0 = 0, t1 = 0, fused = 0; };
+static std::map<std::string, TuneRec> tune_cache_read(const char *path) {
+    std::map<std::string, TuneRec> m;
+    std::ifstream f(path);
+    std::string key;
+    TuneRec r;
+    while (f >> key >> r.t0 >> r.t1 >> r.fused)
+        if (r.t0 >= 0 && r.t0 < TILE_COUNT && r.t1 >= 0 && r.t1 < TILE_COUNT) m[key] = r;
+    return m;
+}
+
 static int autotune_ops(rtmodt_detector *d, std::vector<Op> &ops) {
     hipEvent_t e0, e1;
     RT_HIP(hipEventCreate(&e0)); RT_HIP(hipEventCreate(&e1));
+    const char *cache_path = getenv("RTMODT_TUNE_CACHE");
+    std::map<std::string, TuneRec> cache;
+    if (cache_path) cache = tune_cache_read(cache_path);
+    bool dirty = false;
     for (auto &op : ops) {
+        if (op.kind != OP_CONV && op.kind != OP_GROUP && op.kind != OP_BNECK) continue;
+        const std::string key = tune_key(d, op);
+        auto hit = cache.find(key);
+        if (hit != cache.end()) {
+            const TuneRec &r = hit->second;
+            if (op.kind == OP_CONV) op.conv.tile = r.t0;
+            else if (op.kind == OP_GROUP) op.group_tile = r.t0;
+            else { op.group[0].tile = r.t0; op.group[1].tile = r.t1; op.fused = r.fused != 0; }
+            continue;
+        }
         float ms;
+        TuneRec r;
         if (op.kind == OP_CONV) {
             RT_TRY(tune_conv(d, e0, e1, op.name, &op.conv, 1, op.conv.tile, ms));
+            r.t0 = op.conv.tile;
         } else if (op.kind == OP_GROUP) {
             RT_TRY(tune_conv(d, e0, e1, op.name, op.group.data(), (int)op.group.size(), op.group_tile, ms));
-        } else if (op.kind == OP_BNECK) {
+            r.t0 = op.group_tile;
+        } else {
             float ms1, ms2, msf;
             RT_TRY(tune_conv(d, e0, e1, op.group[0].in.c ? op.name + ".cv1" : op.name, &op.group[0], 1, op.group[0].tile, ms1));
             RT_TRY(tune_conv(d, e0, e1, op.name + ".cv2", &op.group[1], 1, op.group[1].tile, ms2));
@@ -686,9 +726,20 @@ static int autotune_ops(rtmodt_detector *d, std::vector<Op> &ops) {
             if (getenv("RTMODT_TUNE_LOG")) fprintf(stderr, "[tune] %-28s fused %8.2f us vs two launches %8.2f us\n", op.name.c_str(), msf * 1e3f, (ms1 + ms2) * 1e3f);
             op.fused = msf < ms1 + ms2;
             if (const char *e = getenv("RTMODT_BNECK")) op.fused = atoi(e) != 0;      // A/B and test hook
+            r.t0 = op.group[0].tile; r.t1 = op.group[1].tile; r.fused = op.fused;
         }
+        cache[key] = r;
+        dirty = true;
     }
     hipEventDestroy(e0); hipEventDestroy(e1);
+    if (cache_path && dirty) {                            // whole file rewritten through a rename: readers never see half a file
+        const std::string tmp = std::string(cache_path) + ".tmp." + std::to_string((long)getpid());
+        {
+            std::ofstream f(tmp);
+            for (auto &kv : cache) f << kv.first << '\t' << kv.second.t0 << ' ' << kv.second.t1 << ' ' << kv.second.fused << '\n';
+        }
+        rename(tmp.c_str(), cache_path);
+    }
     return RTMODT_OK;
 }
 

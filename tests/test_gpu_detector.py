@@ -442,3 +442,30 @@ def test_letterbox_fused_into_stem_is_bit_identical(pkg, wdir, monkeypatch, h, w
     want = Y.preprocess(wide[1][:, :w], 640, 640)
     assert np.array_equal(outs["1"][1][1].astype(np.float32), want.astype(np.float16).astype(np.float32))
     buf.free()
+
+
+def test_autotune_cache_replays_the_same_configuration(pkg, wdir, monkeypatch, tmp_path):
+    """RTMODT_TUNE_CACHE: the first detector times every tile and records its choices; the second one (same
+    shapes) reads them back -- identical launch configuration, no timing runs; a third one with another batch
+    size adds its own keys to the same file."""
+    import time
+    cache = tmp_path / "tune.txt"
+    monkeypatch.setenv("RTMODT_TUNE_CACHE", str(cache))
+    t0 = time.perf_counter()
+    a, _ = make_detector(pkg, wdir, "n", 320, autotune=True, batch=2)
+    t1 = time.perf_counter()
+    names_a = [n for n, _, _ in a.profile(1)]
+    a.close()
+    lines = cache.read_text().splitlines()
+    assert len(lines) > 30 and all(len(l.split()) == 4 for l in lines)
+    t2 = time.perf_counter()
+    b, _ = make_detector(pkg, wdir, "n", 320, autotune=True, batch=2)
+    t3 = time.perf_counter()
+    assert [n for n, _, _ in b.profile(1)] == names_a
+    assert (t3 - t2) < 0.5 * (t1 - t0), (t1 - t0, t3 - t2)
+    frames = list(pkg.synth.frames(2, 320, 320, seed=5))
+    assert all(len(d.xyxy) == len(d.confidence) for d in b.detect_batch(frames))
+    b.close()
+    c, _ = make_detector(pkg, wdir, "n", 320, autotune=True, batch=1)
+    c.close()
+    assert len(cache.read_text().splitlines()) > len(lines)

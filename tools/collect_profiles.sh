@@ -7,6 +7,9 @@ R=${1:-r01}
 O=gpurun_out/$R
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+# the first run tunes and records its choices; every later process (profilers included) replays exactly that configuration
+export RTMODT_TUNE_CACHE=/tmp/rtmodt_tune_$R.txt
+rm -f $RTMODT_TUNE_CACHE
 python bench.py > $O/bench_default.json 2> $O/bench_default.log || exit 1
 echo "[collect] bench done"
 B="python3 bench.py --no-cpu-baseline --no-latency"

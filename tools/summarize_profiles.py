@@ -17,8 +17,8 @@ os.makedirs(dst, exist_ok=True)
 
 
 def one(pattern):
-    g = glob.glob(os.path.join(src, pattern))
-    return g[0] if g else None
+    g = sorted(glob.glob(os.path.join(src, pattern)), key=os.path.getmtime)      # the newest run wins
+    return g[-1] if g else None
 
 
 for name in ("bench_default.json", "bench_host_frames.json", "bench_host_frames_pageable.json", "bench_streams16.json",
@@ -48,7 +48,7 @@ def per_step(dirname, counters, steps=10):
     sel = [per[i] for i in ids if a <= int(i) < b]
     agg = collections.defaultdict(lambda: collections.defaultdict(float))
     for d in sel:
-        k = d["name"].replace("void rtmodt::", "").replace("rtmodt::", "")
+        k = d["name"].replace("(anonymous namespace)::", "").replace("void rtmodt::", "").replace("rtmodt::", "")
         k = k.split("(")[0] if "<" in k else k[:48]
         agg[k]["calls"] += 1.0 / steps
         agg[k]["us"] += d["dur"] / 1e3 / steps

@@ -31,7 +31,7 @@ for a, b in zip(lb[:-1], lb[1:]):
     prev_end = None
     for s, e, name, _, _ in ks:
         busy += e - s
-        k = name.replace("void rtmodt::", "").replace("rtmodt::", "")
+        k = name.replace("(anonymous namespace)::", "").replace("void rtmodt::", "").replace("rtmodt::", "")
         k = (k.split("(")[0] if "<" in k.split("(")[0] or not k.startswith("_Z") else k)[:60]
         per[k][0] += 1
         per[k][1] += (e - s) / 1e3
