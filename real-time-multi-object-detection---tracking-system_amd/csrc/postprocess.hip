@@ -88,17 +88,47 @@ __global__ __launch_bounds__(256) void decode_kernel(DecodeArgs a) {
     float best = -1.0f;
     int bj = c0;
     float *pr = (a.pred && live) ? a.pred + (long)b * (4 + a.nc) * a.n_anchors + an : nullptr;
-    for (int c = c0; c < c1; ++c) {
-        float x = (float)p[64 + c];
-        float sg = 1.0f / (1.0f + expf(-x));
-        if (sg > best) { best = sg; bj = c; }              // first maximum inside the quarter
-        if (pr) pr[(long)(4 + c) * a.n_anchors] = sg;
-    }
+    // Fast path: the sigmoid is strictly increasing on the fp16 grid as long as it is far from saturating in
+    // float32 (x < 8: neighbouring halves are >= 2^-8 apart and sigmoid' > 3e-4, far above an ulp), so the first
+    // arg-max of the logits IS the first arg-max of the scores and one sigmoid per anchor replaces nc of them.
+    // Anything else (a logit >= 8, the pred dump, a class count that does not split into half4s) takes the
+    // score-by-score loop below; the quad decides together (xm is quad-uniform).
+    bool slow = a.pred != nullptr || (per & 3) != 0 || c1 - c0 != per;
+    if (!slow) {
+        typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+        float xb = -INFINITY;
+        for (int k = 0; k < per; k += 4) {
+            const half4 h = *(const half4 *)(p + 64 + c0 + k);
 #pragma unroll
-    for (int d = 1; d <= 2; d <<= 1) {
-        float ob = __shfl_xor(best, d);
-        int oj = __shfl_xor(bj, d);
-        if (ob > best || (ob == best && oj < bj)) { best = ob; bj = oj; }
+            for (int e = 0; e < 4; ++e) {
+                const float x = (float)h[e];
+                if (x > xb) { xb = x; bj = c0 + k + e; }
+            }
+        }
+#pragma unroll
+        for (int d = 1; d <= 2; d <<= 1) {
+            float ob = __shfl_xor(xb, d);
+            int oj = __shfl_xor(bj, d);
+            if (ob > xb || (ob == xb && oj < bj)) { xb = ob; bj = oj; }
+        }
+        if (xb < 8.0f) best = 1.0f / (1.0f + expf(-xb));
+        else slow = true;
+    }
+    if (slow) {
+        best = -1.0f;
+        bj = c0;
+        for (int c = c0; c < c1; ++c) {
+            float x = (float)p[64 + c];
+            float sg = 1.0f / (1.0f + expf(-x));
+            if (sg > best) { best = sg; bj = c; }              // first maximum inside the quarter
+            if (pr) pr[(long)(4 + c) * a.n_anchors] = sg;
+        }
+#pragma unroll
+        for (int d = 1; d <= 2; d <<= 1) {
+            float ob = __shfl_xor(best, d);
+            int oj = __shfl_xor(bj, d);
+            if (ob > best || (ob == best && oj < bj)) { best = ob; bj = oj; }
+        }
     }
     if (!live || j != 0) return;
     if (pr) {

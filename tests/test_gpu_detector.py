@@ -469,3 +469,29 @@ def test_autotune_cache_replays_the_same_configuration(pkg, wdir, monkeypatch, t
     c, _ = make_detector(pkg, wdir, "n", 320, autotune=True, batch=1)
     c.close()
     assert len(cache.read_text().splitlines()) > len(lines)
+
+
+@pytest.mark.parametrize("bias", [-4.1, 9.0, 14.0])
+def test_decode_fast_path_equals_score_by_score(pkg, tmp_path, bias):
+    """decode_kernel takes the arg-max over class LOGITS and one sigmoid when every logit of the anchor is < 8
+    (the sigmoid is strictly increasing on the fp16 grid there) and the score-by-score loop otherwise; the
+    `pred` dump always takes the loop.  Class ids, scores and NMS survivors from the engine's candidates must
+    equal those derived from the dumped pred -- for ordinary logits (bias -4.1), logits straddling the switch
+    (9) and saturated ones where float32 sigmoids tie (14)."""
+    path = str(tmp_path / "w.rtw")
+    w = pkg.weights.synthetic("n", input_size=320, cls_bias=bias)
+    pkg.weights.save(path, w, "n")
+    det = pkg.Detector(path, input_size=(320, 320), confidence=0.25, max_det=300, warmup=False, autotune=False)
+    frame = pkg.synth.frames(1, 320, 320, seed=8)[0]
+    got = det.detect(frame)
+    _, heads, pred = det.debug_fetch(0, want_input=False)
+    cls_logits = np.concatenate([heads[o:o + n * 144].reshape(n, 144)[:, 64:] for o, n in ((0, 1600), (1600 * 144, 400), (2000 * 144, 100))]).astype(np.float32)
+    if bias > 8:
+        assert (cls_logits.max(axis=1) >= 8).mean() > 0.3            # the loop really is exercised
+    if bias > 12:
+        assert (pred[4:].max(axis=0) == 1.0).any()                  # saturated float32 sigmoids: ties by rounding
+    dets, _ = Y.non_max_suppression(pred, 0.25, det.iou, None, False, 300, 80)
+    assert len(got) == len(dets) > 0
+    assert np.array_equal(got.class_id, dets[:, 5].astype(np.int32))
+    assert np.array_equal(got.confidence.view(np.int32), dets[:, 4].astype(np.float32).view(np.int32))
+    det.close()
