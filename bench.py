@@ -39,6 +39,8 @@ def parse():
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--streams", type=int, default=8, help="video streams batched per GPU")
+    ap.add_argument("--frames-per-stream", type=int, default=2,
+                    help="consecutive frames of every stream per launch (frame batching; the tracker still sees them one at a time, in order)")
     ap.add_argument("--model", default="s")
     ap.add_argument("--size", type=int, default=640)
     ap.add_argument("--ring", type=int, default=16, help="pre-generated frames per stream kept in HBM")
@@ -121,64 +123,74 @@ def main():
     for s, gid in enumerate(my_streams):
         ring.upload(pkg.synth.frames(R, size, size, seed=1234 + gid), offset=s * R * per)
 
-    det = pkg.Detector(wpath, input_size=(size, size), max_det=args.max_det, device=f"cuda:{dev}", batch=S,
-                       use_graph=not args.no_graph, warmup=False)
-    trk = core_cls(device=dev, n_streams=S, max_dets=max(128, args.max_det), max_tracks=2048)
-    flops_step = det.model.conv_flops_per_frame * S
-
-    ptrs = [[ring.ptr + (s * R + r) * per for s in range(S)] for r in range(R)]
+    F = max(1, args.frames_per_stream)
 
     host_ring = None
     if args.host_frames:
-        host_ring = [[pkg.synth.frames(1, size, size, seed=1234 + gid + 1000 * r)[0] for gid in my_streams] for r in range(4)]
+        host_ring = [[pkg.synth.frames(1, size, size, seed=1234 + gid + 1000 * r)[0] for gid in my_streams] for r in range(8)]
         if not args.pageable:                           # what a capture thread would write into: page-locked ring slots
-            pinned = pkg.pipeline.PinnedFrameRing(4 * S, size, size, device=dev)
-            host_ring = [[pinned.write(r * S + s, host_ring[r][s]) for s in range(S)] for r in range(4)]
+            pinned = pkg.pipeline.PinnedFrameRing(8 * S, size, size, device=dev)
+            host_ring = [[pinned.write(r * S + s, host_ring[r][s]) for s in range(S)] for r in range(8)]
+    ptrs = [[ring.ptr + (s * R + r) * per for s in range(S)] for r in range(R)]
 
-    def submit(t):
-        if host_ring is not None:
-            det.enqueue(host_ring[t % 4])               # H2D of 8 x 1.23 MB inside the step
-        else:
-            det.enqueue(ptrs[t % R], height=size, width=size)
-        trk.update_from_detector(det)
-
-    def step(t):
-        """Steady state of a 2-deep pipeline: submit batch t, then collect batch t-1 (whose
-        copy to the host overlapped the GPU's work on batch t)."""
-        submit(t)
-        return det.fetch()
-
-    def sync_all():
+    def sync_all(det):
         det.synchronize()                           # hipDeviceSynchronize through the C ABI
         sync.device_synchronize()                   # + torch.cuda.synchronize() when torch.distributed is up
 
-    # a generation-2 Python GC pass walks every object torch's import created (~40 ms): keep the
-    # collector out of the loop (the per-step garbage is a few hundred short-lived objects)
-    gc.collect()
-    gc.freeze()
-    gc.disable()
-    submit(0)                                       # prime the pipeline: one batch always in flight
-    for t in range(1, args.warmup + 1):
-        step(t)
-    sync_all()
-    sync.barrier()
-    sync_all()
-    fwd_ms = tot_ms = 0.0
-    n_det = 0
-    t0 = time.perf_counter()
-    for t in range(args.steps):
-        out = step(args.warmup + 1 + t)           # submits one batch, retires one batch: K batches per K steps
-        a, b = det.last_timing()                   # HIP events on the detector's stream, already complete
-        tot_ms += a
-        fwd_ms += b
-        n_det += sum(len(d) for d in out)
-    sync_all()
-    sync.barrier()
-    sync_all()
-    elapsed = time.perf_counter() - t0
-    gc.enable()
+    def measure(F, steps, warmup, collective=True):
+        """K timed steps; a step = one launch set over S streams x F consecutive frames (image f * S + s)."""
+        det = pkg.Detector(wpath, input_size=(size, size), max_det=args.max_det, device=f"cuda:{dev}", batch=S * F,
+                           use_graph=not args.no_graph, warmup=False)
+        trk = core_cls(device=dev, n_streams=S, max_dets=max(128, args.max_det), max_tracks=2048)
+
+        def submit(t):
+            if host_ring is not None:                   # H2D of S x F x 1.23 MB inside the step (copy stream)
+                det.enqueue([fr for f in range(F) for fr in host_ring[(t * F + f) % 8]])
+            else:
+                det.enqueue([pt for f in range(F) for pt in ptrs[(t * F + f) % R]], height=size, width=size)
+            for f in range(F):                          # frame f of every stream, then frame f + 1: tracker.py:58-141 order
+                trk.update_from_detector(det, f * S, S)
+
+        def step(t):
+            """Steady state of a 2-deep pipeline: submit batch t, then collect batch t-1 (whose
+            copy to the host overlapped the GPU's work on batch t)."""
+            submit(t)
+            return det.fetch()
+
+        # a generation-2 Python GC pass walks every object torch's import created (~40 ms): keep the
+        # collector out of the loop (the per-step garbage is a few hundred short-lived objects)
+        gc.collect()
+        gc.freeze()
+        gc.disable()
+        submit(0)                                       # prime the pipeline: one batch always in flight
+        for t in range(1, warmup + 1):
+            step(t)
+        sync_all(det)
+        if collective:
+            sync.barrier()
+            sync_all(det)
+        fwd_ms = tot_ms = 0.0
+        n_det = 0
+        t0 = time.perf_counter()
+        for t in range(steps):
+            out = step(warmup + 1 + t)                # submits one batch, retires one batch: K batches per K steps
+            a, b = det.last_timing()                   # HIP events on the detector's stream, already complete
+            tot_ms += a
+            fwd_ms += b
+            n_det += sum(len(d) for d in out)
+        sync_all(det)
+        if collective:
+            sync.barrier()
+            sync_all(det)
+        elapsed = time.perf_counter() - t0
+        gc.enable()
+        det.fetch()                                      # drain the batch still in flight (outside the timed region)
+        return {"elapsed": elapsed, "fwd_ms": fwd_ms, "tot_ms": tot_ms, "n_det": n_det, "det": det, "trk": trk}
+
+    m = measure(F, args.steps, args.warmup)
+    det, trk, elapsed, fwd_ms, tot_ms, n_det = m["det"], m["trk"], m["elapsed"], m["fwd_ms"], m["tot_ms"], m["n_det"]
+    flops_step = det.model.conv_flops_per_frame * S * F
     elapsed = sync.max_time(elapsed)                # MAX over ranks
-    det.fetch()                                      # drain the batch still in flight (outside the timed region)
     n_tracks = sum(len(trk.snapshot(s)["ids"]) for s in range(S))
     # optional stats reduce (SURVEY C1): ~24 bytes over RCCL, once per run
     n_det, n_tracks_node = sync.sum_stats([n_det, n_tracks])
@@ -188,7 +200,7 @@ def main():
         sync.close()
         return
 
-    frames_total = world * S * args.steps
+    frames_total = world * S * F * args.steps
     fps = frames_total / elapsed
     fwd_ms_step = fwd_ms / args.steps
     achieved = flops_step / (fwd_ms_step * 1e-3) / 1e12
@@ -198,9 +210,11 @@ def main():
         "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f16", "data": "synthetic",
         "config": {"workload": f"YOLOv8{args.model} {size}x{size} fp16, {S} synthetic streams per GPU (BASELINE config 4 shard), "
-                               f"detect (letterbox+forward+decode+NMS, max_det {args.max_det}) + ByteTrack update, frames resident in HBM, "
-                               "detections copied to host every step",
-                   "streams_per_gpu": S, "frames_per_step": S * world, "weights": "synthetic seed 0, LSUV-calibrated on noise frames",
+                               f"{F} consecutive frame(s) of every stream per launch set, "
+                               f"detect (letterbox+forward+decode+NMS, max_det {args.max_det}) + ByteTrack update (frame by frame, in order), "
+                               "frames resident in HBM, detections copied to host every step",
+                   "streams_per_gpu": S, "frames_per_stream_per_step": F, "frames_per_step": S * F * world,
+                   "weights": "synthetic seed 0, LSUV-calibrated on noise frames",
                    "parallelism": f"streams sharded {world} ways, no data-path collective"},
         "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_F16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(achieved / MFMA_F16_DENSE_PEAK_TFLOPS, 4), "traffic": None,
@@ -214,7 +228,7 @@ def main():
     tpath = os.path.join(ROOT, "profiles", "traffic_current.json")
     if os.path.exists(tpath) and not args.host_frames:
         tj = json.load(open(tpath))
-        if tj.get("workload_key") == f"{args.model}-{size}-{S}":
+        if tj.get("workload_key") == f"{args.model}-{size}-{S}x{F}":
             res["roofline"]["traffic"] = tj["hbm_bytes_per_step"]      # rocprofv3 PMC passes, see profiles/r01/README.md
             res["roofline"]["traffic_unit"] = "bytes per step (FETCH_SIZE x2 + WRITE_SIZE over the forward-pass launches)"
             res["roofline"]["traffic_source"] = tj["source"]
@@ -227,6 +241,17 @@ def main():
     res["roofline"]["conv_kernels_tflops_eager"] = round(flops_step / (conv_ms * 1e-3) / 1e12, 2)
     top = sorted(prof, key=lambda r: -r[1])[:6]
     res["roofline"]["slowest_launches"] = [{"op": n, "ms": round(ms, 4), "tflops": round(fl / (ms * 1e-3) / 1e12, 1) if ms > 0 else 0} for n, ms, fl in top]
+
+    # ---- the same workload without frame batching (one frame of every stream per launch set), for comparison ----
+    if F > 1 and world == 1 and not args.host_frames:
+        det.close()
+        m1 = measure(1, args.steps, args.warmup, collective=False)
+        f1 = m1["fwd_ms"] / args.steps
+        res["one_frame_per_stream_per_step"] = {"value": round(S * args.steps / m1["elapsed"], 1), "unit": "frames/s",
+                                                "ms_per_step": round(m1["elapsed"] / args.steps * 1e3, 4), "forward_ms_per_step": round(f1, 4),
+                                                "achieved_tflops": round(m1["det"].model.conv_flops_per_frame * S / (f1 * 1e-3) / 1e12, 2)}
+        m1["det"].close()
+        m1["trk"].close()
 
     # ---- single-stream latency (BASELINE config 1/2 shape: batch 1, sync per frame) ----
     if not args.no_latency:

@@ -156,6 +156,10 @@ int rtmodt_tracker_update_batch(rtmodt_tracker *trk, const float *xyxy, const fl
 /* Consumes the device-resident detections of det's last enqueue_batch (stream i <- frame i),
  * asynchronously on det's HIP stream. */
 int rtmodt_tracker_update_from_detector(rtmodt_tracker *trk, rtmodt_detector *det);
+/* The same for frames [first_frame, first_frame + n_frames) of det's batch (stream i <- frame first_frame + i):
+ * a batch that holds several CONSECUTIVE frames of every stream (frame-major: image f * n_streams + s) is
+ * tracked by calling this once per f, in order -- tracker.py:58-141 still sees each stream's frames one at a time. */
+int rtmodt_tracker_update_from_detector_frames(rtmodt_tracker *trk, rtmodt_detector *det, int first_frame, int n_frames);
 /* List-order snapshot of a stream's state = the reference's _core._tracks + _core._next_id
  * (the parity surface).  Arrays sized max_tracks; any may be NULL. */
 int rtmodt_tracker_state(rtmodt_tracker *trk, int stream, int64_t *ids, float *xyxy, float *conf,

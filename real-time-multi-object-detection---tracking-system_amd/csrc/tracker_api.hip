@@ -182,19 +182,30 @@ int rtmodt_tracker_update_batch(rtmodt_tracker *t, const float *xyxy, const floa
     return finish(t, 0, t->S, n_active_out);
 }
 
-int rtmodt_tracker_update_from_detector(rtmodt_tracker *t, rtmodt_detector *det) {
+static int update_from_detector_slice(rtmodt_tracker *t, rtmodt_detector *det, int first, int count) {
     RT_CHECK(t && det, RTMODT_E_INVALID, "null argument");
     DetOutputs o;
     RT_TRY(detector_outputs(det, &o));
+    if (count < 0) count = o.count - first;
     RT_CHECK(o.device == t->device, RTMODT_E_INVALID, "tracker on device %d, detector on device %d", t->device, o.device);
-    RT_CHECK(o.count <= t->S, RTMODT_E_INVALID, "detector batch %d > tracker streams %d", o.count, t->S);
+    RT_CHECK(first >= 0 && count >= 1 && first + count <= o.count, RTMODT_E_INVALID, "frames [%d, %d) outside the detector's batch of %d", first,
+             first + count, o.count);
+    RT_CHECK(count <= t->S, RTMODT_E_INVALID, "%d frames > tracker streams %d", count, t->S);
     RT_CHECK(o.stride <= t->Nc, RTMODT_E_CAPACITY, "detector max_det %d > tracker max_dets %d", o.stride, t->Nc);
     RT_HIP(hipSetDevice(t->device));
     TrackerArgs a = make_args(t);
-    a.n_streams = o.count;
-    a.det_box = o.box; a.det_conf = o.conf; a.det_cls = o.cls; a.det_n = o.n; a.det_stride = o.stride;
+    a.n_streams = count;
+    a.det_box = o.box + (size_t)first * o.stride; a.det_conf = o.conf + (size_t)first * o.stride; a.det_cls = o.cls + (size_t)first * o.stride;
+    a.det_n = o.n + first; a.det_stride = o.stride;
     t->last_stream = o.stream;
     return launch_tracker_update(a, o.stream);          // same HIP stream as the detector: ordered, no host sync
+}
+
+int rtmodt_tracker_update_from_detector(rtmodt_tracker *t, rtmodt_detector *det) { return update_from_detector_slice(t, det, 0, -1); }
+
+int rtmodt_tracker_update_from_detector_frames(rtmodt_tracker *t, rtmodt_detector *det, int first_frame, int n_frames) {
+    RT_CHECK(n_frames >= 1, RTMODT_E_INVALID, "n_frames %d", n_frames);
+    return update_from_detector_slice(t, det, first_frame, n_frames);
 }
 
 int rtmodt_tracker_state(rtmodt_tracker *t, int stream, int64_t *ids, float *xyxy, float *conf, int32_t *cls, int32_t *age,

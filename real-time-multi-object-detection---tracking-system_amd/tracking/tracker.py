@@ -82,9 +82,14 @@ class _ByteTrackCore:
                                                           _ffi.ptr(counts), _ffi.ptr(act)))
         return act
 
-    def update_from_detector(self, detector) -> None:
-        """Consume the detector's device-resident detections (stream i <- frame i), no host hop."""
-        _ffi.check(_ffi.lib().rtmodt_tracker_update_from_detector(self._h, detector.model.handle))
+    def update_from_detector(self, detector, first_frame: int = 0, n_frames: int = -1) -> None:
+        """Consume the detector's device-resident detections (stream i <- frame first_frame + i), no host hop.
+        A batch with F consecutive frames per stream (image f * n_streams + s) takes F calls, f ascending."""
+        if first_frame == 0 and n_frames < 0:
+            _ffi.check(_ffi.lib().rtmodt_tracker_update_from_detector(self._h, detector.model.handle))
+        else:
+            _ffi.check(_ffi.lib().rtmodt_tracker_update_from_detector_frames(self._h, detector.model.handle, int(first_frame),
+                                                                             int(self.n_streams if n_frames < 0 else n_frames)))
 
     # -- parity surface ----------------------------------------------------------------
     def snapshot(self, stream: int = 0) -> dict:

@@ -495,3 +495,45 @@ def test_decode_fast_path_equals_score_by_score(pkg, tmp_path, bias):
     assert np.array_equal(got.class_id, dets[:, 5].astype(np.int32))
     assert np.array_equal(got.confidence.view(np.int32), dets[:, 4].astype(np.float32).view(np.int32))
     det.close()
+
+
+@pytest.mark.parametrize("F", [2, 3])
+def test_frame_batching_keeps_tracker_order(pkg, wdir, monkeypatch, F):
+    """bench.py's default launch set holds F consecutive frames of every stream (image f * S + s); the tracker
+    consumes them slice by slice on the device.  Detections and every stream's tracker state must equal the
+    frame-at-a-time run (same tiles forced so the convs are bit-identical) and the oracle."""
+    from oracle import tracker_oracle as T
+    from importlib import import_module
+    core_cls = import_module(pkg.__name__ + ".tracking.tracker")._ByteTrackCore
+    monkeypatch.setenv("RTMODT_TILE", "2")
+    monkeypatch.setenv("RTMODT_BNECK", "0")
+    S, steps = 3, 4
+    frames = pkg.synth.frames(S * F * steps, 320, 320, seed=33).reshape(steps, F, S, 320, 320, 3)
+    buf = pkg._ffi.DeviceBuffer(frames.nbytes)
+    buf.upload(frames)
+    per = 320 * 320 * 3
+    big, _ = make_detector(pkg, wdir, "s", 320, batch=S * F, autotune=False, confidence=0.2)
+    one, _ = make_detector(pkg, wdir, "s", 320, batch=S, autotune=False, confidence=0.2)
+    core_b, core_1 = core_cls(n_streams=S, max_dets=128, max_tracks=512), core_cls(n_streams=S, max_dets=128, max_tracks=512)
+    oracles = [T.TrackerOracle() for _ in range(S)]
+    for t in range(steps):
+        big.enqueue([buf.ptr + ((t * F + f) * S + s) * per for f in range(F) for s in range(S)], height=320, width=320)
+        for f in range(F):
+            core_b.update_from_detector(big, f * S, S)
+        got = big.fetch()
+        assert len(got) == S * F
+        for f in range(F):
+            one.enqueue([buf.ptr + ((t * F + f) * S + s) * per for s in range(S)], height=320, width=320)
+            core_1.update_from_detector(one)
+            ref = one.fetch()
+            for s in range(S):
+                d = got[f * S + s]
+                assert np.array_equal(d.xyxy.view(np.int32), ref[s].xyxy.view(np.int32)) and np.array_equal(d.class_id, ref[s].class_id)
+                oracles[s].update(d.xyxy, d.confidence, d.class_id)
+        for s in range(S):
+            assert np.array_equal(T.state_digest(core_b.snapshot(s)), T.state_digest(core_1.snapshot(s))), (t, s)
+            assert np.array_equal(T.state_digest(core_b.snapshot(s)), T.state_digest(oracles[s].snapshot())), (t, s)
+    assert sum(len(core_b.snapshot(s)["ids"]) for s in range(S)) > 0
+    with pytest.raises(pkg._ffi.RtmodtError):
+        core_b.update_from_detector(big, S * F - 1, S)          # slice runs past the batch
+    buf.free(); big.close(); one.close()

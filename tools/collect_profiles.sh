@@ -23,8 +23,10 @@ rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_AC
     --output-format csv -d $O/pmc_sq -- $B --steps 20 --warmup 5 > /dev/null 2> $O/pmc_sq.log || exit 1
 echo "[collect] pmc done"
 python tools/profile_layers.py > $O/layers.txt 2> /dev/null
-$B --steps 300 --warmup 30 --streams 16 > $O/bench_streams16.json 2> /dev/null
-$B --steps 200 --warmup 20 --streams 32 > $O/bench_streams32.json 2> /dev/null
+$B --steps 300 --warmup 30 --frames-per-stream 1 > $O/bench_frames1.json 2> /dev/null
+$B --steps 200 --warmup 20 --frames-per-stream 4 > $O/bench_frames4.json 2> /dev/null
+$B --steps 300 --warmup 30 --streams 16 --frames-per-stream 1 > $O/bench_streams16.json 2> /dev/null
+$B --steps 200 --warmup 20 --streams 32 --frames-per-stream 1 > $O/bench_streams32.json 2> /dev/null
 $B --steps 300 --warmup 30 --host-frames > $O/bench_host_frames.json 2> /dev/null
 $B --steps 300 --warmup 30 --host-frames --pageable > $O/bench_host_frames_pageable.json 2> /dev/null
 python tools/run_pipeline_synth.py > $O/pipeline_640.json 2> /dev/null

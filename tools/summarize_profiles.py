@@ -22,7 +22,7 @@ def one(pattern):
 
 
 for name in ("bench_default.json", "bench_host_frames.json", "bench_host_frames_pageable.json", "bench_streams16.json",
-             "bench_streams32.json", "stats_bench.json", "pipeline_640.json", "pipeline_1080p.json", "layers.txt", "step_gaps.txt",
+             "bench_streams32.json", "bench_frames1.json", "bench_frames4.json", "stats_bench.json", "pipeline_640.json", "pipeline_1080p.json", "layers.txt", "step_gaps.txt",
              "bandwidth_probe.txt", "tracker_modes.json"):
     p = os.path.join(src, name)
     if os.path.exists(p):
@@ -67,7 +67,9 @@ if fetch and write:
     F = sum(v["FETCH_SIZE"] for k, v in fetch.items() if not k.startswith(post))
     W = sum(v["WRITE_SIZE"] for k, v in write.items() if not k.startswith(post))
     hbm = int((2 * F + W) * 1024)
-    json.dump({"workload_key": "s-640-8", "hbm_bytes_per_step": hbm, "fetch_size_kb_per_step": round(F, 1),
+    cfg = json.loads(open(os.path.join(src, "stats_bench.json")).read().strip().splitlines()[-1])["config"]
+    key = f"s-640-{cfg['streams_per_gpu']}x{cfg.get('frames_per_stream_per_step', 1)}"
+    json.dump({"workload_key": key, "hbm_bytes_per_step": hbm, "fetch_size_kb_per_step": round(F, 1),
                "write_size_kb_per_step": round(W, 1),
                "source": "profiles/r01/pmc_per_kernel.csv: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over "
                          "`bench.py --steps 20`; forward-pass launches of the last 10 steps; bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 "
