@@ -47,6 +47,7 @@ def parse():
     ap.add_argument("--max-det", type=int, default=100)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true")
+    ap.add_argument("--no-compare", action="store_true", help="skip the extra one-frame-per-stream run (profiler passes: one workload per process)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend: nccl (= RCCL, default) or gloo (rehearsal on a 1-GPU box)")
     ap.add_argument("--one-device", action="store_true", help="rehearsal only: every rank uses cuda:0")
@@ -243,7 +244,7 @@ def main():
     res["roofline"]["slowest_launches"] = [{"op": n, "ms": round(ms, 4), "tflops": round(fl / (ms * 1e-3) / 1e12, 1) if ms > 0 else 0} for n, ms, fl in top]
 
     # ---- the same workload without frame batching (one frame of every stream per launch set), for comparison ----
-    if F > 1 and world == 1 and not args.host_frames:
+    if F > 1 and world == 1 and not args.host_frames and not args.no_compare:
         det.close()
         m1 = measure(1, args.steps, args.warmup, collective=False)
         f1 = m1["fwd_ms"] / args.steps

@@ -12,7 +12,7 @@ export RTMODT_TUNE_CACHE=/tmp/rtmodt_tune_$R.txt
 rm -f $RTMODT_TUNE_CACHE
 python bench.py > $O/bench_default.json 2> $O/bench_default.log || exit 1
 echo "[collect] bench done"
-B="python3 bench.py --no-cpu-baseline --no-latency"
+B="python3 bench.py --no-cpu-baseline --no-latency --no-compare"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- $B --steps 100 --warmup 10 > $O/stats_bench.json 2> $O/stats.log || exit 1
 python tools/trace_gaps.py $O/stats/*/*_kernel_trace.csv 50 > $O/step_gaps.txt 2>&1
 rm -f $O/stats/*/*_kernel_trace.csv

@@ -15,14 +15,16 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--model", default="s")
 ap.add_argument("--size", type=int, default=640)
 ap.add_argument("--streams", type=int, default=8)
+ap.add_argument("--frames-per-stream", type=int, default=2)        # bench.py default: 16 frames per launch set
 ap.add_argument("--no-autotune", action="store_true")
 ap.add_argument("--iters", type=int, default=10)
 a = ap.parse_args()
 wpath = os.path.join(tempfile.gettempdir(), f"rtmodt_bench_yolov8{a.model}_{a.size}.rtw")
 if not os.path.exists(wpath):
     pkg.weights.save(wpath, pkg.weights.synthetic(a.model, input_size=a.size), a.model)
-det = pkg.Detector(wpath, input_size=(a.size, a.size), batch=a.streams, warmup=False, autotune=not a.no_autotune)
-frames = list(pkg.synth.frames(a.streams, a.size, a.size, seed=1))
+B = a.streams * a.frames_per_stream
+det = pkg.Detector(wpath, input_size=(a.size, a.size), batch=B, warmup=False, autotune=not a.no_autotune)
+frames = list(pkg.synth.frames(B, a.size, a.size, seed=1))
 det.detect_batch(frames)
 rows = det.profile(a.iters)
 tot = sum(ms for _, ms, _ in rows)
