@@ -44,6 +44,8 @@ struct ConvArgs {
     f16 *out2;                           // optional second destination: nearest-2x upsampled copy (neck concat slice)
     int out2_Hp, out2_Wp, out2_cs, out2_pad;
     int cin, cout, ks, stride, act, kp, K;
+    int epi16;                           // epilogue through LDS with 16-byte NHWC stores (all channel offsets / strides % 8 == 0):
+                                         // 1 = tile kernels, 2 = also the tap-reuse kernel
 };
 
 __device__ __forceinline__ float silu_f(float x) {
@@ -164,6 +166,67 @@ __device__ __forceinline__ int input_offset(const ConvArgs &p, int m) {
     return ((b * p.in_Hp + oy * p.stride + p.in_org) * p.in_Wp + ox * p.stride + p.in_org) * p.in_cs;
 }
 
+
+// Epilogue through LDS: the accumulator layout (lane = pixel r, 4 channels) stores 8 bytes per lane in 32-byte runs;
+// staged as a [pixel][channel] fp16 tile instead, every lane then moves 16 bytes and a wave instruction covers whole
+// cache lines of the NHWC output (and of the nearest-2x copy).  bias / SiLU / residual are applied on the way in, in
+// fp32, exactly as store_tile does -- the stored values are identical.  `lds` = the (drained) stage buffers.
+// pix(pm, opix, rpix, opix2) -> false for a row of the tile that is not an output pixel.
+template <int BM, int BN, int TM, int TN, typename PixFn>
+__device__ __forceinline__ void epilogue_lds(const ConvArgs &p, const int n0, const floatx4 (&acc)[TM][TN], const floatx4 (&bv)[TN],
+                                             unsigned char *lds, const int wm, const int wn, PixFn pix) {
+    constexpr int ROWB = BN * 2 + 16;                      // +16: the b64 writes of a 16-pixel group land in distinct banks
+    const int lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
+    __syncthreads();                                       // every wave is done reading the last stage
+#pragma unroll
+    for (int t = 0; t < TM; ++t) {
+        const int pm = (wm * TM + t) * 16 + r;
+        long opix = 0, rpix = 0, opix2 = 0;
+        const bool live = pix(pm, opix, rpix, opix2);
+#pragma unroll
+        for (int u = 0; u < TN; ++u) {
+            const int nl = (wn * TN + u) * 16 + q * 4;
+            floatx4 v = acc[t][u] + bv[u];
+            if (p.act) { v[0] = silu_f(v[0]); v[1] = silu_f(v[1]); v[2] = silu_f(v[2]); v[3] = silu_f(v[3]); }
+            if (p.res && live && n0 + nl < p.cout) {
+                half4 rv = *(const half4 *)(p.res + rpix + n0 + nl);
+                v[0] += (float)rv[0]; v[1] += (float)rv[1]; v[2] += (float)rv[2]; v[3] += (float)rv[3];
+            }
+            *(half4 *)(lds + pm * ROWB + nl * 2) = half4{(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
+        }
+    }
+    __syncthreads();
+    constexpr int CPR = BN / 8;                            // 16-byte chunks per pixel
+    for (int c = threadIdx.x; c < BM * CPR; c += 256) {
+        const int pm = c / CPR, k8 = c - pm * CPR, n = n0 + k8 * 8;
+        if (n >= p.cout) continue;
+        long opix, rpix, opix2;
+        if (!pix(pm, opix, rpix, opix2)) continue;
+        const unsigned char *src = lds + pm * ROWB + k8 * 16;
+        if (n + 8 <= p.cout) {
+            const half8 v = *(const half8 *)src;
+            *(half8 *)(p.out + opix + n) = v;
+            if (opix2 >= 0) {
+                const long row = (long)p.out2_Wp * p.out2_cs;
+                *(half8 *)(p.out2 + opix2 + n) = v;
+                *(half8 *)(p.out2 + opix2 + p.out2_cs + n) = v;
+                *(half8 *)(p.out2 + opix2 + row + n) = v;
+                *(half8 *)(p.out2 + opix2 + row + p.out2_cs + n) = v;
+            }
+        } else {                                           // cout % 8 == 4: the last chunk is half a chunk
+            const half4 v = *(const half4 *)src;
+            *(half4 *)(p.out + opix + n) = v;
+            if (opix2 >= 0) {
+                const long row = (long)p.out2_Wp * p.out2_cs;
+                *(half4 *)(p.out2 + opix2 + n) = v;
+                *(half4 *)(p.out2 + opix2 + p.out2_cs + n) = v;
+                *(half4 *)(p.out2 + opix2 + row + n) = v;
+                *(half4 *)(p.out2 + opix2 + row + p.out2_cs + n) = v;
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------
 // conv_mfma: block tile BM x BN shared by 4 waves (WM x WN), THREE LDS stages.  The DMA of
 // k-steps kt+1 and kt+2 is in flight while kt is multiplied: each step waits with a COUNTED
@@ -193,6 +256,7 @@ __device__ __forceinline__ void conv_mfma_body(const ConvArgs &p, const int bx, 
     static_assert(NSTAGE >= 2 && (LA + LBF + 1) * (DEPTH - 1) <= 63, "vmcnt is a 6-bit counter");
     constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
     __shared__ __attribute__((aligned(1024))) unsigned char lds[NSTAGE * STAGE];
+    static_assert(BM * (BN * 2 + 16) <= NSTAGE * STAGE, "the epilogue's fp16 tile must fit the stage buffers");
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -263,6 +327,10 @@ __device__ __forceinline__ void conv_mfma_body(const ConvArgs &p, const int bx, 
     }
 
     // ---- epilogue: D[row = cout (lane>>4)*4+j][col = pixel lane&15] ----
+    if (p.epi16) {
+        epilogue_lds<BM, BN, TM, TN>(p, n0, acc, bv, lds, wm, wn, [&](int pm, long &o, long &rp, long &o2) { return pixel_offsets(p, m0 + pm, o, rp, o2); });
+        return;
+    }
 #pragma unroll
     for (int t = 0; t < TM; ++t) {
         long opix, rpix, opix2;
@@ -293,6 +361,7 @@ __device__ __forceinline__ void conv_mfma64_body(const ConvArgs &p, const int bx
     constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
     static_assert((LA + LBp) * (DEPTH > 1 ? DEPTH - 1 : 1) <= 63, "vmcnt is a 6-bit counter");
     __shared__ __attribute__((aligned(1024))) unsigned char lds[NSTAGE * STAGE];
+    static_assert(BM * (BN * 2 + 16) <= NSTAGE * STAGE, "the epilogue's fp16 tile must fit the stage buffers");
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -370,6 +439,10 @@ __device__ __forceinline__ void conv_mfma64_body(const ConvArgs &p, const int bx
         }
     }
 
+    if (p.epi16) {
+        epilogue_lds<BM, BN, TM, TN>(p, n0, acc, bv, lds, wm, wn, [&](int pm, long &o, long &rp, long &o2) { return pixel_offsets(p, m0 + pm, o, rp, o2); });
+        return;
+    }
 #pragma unroll
     for (int t = 0; t < TM; ++t) {
         long opix, rpix, opix2;
@@ -407,6 +480,7 @@ __device__ __forceinline__ void conv3x3_rows_body(const ConvArgs &p, const int b
     constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
     constexpr int TILE_BYTES = 16 * RB;            // LDS bytes of a 16-row operand tile
     __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * STAGE];
+    static_assert(BM * (BN * 2 + 16) <= 2 * STAGE, "the epilogue's fp16 tile must fit the stage buffers");
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -510,6 +584,20 @@ __device__ __forceinline__ void conv3x3_rows_body(const ConvArgs &p, const int b
 
     // ---- epilogue: padded position -> (b, y, x); border rows/columns are junk ----
     const int HW = p.in_Hp * p.in_Wp;
+    if (p.epi16 > 1) {                                     // measured: the extra LDS round trip costs this MFMA-heavier kernel more than its stores do
+        epilogue_lds<BM, BN, TM, TN>(p, n0, acc, bv, lds, wm, wn, [&](int pm, long &opix, long &rpix, long &opix2) {
+            const int m = m0 + pm;
+            if (m >= Mp) return false;
+            const int b = m / HW, rem = m - b * HW;
+            const int oy = rem / p.in_Wp, ox = rem - oy * p.in_Wp;
+            if (oy >= p.Ho || ox >= p.Wo) return false;
+            opix = ((long)(b * p.out_Hp + oy + p.out_pad) * p.out_Wp + ox + p.out_pad) * p.out_cs;
+            rpix = p.res ? ((long)(b * p.res_Hp + oy + p.res_pad) * p.res_Wp + ox + p.res_pad) * p.res_cs : 0;
+            opix2 = upsampled_offset(p, b, oy, ox);
+            return true;
+        });
+        return;
+    }
 #pragma unroll
     for (int t = 0; t < TM; ++t) {
         int m = m0 + (wm * TM + t) * 16 + r;
@@ -795,6 +883,8 @@ static int make_args(const ConvLaunch &c, ConvArgs &a) {
     a.cin = c.cin; a.cout = c.cout; a.ks = c.ks; a.stride = c.stride; a.act = c.act;
     a.K = c.ks * c.ks * c.cin;
     a.kp = c.kp;
+    a.epi16 = c.out.coff % 8 == 0 && c.out.C % 8 == 0 && (!c.out2.base || (c.out2.coff % 8 == 0 && c.out2.C % 8 == 0)) &&
+              (!c.res.base || (c.res.coff % 4 == 0)) ? c.epilogue : 0;
     RT_CHECK(a.kp % 32 == 0 && a.kp >= a.K, RTMODT_E_INVALID, "launch_conv: kp %d for K %d", a.kp, a.K);
     // 32-bit element offsets inside the kernel
     RT_CHECK((long)c.B * a.in_Hp * a.in_Wp * a.in_cs < (1L << 31) && (long)c.B * a.out_Hp * a.out_Wp * a.out_cs < (1L << 31),

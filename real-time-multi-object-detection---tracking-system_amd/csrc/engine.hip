@@ -349,6 +349,7 @@ static int make_conv(rtmodt_detector *d, WeightFile &wf, const std::vector<std::
     c.in = in; c.out = out; if (res) c.res = *res;
     c.wt = (const f16 *)dw; c.bias = (const float *)db;
     c.B = d->B; c.cin = r0.cin; c.cout = cout_eff; c.ks = r0.k; c.stride = r0.stride; c.act = r0.act; c.kp = kp;
+    if (const char *e = getenv("RTMODT_EPI16")) c.epilogue = atoi(e);      // A/B and test hook
     int M = d->B * out.H * out.W;
     c.tile = pick_tile(M, cout_eff);
     if (const char *e = getenv("RTMODT_TILE_3X3S1")) {          // test hook: force a tap-reuse tile wherever it is legal

@@ -46,6 +46,7 @@ struct ConvLaunch {
     int cin = 0, cout = 0, ks = 1, stride = 1, act = 1;
     int kp = 0;                   // weight row stride (K rounded up to 32)
     int tile = TILE_128x128;
+    int epilogue = 1;             // 0: 8-byte stores from the accumulator layout; 1: 16-byte stores through LDS in the tile kernels; 2: also in the tap-reuse kernel
 };
 
 int launch_conv(const ConvLaunch &c, hipStream_t s);

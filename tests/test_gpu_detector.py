@@ -537,3 +537,25 @@ def test_frame_batching_keeps_tracker_order(pkg, wdir, monkeypatch, F):
     with pytest.raises(pkg._ffi.RtmodtError):
         core_b.update_from_detector(big, S * F - 1, S)          # slice runs past the batch
     buf.free(); big.close(); one.close()
+
+
+def test_epilogue_variants_store_identical_values(pkg, wdir, monkeypatch):
+    """The conv epilogue either stores 8 bytes per lane straight from the MFMA accumulator layout (0) or stages the
+    fp16 tile in LDS and stores 16 bytes per lane (1: tile kernels -- the default; 2: also the 3x3 tap-reuse kernel,
+    forced here).  bias / SiLU / residual / nearest-2x copy happen in fp32 before the single rounding in all of them,
+    so every layer must be bit-identical."""
+    monkeypatch.setenv("RTMODT_BNECK", "0")
+    monkeypatch.setenv("RTMODT_TILE_3X3S1", "22")
+    frames = list(pkg.synth.frames(2, 320, 320, seed=61))
+    names = [c.name for c in pkg.weights.spec("s")]
+    outs = {}
+    for mode in ("0", "1", "2"):
+        monkeypatch.setenv("RTMODT_EPI16", mode)
+        det, _ = make_detector(pkg, wdir, "s", 320, autotune=False, batch=2)
+        det.detect_batch(frames)
+        outs[mode] = [fetch_layers(pkg, det, names, i) for i in range(2)]
+        det.close()
+    for mode in ("1", "2"):
+        for i in range(2):
+            for n in outs["0"][i]:
+                assert np.array_equal(outs["0"][i][n].view(np.uint16), outs[mode][i][n].view(np.uint16)), (mode, i, n)
