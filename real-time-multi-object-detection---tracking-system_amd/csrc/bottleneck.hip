@@ -213,26 +213,39 @@ __global__ __launch_bounds__(BN_THREADS) void bottleneck_fused(BneckArgs p) {
 #pragma unroll
             for (int u = 0; u < NT; ++u) acc[i][u] = *(const floatx4 *)(p.b2 + u * 16 + q * 4);
         gemm_from_lds<G, G::TM2, G::IW, G::T_ROWS>(tbuf, wring, p.w2, p.kp, pb, acc, lane, wave);
+        // epilogue 2: SiLU (+ residual) in fp32, one rounding, staged as a [pixel][channel] fp16 tile in the (dead) patch
+        // region so that every lane then stores 16 bytes -- whole cache lines of the NHWC output per wave instruction
+        constexpr int ROWB = CH * 2 + 16;
+        static_assert(G::M2 * ROWB <= G::PATCH_BYTES, "output tile must fit the patch region");
 #pragma unroll
         for (int i = 0; i < G::TM2; ++i) {
             const int m = mrow[i];
             if (m < 0) continue;
             const int oy = m / TW, ox = m - oy * TW;
             const int gy = y0 + oy, gx = x0 + ox;
-            if (gy >= p.H || gx >= p.W) continue;
-            const long opix = ((long)(b * p.out_Hp + gy + p.out_pad) * p.out_Wp + gx + p.out_pad) * p.out_cs;
-            const long rpix = p.res ? ((long)(b * p.res_Hp + gy + p.res_pad) * p.res_Wp + gx + p.res_pad) * p.res_cs : 0;
+            const bool live = gy < p.H && gx < p.W;
+            const long rpix = (p.res && live) ? ((long)(b * p.res_Hp + gy + p.res_pad) * p.res_Wp + gx + p.res_pad) * p.res_cs : 0;
 #pragma unroll
             for (int u = 0; u < NT; ++u) {
                 const int n = u * 16 + q * 4;
                 floatx4 v = acc[i][u];
                 v[0] = silu_b(v[0]); v[1] = silu_b(v[1]); v[2] = silu_b(v[2]); v[3] = silu_b(v[3]);
-                if (p.res) {
+                if (p.res && live) {
                     half4 rv = *(const half4 *)(p.res + rpix + n);
                     v[0] += (float)rv[0]; v[1] += (float)rv[1]; v[2] += (float)rv[2]; v[3] += (float)rv[3];
                 }
-                *(half4 *)(p.out + opix + n) = half4{(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
+                *(half4 *)(patch + m * ROWB + n * 2) = half4{(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
             }
+        }
+        __syncthreads();
+        constexpr int CPR = CH / 8;
+        for (int c = threadIdx.x; c < G::M2 * CPR; c += BN_THREADS) {
+            const int m = c / CPR, k8 = c - m * CPR;
+            const int oy = m / TW, ox = m - oy * TW;
+            const int gy = y0 + oy, gx = x0 + ox;
+            if (gy >= p.H || gx >= p.W) continue;
+            const long opix = ((long)(b * p.out_Hp + gy + p.out_pad) * p.out_Wp + gx + p.out_pad) * p.out_cs;
+            *(half8 *)(p.out + opix + k8 * 8) = *(const half8 *)(patch + m * ROWB + k8 * 16);
         }
     }
 }
@@ -261,7 +274,7 @@ int launch_bottleneck(const BottleneckLaunch &l, hipStream_t s) {
     RT_CHECK(bottleneck_supported(l.c), RTMODT_E_UNSUPPORTED, "launch_bottleneck: %d channels", l.c);
     RT_CHECK(in.pad == 1 && in.c == l.c && out.c == l.c && in.H == out.H && in.W == out.W && l.kp == 9 * l.c, RTMODT_E_INVALID,
              "launch_bottleneck: shapes");
-    RT_CHECK(in.coff % 8 == 0 && in.C % 8 == 0 && out.coff % 4 == 0 && out.C % 4 == 0 && l.zeros, RTMODT_E_INVALID, "launch_bottleneck: alignment");
+    RT_CHECK(in.coff % 8 == 0 && in.C % 8 == 0 && out.coff % 8 == 0 && out.C % 8 == 0 && l.zeros, RTMODT_E_INVALID, "launch_bottleneck: alignment");
     BneckArgs a{};
     a.in = in.base + in.coff; a.w1 = l.w1; a.w2 = l.w2; a.b1 = l.b1; a.b2 = l.b2; a.zeros = l.zeros;
     a.out = out.base + out.coff;
