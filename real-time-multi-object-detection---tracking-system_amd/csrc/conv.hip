@@ -3,24 +3,32 @@
 // What they replace: the ATen/cuDNN kernels `ultralytics.YOLO.predict` runs for the call at
 // /root/reference/src/detection/detector.py:100-111.
 //
-//  * conv_mfma  -- fused Conv(+folded BN)+bias+SiLU(+residual) as an implicit GEMM on the
-//                  matrix cores (v_mfma_f32_16x16x32_f16, fp32 accumulate).  NHWC fp16,
-//                  K order (kh, kw, cin).  Both operands are K-contiguous, so each 16-row x
-//                  32-k block of either operand is ONE 1-KiB LDS-DMA piece
-//                  (global_load_lds_dwordx4: per-lane global source, lane-linear LDS image)
-//                  that a wave later reads back with one conflict-free ds_read_b128 at
-//                  lane*16 -- no VGPR staging, no ds_write, no bank conflicts by construction.
-//                  Two LDS stages, one barrier per 32-deep k-step; the DMA of step k+1 flies
-//                  under the MFMAs of step k.  Weights are the MFMA "A" operand (rows =
-//                  cout) and pixels the "B" operand (cols = pixel), so a lane ends up holding
-//                  4 consecutive output channels of one pixel: an 8-byte NHWC store.
-//                  Input halo comes from the tensors' zero border (kernels.h) -- no bounds
-//                  checks in the k-loop.  Channel-slice views make C2f split/concat, the
-//                  neck concats and the Detect-head fusion copy-free.
-//  * stem_conv  -- 3->cout 3x3/s2 conv (K = 27, too thin for MFMA): one thread per output
-//                  pixel, weights wave-uniform (scalar loads), fp32 accumulate.
-//  * sppf_pool  -- the three chained 5x5 max-pools of SPPF as 5/9/13 windows from one LDS tile.
-//  * upsample2  -- nearest 2x into a channel slice of the concat tensor.
+//  All convs are fused Conv(+folded BN)+bias+SiLU(+residual)(+nearest-2x copy) implicit GEMMs on the
+//  matrix cores (v_mfma_f32_16x16x32_f16, fp32 accumulate), NHWC fp16, K order (kh, kw, cin).
+//  Weights are the MFMA "A" operand (rows = cout) and pixels the "B" operand (cols = pixel), so a
+//  lane ends up holding 4 consecutive output channels of one pixel.  Both operands are
+//  K-contiguous and travel global -> LDS by LDS-DMA (global_load_lds_dwordx4: per-lane global
+//  source, lane-linear LDS image) in 1-KiB pieces of whole rows (16 x 64 B or 8 x 128 B), XOR
+//  swizzled on the SOURCE address so that every fragment read is a conflict-free ds_read_b128;
+//  counted s_waitcnt vmcnt(N) + raw s_barrier per k-step, never vmcnt(0) inside a ring.  Input halo
+//  comes from the tensors' zero border (kernels.h) -- no bounds checks in the k-loop.  Channel-slice
+//  views make C2f split/concat, the neck concats and the Detect-head fusion copy-free.
+//
+//  * conv_mfma      -- block tile BM x BN, 32-deep k-steps, NSTAGE-deep ring (any cin % 8 == 0).
+//  * conv_mfma64    -- the same with 64-deep k-steps (cin % 64 == 0): one barrier per 64 of K.
+//  * conv3x3_rows   -- 3x3 / stride 1 with TAP REUSE: the GEMM runs over padded positions so one
+//                      strip of input rows in LDS serves the three horizontal taps.
+//  * conv_mfma_wsk  -- the 4 waves split K over one tile (small-M layers), LDS reduction.
+//  * epilogue_lds   -- bias / SiLU / residual in fp32, one rounding, fp16 tile staged in the drained
+//                      stage buffers, 16-byte NHWC stores (tile kernels; the rows kernel stores directly).
+//  * *_grp          -- up to 6 independent problems sharing a tile configuration in ONE launch (Detect head).
+//  * xcd_tile       -- workgroup id remap so that the tiles one XCD (one L2) works on are neighbours.
+//  * stem_mfma / stem_fused -- 3->cout 3x3/s2 conv with K re-indexed kh*16 + kw*4 + c (two MFMA
+//                      k-steps of adjacent-pixel pairs); stem_fused builds those pairs from the BGR
+//                      bytes of the frame itself (letterbox, BGR->RGB, /255, .half() folded in).
+//  * sppf_pool      -- the three chained 5x5 max-pools of SPPF as 5/9/13 windows from one LDS tile.
+//  * upsample2      -- nearest 2x into a channel slice of the concat tensor (only when the producer
+//                      cannot fold the copy into its epilogue).
 #include <algorithm>
 
 #include "kernels.h"

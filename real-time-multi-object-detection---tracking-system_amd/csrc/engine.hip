@@ -746,12 +746,19 @@ static int autotune_ops(rtmodt_detector *d, std::vector<Op> &ops) {
 
 static int autotune_tiles(rtmodt_detector *d) {
     RT_TRY(autotune_ops(d, d->ops));
+    // the tuner's decisions travel from the op it timed to the copies that run
+    auto adopt = [](Op &dst, const Op &src) {
+        dst.conv.tile = src.conv.tile;
+        dst.group_tile = src.group_tile;
+        dst.fused = src.fused;
+        for (size_t g = 0; g < dst.group.size(); ++g) dst.group[g].tile = src.group[g].tile;
+    };
     if (d->n_chains > 1) {
         RT_TRY(autotune_ops(d, d->chain_ops[0]));          // the sub-batch GEMMs have their own best tiles
         for (int c = 1; c < d->n_chains; ++c)
-            for (size_t i = 0; i < d->ops.size(); ++i) { d->chain_ops[c][i].conv.tile = d->chain_ops[0][i].conv.tile; d->chain_ops[c][i].group_tile = d->chain_ops[0][i].group_tile; d->chain_ops[c][i].fused = d->chain_ops[0][i].fused; for (size_t g = 0; g < d->chain_ops[c][i].group.size(); ++g) d->chain_ops[c][i].group[g].tile = d->chain_ops[0][i].group[g].tile; }
+            for (size_t i = 0; i < d->ops.size(); ++i) adopt(d->chain_ops[c][i], d->chain_ops[0][i]);
     } else {
-        for (size_t i = 0; i < d->ops.size(); ++i) { d->chain_ops[0][i].conv.tile = d->ops[i].conv.tile; d->chain_ops[0][i].group_tile = d->ops[i].group_tile; d->chain_ops[0][i].fused = d->ops[i].fused; for (size_t g = 0; g < d->ops[i].group.size(); ++g) d->chain_ops[0][i].group[g].tile = d->ops[i].group[g].tile; }
+        for (size_t i = 0; i < d->ops.size(); ++i) adopt(d->chain_ops[0][i], d->ops[i]);
     }
     // the tuning launches left stale activations; run one clean pass
     RT_TRY(forward_eager_all(d));
