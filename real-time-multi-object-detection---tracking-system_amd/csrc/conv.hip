@@ -52,6 +52,10 @@ struct ConvArgs {
     f16 *out2;                           // optional second destination: nearest-2x upsampled copy (neck concat slice)
     int out2_Hp, out2_Wp, out2_cs, out2_pad;
     int cin, cout, ks, stride, act, kp, K;
+    // optional fused TAIL: a 1x1 conv (+bias +SiLU) applied to this conv's output tile while it sits in LDS; only the
+    // tail's output is stored (the tile kernels with BN == cout, TAIL instantiations)
+    const f16 *t_wt; const float *t_bias; f16 *t_out;
+    int t_cout, t_kp, t_act, t_out_Hp, t_out_Wp, t_out_cs, t_out_pad;
     int epi16;                           // epilogue through LDS with 16-byte NHWC stores (all channel offsets / strides % 8 == 0):
                                          // 1 = tile kernels, 2 = also the tap-reuse kernel
 };
@@ -235,6 +239,96 @@ __device__ __forceinline__ void epilogue_lds(const ConvArgs &p, const int n0, co
     }
 }
 
+
+// Epilogue with a fused 1x1 TAIL conv (conv -> C2f.cv1 pairs of the backbone): the fp16 tile of this conv's output
+// (all cout channels of BM pixels: BN == cout) is staged in LDS exactly as epilogue_lds does, the tail's weights
+// [t_cout][cout] arrive by DMA next to it, every wave multiplies its BM/64 pixel tiles by them, and the tail's
+// output tile replaces the first one in LDS on its way to 16-byte stores.  The intermediate tensor never exists in
+// HBM (one launch, one store and one load less per pair).  N2T = cout tiles of the tail (t_cout <= 16 * N2T).
+template <int BM, int BN, int TM, int TN, int N2T, typename PixFn>
+__device__ __forceinline__ void epilogue_tail(const ConvArgs &p, const floatx4 (&acc)[TM][TN], const floatx4 (&bv)[TN], unsigned char *lds,
+                                              const int wm, const int wn, PixFn pix) {
+    constexpr int ROWB = BN * 2 + 16, KC2 = BN / 32, TM2 = BM / 64;
+    constexpr int W2_OFF = (BM * ROWB + 1023) / 1024 * 1024;
+    const int lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const LaneMap lm(lane);
+    __syncthreads();                                       // every wave is done reading the last stage
+    for (int pi = wave; pi < N2T * KC2; pi += 4) {         // piece (k-chunk kc, cout tile u) of the tail's weights
+        const int kc = pi / N2T, u = pi - kc * N2T;
+        glds16(p.t_wt + ((u * 16 + lm.ld_row) * p.t_kp + kc * 32 + lm.ld_chunk * 8), lds + W2_OFF + pi * 1024);
+    }
+#pragma unroll
+    for (int t = 0; t < TM; ++t) {                         // this conv's tile -> LDS (bias, SiLU in fp32, one rounding)
+        const int pm = (wm * TM + t) * 16 + r;
+#pragma unroll
+        for (int u = 0; u < TN; ++u) {
+            const int nl = (wn * TN + u) * 16 + q * 4;
+            floatx4 v = acc[t][u] + bv[u];
+            if (p.act) { v[0] = silu_f(v[0]); v[1] = silu_f(v[1]); v[2] = silu_f(v[2]); v[3] = silu_f(v[3]); }
+            *(half4 *)(lds + pm * ROWB + nl * 2) = half4{(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
+        }
+    }
+    floatx4 acc2[TM2][N2T], b2[N2T];
+#pragma unroll
+    for (int u = 0; u < N2T; ++u) {
+        b2[u] = *(const floatx4 *)(p.t_bias + u * 16 + q * 4);                 // padded to 128 entries; added after the sum like store_tile does
+#pragma unroll
+        for (int i = 0; i < TM2; ++i) acc2[i][u] = floatx4{0.f, 0.f, 0.f, 0.f};
+    }
+    wait_vmcnt<0>();
+    __syncthreads();                                       // tile and weights complete
+#pragma unroll
+    for (int kc = 0; kc < KC2; ++kc) {
+        half8 fa[TM2], fb[N2T];
+#pragma unroll
+        for (int i = 0; i < TM2; ++i) fa[i] = *(const half8 *)(lds + ((wave + 4 * i) * 16 + r) * ROWB + (kc * 4 + q) * 16);
+#pragma unroll
+        for (int u = 0; u < N2T; ++u) fb[u] = *(const half8 *)(lds + W2_OFF + (kc * N2T + u) * 1024 + lm.rd_off);
+#pragma unroll
+        for (int i = 0; i < TM2; ++i)
+#pragma unroll
+            for (int u = 0; u < N2T; ++u) acc2[i][u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[u], fa[i], acc2[i][u], 0, 0, 0);
+    }
+    __syncthreads();                                       // everyone is done reading the first tile
+    constexpr int ROWB2 = N2T * 32 + 16;
+#pragma unroll
+    for (int i = 0; i < TM2; ++i) {
+        const int pm = (wave + 4 * i) * 16 + r;
+#pragma unroll
+        for (int u = 0; u < N2T; ++u) {
+            floatx4 v = acc2[i][u] + b2[u];
+            if (p.t_act) { v[0] = silu_f(v[0]); v[1] = silu_f(v[1]); v[2] = silu_f(v[2]); v[3] = silu_f(v[3]); }
+            *(half4 *)(lds + pm * ROWB2 + (u * 16 + q * 4) * 2) = half4{(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
+        }
+    }
+    __syncthreads();
+    constexpr int CPR = N2T * 2;                           // 16-byte chunks per pixel of the tail's tile
+    for (int c = threadIdx.x; c < BM * CPR; c += 256) {
+        const int pm = c / CPR, k8 = c - pm * CPR, n = k8 * 8;
+        if (n >= p.t_cout) continue;
+        long opix;
+        if (!pix(pm, opix)) continue;
+        *(half8 *)(p.t_out + opix + n) = *(const half8 *)(lds + pm * ROWB2 + k8 * 16);
+    }
+}
+
+
+template <int BM, int BN, int N2T>
+constexpr int tail_lds_bytes() {
+    constexpr int ROWB = BN * 2 + 16, W2_OFF = (BM * ROWB + 1023) / 1024 * 1024;
+    constexpr int a = W2_OFF + N2T * (BN / 32) * 1024, b = BM * (N2T * 32 + 16);
+    return a > b ? a : b;
+}
+__device__ __forceinline__ bool tail_pixel_offset(const ConvArgs &p, int m, long &opix) {
+    if (m >= p.M) return false;
+    const int HoWo = p.Ho * p.Wo;
+    const int b = m / HoWo, rem = m - b * HoWo;
+    const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+    opix = ((long)(b * p.t_out_Hp + oy + p.t_out_pad) * p.t_out_Wp + ox + p.t_out_pad) * p.t_out_cs;
+    return true;
+}
+
 // ---------------------------------------------------------------------------------------
 // conv_mfma: block tile BM x BN shared by 4 waves (WM x WN), THREE LDS stages.  The DMA of
 // k-steps kt+1 and kt+2 is in flight while kt is multiplied: each step waits with a COUNTED
@@ -251,7 +345,7 @@ __device__ __forceinline__ void wait_steps(int steps) {
     }
 }
 
-template <int BM, int BN, int WM, int WN, int NSTAGE, bool GENERAL>
+template <int BM, int BN, int WM, int WN, int NSTAGE, bool GENERAL, int N2T = 0>
 __device__ __forceinline__ void conv_mfma_body(const ConvArgs &p, const int bx, const int by) {
     static_assert(WM * WN == 4, "4 waves per workgroup");
     static_assert(BM % 64 == 0 && BN % 16 == 0, "tile shape");
@@ -263,7 +357,8 @@ __device__ __forceinline__ void conv_mfma_body(const ConvArgs &p, const int bx, 
     constexpr int STAGE = NRB * 1024;
     static_assert(NSTAGE >= 2 && (LA + LBF + 1) * (DEPTH - 1) <= 63, "vmcnt is a 6-bit counter");
     constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
-    __shared__ __attribute__((aligned(1024))) unsigned char lds[NSTAGE * STAGE];
+    constexpr int TAIL_BYTES = N2T > 0 ? tail_lds_bytes<BM, BN, N2T>() : 0;
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[NSTAGE * STAGE > TAIL_BYTES ? NSTAGE * STAGE : TAIL_BYTES];
     static_assert(BM * (BN * 2 + 16) <= NSTAGE * STAGE, "the epilogue's fp16 tile must fit the stage buffers");
 
     const int lane = threadIdx.x & 63;
@@ -335,6 +430,10 @@ __device__ __forceinline__ void conv_mfma_body(const ConvArgs &p, const int bx, 
     }
 
     // ---- epilogue: D[row = cout (lane>>4)*4+j][col = pixel lane&15] ----
+    if constexpr (N2T > 0) {
+        epilogue_tail<BM, BN, TM, TN, N2T>(p, acc, bv, lds, wm, wn, [&](int pm, long &o) { return tail_pixel_offset(p, m0 + pm, o); });
+        return;
+    }
     if (p.epi16) {
         epilogue_lds<BM, BN, TM, TN>(p, n0, acc, bv, lds, wm, wn, [&](int pm, long &o, long &rp, long &o2) { return pixel_offsets(p, m0 + pm, o, rp, o2); });
         return;
@@ -358,7 +457,7 @@ __device__ __forceinline__ void conv_mfma_body(const ConvArgs &p, const int bx, 
 // one barrier per 64 of K.  Chunk c (0..7) of row r sits in slot c ^ ((r>>1)&7): conflict-free
 // ds_read_b128 for both k-substeps.
 // ---------------------------------------------------------------------------------------
-template <int BM, int BN, int WM, int WN, int NSTAGE>
+template <int BM, int BN, int WM, int WN, int NSTAGE, int N2T = 0>
 __device__ __forceinline__ void conv_mfma64_body(const ConvArgs &p, const int bx, const int by) {
     static_assert(WM * WN == 4, "4 waves per workgroup");
     static_assert(BM % 32 == 0 && BN % 32 == 0, "tile shape");
@@ -368,7 +467,8 @@ __device__ __forceinline__ void conv_mfma64_body(const ConvArgs &p, const int bx
     constexpr int STAGE = NP * 1024;
     constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
     static_assert((LA + LBp) * (DEPTH > 1 ? DEPTH - 1 : 1) <= 63, "vmcnt is a 6-bit counter");
-    __shared__ __attribute__((aligned(1024))) unsigned char lds[NSTAGE * STAGE];
+    constexpr int TAIL_BYTES = N2T > 0 ? tail_lds_bytes<BM, BN, N2T>() : 0;
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[NSTAGE * STAGE > TAIL_BYTES ? NSTAGE * STAGE : TAIL_BYTES];
     static_assert(BM * (BN * 2 + 16) <= NSTAGE * STAGE, "the epilogue's fp16 tile must fit the stage buffers");
 
     const int lane = threadIdx.x & 63;
@@ -447,6 +547,10 @@ __device__ __forceinline__ void conv_mfma64_body(const ConvArgs &p, const int bx
         }
     }
 
+    if constexpr (N2T > 0) {
+        epilogue_tail<BM, BN, TM, TN, N2T>(p, acc, bv, lds, wm, wn, [&](int pm, long &o) { return tail_pixel_offset(p, m0 + pm, o); });
+        return;
+    }
     if (p.epi16) {
         epilogue_lds<BM, BN, TM, TN>(p, n0, acc, bv, lds, wm, wn, [&](int pm, long &o, long &rp, long &o2) { return pixel_offsets(p, m0 + pm, o, rp, o2); });
         return;
@@ -732,6 +836,10 @@ __global__ __launch_bounds__(256) void conv_mfma_grp(ConvGroupArgs g) {
     if ((int)blockIdx.x * BM >= p.M || (int)blockIdx.y * BN >= p.cout) return;
     conv_mfma_body<BM, BN, WM, WN, NSTAGE, GENERAL>(p, blockIdx.x, blockIdx.y);
 }
+template <int BM, int BN, int WM, int WN, int NSTAGE, int N2T>
+__global__ __launch_bounds__(256) void conv_mfma_tail(ConvArgs p) { conv_mfma_body<BM, BN, WM, WN, NSTAGE, false, N2T>(p, blockIdx.x, blockIdx.y); }
+template <int BM, int BN, int WM, int WN, int NSTAGE, int N2T>
+__global__ __launch_bounds__(256) void conv_mfma64_tail(ConvArgs p) { conv_mfma64_body<BM, BN, WM, WN, NSTAGE, N2T>(p, blockIdx.x, blockIdx.y); }
 template <int BM, int BN, int WM, int WN, int NSTAGE>
 __global__ __launch_bounds__(256) void conv_mfma64(ConvArgs p) { conv_mfma64_body<BM, BN, WM, WN, NSTAGE>(p, blockIdx.x, blockIdx.y); }
 template <int BM, int BN, int WM, int WN, int NSTAGE>
@@ -761,12 +869,17 @@ const char *tile_name(int tile) {
     static const char *names[TILE_COUNT] = {"128x128s3", "128x64s3", "64x64s3", "256x32s3", "64x128s3", "wsk64x64", "wsk32x64", "wsk64x32",
                                             "128x128s4", "128x64s5", "64x64s6", "64x128s5", "128x128s6",
                                             "k64:128x128s2", "k64:128x128s3", "k64:128x64s3", "k64:64x128s3", "k64:64x64s3", "k64:64x64s4", "k64:256x64s2", "k64:256x128s2", "k64:128x128s2w",
-                                            "rows:128x64", "rows:256x32", "rows:128x32", "rows64:128x64", "rows64:128x128", "rows64:64x64", "rows64:256x64"};
+                                            "rows:128x64", "rows:256x32", "rows:128x32", "rows64:128x64", "rows64:128x128", "rows64:64x64", "rows64:256x64",
+                                            "tail:128x64", "tail:64x64", "tail:k64:128x128", "tail:k64:64x128"};
     return tile >= 0 && tile < TILE_COUNT ? names[tile] : "?";
 }
 
-bool tile_needs_cin64(int tile) { return (tile >= TILE_K64_128x128_S2 && tile <= TILE_K64_128x128_S2W) || tile >= TILE_ROWS_K64_128x64; }
-bool tile_is_rows(int tile) { return tile >= TILE_ROWS_128x64 && tile < TILE_COUNT; }
+bool tile_needs_cin64(int tile) {
+    return (tile >= TILE_K64_128x128_S2 && tile <= TILE_K64_128x128_S2W) || (tile >= TILE_ROWS_K64_128x64 && tile <= TILE_ROWS_K64_256x64) ||
+           tile == TILE_TAIL_K64_128x128 || tile == TILE_TAIL_K64_64x128;
+}
+bool tile_is_tail(int tile) { return tile >= TILE_TAIL_128x64 && tile <= TILE_TAIL_K64_64x128; }
+bool tile_is_rows(int tile) { return tile >= TILE_ROWS_128x64 && tile <= TILE_ROWS_K64_256x64; }
 
 TileShape tile_shape(int tile) {
     switch (tile) {
@@ -795,6 +908,10 @@ TileShape tile_shape(int tile) {
         case TILE_ROWS_K64_128x128: return {128, 128};
         case TILE_ROWS_K64_64x64: return {64, 64};
         case TILE_ROWS_K64_256x64: return {256, 64};
+        case TILE_TAIL_128x64: return {128, 64};
+        case TILE_TAIL_64x64: return {64, 64};
+        case TILE_TAIL_K64_128x128: return {128, 128};
+        case TILE_TAIL_K64_64x128: return {64, 128};
     }
     return {0, 0};
 }
@@ -859,6 +976,9 @@ static void launch_wsk(const LaunchPlan &l, hipStream_t s) {
 
 static int make_args(const ConvLaunch &c, ConvArgs &a) {
     RT_CHECK(c.in.base && c.out.base && c.wt && c.bias, RTMODT_E_INVALID, "launch_conv: null operand");
+    // a view that still holds an arena OFFSET instead of a device address (engine.hip rebases them once) must never reach a kernel
+    for (const TensorView *v : {&c.in, &c.out, &c.res, &c.out2, &c.tail_out})
+        RT_CHECK(!v->base || (uintptr_t)v->base >= (1ull << 32), RTMODT_E_INVALID, "launch_conv: view base %p is not a device address", (void *)v->base);
     RT_CHECK(c.ks == 1 || c.ks == 3, RTMODT_E_INVALID, "launch_conv: kernel size %d", c.ks);
     RT_CHECK(c.cin % 8 == 0 && c.cout % 4 == 0, RTMODT_E_INVALID, "launch_conv: cin %d / cout %d granularity", c.cin, c.cout);
     RT_CHECK(c.in.pad >= c.ks / 2, RTMODT_E_INVALID, "launch_conv: input border %d < %d", c.in.pad, c.ks / 2);
@@ -891,6 +1011,9 @@ static int make_args(const ConvLaunch &c, ConvArgs &a) {
     a.cin = c.cin; a.cout = c.cout; a.ks = c.ks; a.stride = c.stride; a.act = c.act;
     a.K = c.ks * c.ks * c.cin;
     a.kp = c.kp;
+    a.t_wt = c.tail_wt; a.t_bias = c.tail_bias; a.t_out = c.tail_wt ? c.tail_out.base + c.tail_out.coff : nullptr;
+    a.t_cout = c.tail_cout; a.t_kp = c.tail_kp; a.t_act = c.tail_act;
+    a.t_out_Hp = c.tail_out.H + 2 * c.tail_out.pad; a.t_out_Wp = c.tail_out.W + 2 * c.tail_out.pad; a.t_out_cs = c.tail_out.C; a.t_out_pad = c.tail_out.pad;
     a.epi16 = c.out.coff % 8 == 0 && c.out.C % 8 == 0 && (!c.out2.base || (c.out2.coff % 8 == 0 && c.out2.C % 8 == 0)) &&
               (!c.res.base || (c.res.coff % 4 == 0)) ? c.epilogue : 0;
     RT_CHECK(a.kp % 32 == 0 && a.kp >= a.K, RTMODT_E_INVALID, "launch_conv: kp %d for K %d", a.kp, a.K);
@@ -919,6 +1042,16 @@ int launch_conv_group(const ConvLaunch *c, int n, int tile, hipStream_t s) {
             a[i].M = c[i].B * a[i].in_Hp * a[i].in_Wp;       // the GEMM runs over padded positions
             RT_CHECK((long)a[i].M * a[i].in_cs < (1L << 31) && a[i].M < (1 << 28), RTMODT_E_INVALID, "launch_conv: tensor exceeds 2^31 elements");
         }
+    }
+    if (tile_is_tail(tile)) {
+        const TileShape ts = tile_shape(tile);
+        const int n2max = ts.bn == 64 ? 64 : 128;
+        RT_CHECK(n == 1 && !general && c[0].tail_wt && c[0].tail_bias && c[0].tail_out.base, RTMODT_E_INVALID, "launch_conv: tile %s needs one conv with a tail", tile_name(tile));
+        RT_CHECK(c[0].cout == ts.bn && c[0].tail_kp == c[0].cout && c[0].tail_cout >= 8 && c[0].tail_cout <= n2max && c[0].tail_cout % 8 == 0,
+                 RTMODT_E_INVALID, "launch_conv: tile %s cannot fuse cout %d -> tail %d", tile_name(tile), c[0].cout, c[0].tail_cout);
+        RT_CHECK(!c[0].res.base && !c[0].out2.base && c[0].tail_out.H == c[0].out.H && c[0].tail_out.W == c[0].out.W && c[0].tail_out.c == c[0].tail_cout &&
+                     c[0].tail_out.coff % 8 == 0 && c[0].tail_out.C % 8 == 0,
+                 RTMODT_E_INVALID, "launch_conv: tile %s: tail output view", tile_name(tile));
     }
     LaunchPlan l{a, n, general};
     switch (tile) {
@@ -951,6 +1084,10 @@ int launch_conv_group(const ConvLaunch *c, int n, int tile, hipStream_t s) {
         case TILE_ROWS_K64_128x128: launch_rows<128, 128, 2, 2, true>(l, s); break;
         case TILE_ROWS_K64_64x64: launch_rows<64, 64, 2, 2, true>(l, s); break;
         case TILE_ROWS_K64_256x64: launch_rows<256, 64, 4, 1, true>(l, s); break;
+        case TILE_TAIL_128x64: hipLaunchKernelGGL((conv_mfma_tail<128, 64, 2, 2, 3, 4>), l.grid(128, 64), dim3(256), 0, s, a[0]); break;
+        case TILE_TAIL_64x64: hipLaunchKernelGGL((conv_mfma_tail<64, 64, 2, 2, 3, 4>), l.grid(64, 64), dim3(256), 0, s, a[0]); break;
+        case TILE_TAIL_K64_128x128: hipLaunchKernelGGL((conv_mfma64_tail<128, 128, 4, 1, 2, 8>), l.grid(128, 128), dim3(256), 0, s, a[0]); break;
+        case TILE_TAIL_K64_64x128: hipLaunchKernelGGL((conv_mfma64_tail<64, 128, 1, 4, 3, 8>), l.grid(64, 128), dim3(256), 0, s, a[0]); break;
         default: return fail(RTMODT_E_INVALID, "launch_conv: tile %d", tile);
     }
     RT_HIP(hipGetLastError());

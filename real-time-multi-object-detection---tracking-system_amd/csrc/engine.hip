@@ -157,6 +157,10 @@ struct Op {
     int64_t flops = 0;               // per frame
     int B = 1;                       // images this launch covers
     int head_level = -1;             // >= 0: belongs to the Detect branch of that level (independent of the other levels)
+    // conv -> 1x1 pairs (backbone Conv -> C2f.cv1): the producer carries the 1x1 as conv.tail_*; when the tuner finds the
+    // fused launch faster, `tail_on` runs it with `tail_tile` and the 1x1's own op is skipped
+    bool tail_on = false, skip = false;
+    int tail_tile = TILE_TAIL_128x64;
 };
 
 }  // namespace rtmodt
@@ -279,7 +283,7 @@ static Op sub_batch(const Op &op, int b0, int nb) {
         if (v.c) v.base += (size_t)b0 * (v.H + 2 * v.pad) * (v.W + 2 * v.pad) * v.C;
     };
     o.B = nb;
-    if (o.kind == OP_CONV) { shift(o.conv.in); shift(o.conv.out); shift(o.conv.res); shift(o.conv.out2); o.conv.B = nb; }
+    if (o.kind == OP_CONV) { shift(o.conv.in); shift(o.conv.out); shift(o.conv.res); shift(o.conv.out2); shift(o.conv.tail_out); o.conv.B = nb; }
     else if (o.kind == OP_GROUP || o.kind == OP_BNECK) {
         for (auto &c : o.group) { shift(c.in); shift(c.out); shift(c.res); c.B = nb; }
         if (o.kind == OP_BNECK) { shift(o.bneck.in); shift(o.bneck.out); shift(o.bneck.res); o.bneck.B = nb; }
@@ -293,8 +297,8 @@ static int pick_tile(int M, int cout) {
         int t = atoi(e);
         if (t >= 0 && t < TILE_COUNT) return t;
     }
-    static const float eff[TILE_COUNT] = {1.0f, 0.85f, 0.62f, 0.75f, 0.85f, 0.5f, 0.4f, 0.4f, 1.05f, 0.9f, 0.65f, 0.9f, 1.0f, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    static const int occ[TILE_COUNT] = {3, 5, 8, 4, 5, 2, 3, 3, 2, 2, 3, 2, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1};
+    static const float eff[TILE_COUNT] = {1.0f, 0.85f, 0.62f, 0.75f, 0.85f, 0.5f, 0.4f, 0.4f, 1.05f, 0.9f, 0.65f, 0.9f, 1.0f, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    static const int occ[TILE_COUNT] = {3, 5, 8, 4, 5, 2, 3, 3, 2, 2, 3, 2, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1};
     int best = 0;
     double best_cost = 1e30;
     for (int t = 0; t < TILE_COUNT; ++t) {
@@ -485,6 +489,24 @@ static int build_graph(rtmodt_detector *d, WeightFile &wf) {
     int t21 = T(H / 32, W / 32, c5, 1);
     c2f("21", V(cat20), c5, rep(3), false, V(t21));
     RT_TRY(rc);
+    // conv -> C2f.cv1 pairs of the backbone ("1" -> "2.cv1", "3" -> "4.cv1"): the conv's output tensor has no other
+    // reader, so the 1x1 can run as a tail of the conv's launch (conv.hip: epilogue_tail) and the tensor never exists
+    if (!getenv("RTMODT_NO_TAIL"))
+        for (size_t i = 0; i + 1 < d->ops.size(); ++i) {
+            Op &a = d->ops[i], &b = d->ops[i + 1];
+            if (a.kind != OP_CONV || b.kind != OP_CONV || b.conv.ks != 1 || b.conv.stride != 1 || a.conv.res.base || a.conv.out2.base || b.conv.res.base || b.conv.out2.base) continue;
+            if (a.name.find('.') != std::string::npos || b.name != std::to_string(atoi(a.name.c_str()) + 1) + ".cv1") continue;   // plain backbone Conv feeding the next C2f
+            if (b.conv.in.base != a.conv.out.base || b.conv.in.coff != a.conv.out.coff || b.conv.in.c != a.conv.cout) continue;
+            if ((a.conv.cout != 64 && a.conv.cout != 128) || a.conv.cin % 32 != 0 || b.conv.cout > a.conv.cout || b.conv.cout % 8 != 0 || b.conv.kp != a.conv.cout) continue;
+            if (b.conv.out.coff % 8 != 0 || b.conv.out.C % 8 != 0) continue;
+            a.conv.tail_out = b.conv.out; a.conv.tail_wt = b.conv.wt; a.conv.tail_bias = b.conv.bias;
+            a.conv.tail_cout = b.conv.cout; a.conv.tail_kp = b.conv.kp; a.conv.tail_act = b.conv.act;
+            a.tail_tile = a.conv.cout == 64 ? TILE_TAIL_128x64 : (a.conv.cin % 64 == 0 ? TILE_TAIL_K64_128x128 : TILE_TAIL_128x64);
+            if (const char *e = getenv("RTMODT_TAIL")) {     // test hook (no autotune): force the fused launch on
+                a.tail_on = atoi(e) != 0 && tile_shape(a.tail_tile).bn == a.conv.cout && !(tile_needs_cin64(a.tail_tile) && a.conv.cin % 64 != 0);
+                b.skip = a.tail_on;
+            }
+        }
     // Detect head: the two first 3x3 convs of a level share their input -> one conv, cout = cbox + ccls
     const int cbox = std::max(16, std::max(c3 / 4, 64)), ccls = std::max(c3, std::min(d->nc, 100));
     const int nc4 = (int)align_up(d->nc, 4), no = 64 + (int)align_up(d->nc, 8);
@@ -550,6 +572,7 @@ static int build_graph(rtmodt_detector *d, WeightFile &wf) {
             rebase(op.conv.in); rebase(op.conv.out);
             if (op.conv.res.c) rebase(op.conv.res);
             if (op.conv.out2.c) rebase(op.conv.out2);
+            if (op.conv.tail_out.c) rebase(op.conv.tail_out);
         } else if (op.kind == OP_GROUP || op.kind == OP_BNECK) {
             for (auto &c : op.group) { rebase(c.in); rebase(c.out); if (c.res.c) rebase(c.res); }
             if (op.kind == OP_BNECK) { rebase(op.bneck.in); rebase(op.bneck.out); if (op.bneck.res.c) rebase(op.bneck.res); }
@@ -575,7 +598,13 @@ static int build_graph(rtmodt_detector *d, WeightFile &wf) {
 static int run_op_on(const Op &op, hipStream_t s) {
     switch (op.kind) {
         case OP_STEM: return launch_stem(op.v[0], op.v[1], op.stem_w, op.stem_b, op.B, op.v[1].c, s);
-        case OP_CONV: return launch_conv(op.conv, s);
+        case OP_CONV: {
+            if (op.skip) return RTMODT_OK;                 // runs as the tail of the previous launch
+            if (!op.tail_on) return launch_conv(op.conv, s);
+            ConvLaunch c = op.conv;
+            c.tile = op.tail_tile;
+            return launch_conv(c, s);
+        }
         case OP_GROUP: return launch_conv_group(op.group.data(), (int)op.group.size(), op.group_tile, s);
         case OP_BNECK:
             if (op.fused) return launch_bottleneck(op.bneck, s);
@@ -661,6 +690,7 @@ static int tune_conv(rtmodt_detector *d, hipEvent_t e0, hipEvent_t e1, const std
     for (int t = 0; t < TILE_COUNT; ++t) {
         if (tile_needs_cin64(t) && !cin64) continue;
         if (tile_is_rows(t) && !rows_ok) continue;
+        if (tile_is_tail(t)) continue;                     // only through tune_tails()
         float ms;
         RT_TRY(time_launch(d, e0, e1, [&]() { return launch_conv_group(c, n, t, d->stream); }, ms));
         if (getenv("RTMODT_TUNE_LOG")) fprintf(stderr, "[tune] %-28s %-16s %8.2f us\n", name.c_str(), tile_name(t), ms * 1e3f);
@@ -706,7 +736,7 @@ static int autotune_ops(rtmodt_detector *d, std::vector<Op> &ops) {
         auto hit = cache.find(key);
         if (hit != cache.end()) {
             const TuneRec &r = hit->second;
-            if (op.kind == OP_CONV) op.conv.tile = r.t0;
+            if (op.kind == OP_CONV) { op.conv.tile = r.t0; if (op.conv.tail_wt) { op.tail_tile = r.t1; op.tail_on = r.fused != 0; } }
             else if (op.kind == OP_GROUP) op.group_tile = r.t0;
             else { op.group[0].tile = r.t0; op.group[1].tile = r.t1; op.fused = r.fused != 0; }
             continue;
@@ -732,6 +762,35 @@ static int autotune_ops(rtmodt_detector *d, std::vector<Op> &ops) {
         cache[key] = r;
         dirty = true;
     }
+    // conv -> 1x1 pairs: the fused launch (every legal tail tile) against the two tuned launches
+    for (size_t i = 0; i + 1 < ops.size(); ++i) {
+        Op &op = ops[i], &nx = ops[i + 1];
+        if (op.kind != OP_CONV || !op.conv.tail_wt) continue;
+        const std::string key = tune_key(d, op);
+        auto hit = cache.find(key);
+        const bool cached = hit != cache.end() && hit->second.t1 != 0;      // t1 == 0 (TILE_128x128) is never a tail tile: "not decided yet"
+        if (!cached) {
+            float ms_a, ms_b, best = 1e30f;
+            RT_TRY(time_launch(d, e0, e1, [&]() { return launch_conv(op.conv, d->stream); }, ms_a));
+            RT_TRY(time_launch(d, e0, e1, [&]() { return launch_conv(nx.conv, d->stream); }, ms_b));
+            for (int t = TILE_TAIL_128x64; t <= TILE_TAIL_K64_64x128; ++t) {
+                if (tile_shape(t).bn != op.conv.cout || (tile_needs_cin64(t) && (op.conv.cin % 64 != 0 || op.conv.kp % 64 != 0)) || op.conv.cin % 32 != 0) continue;
+                ConvLaunch c = op.conv;
+                c.tile = t;
+                float ms;
+                RT_TRY(time_launch(d, e0, e1, [&]() { return launch_conv(c, d->stream); }, ms));
+                if (getenv("RTMODT_TUNE_LOG")) fprintf(stderr, "[tune] %-28s %-16s %8.2f us (+ %s)\n", op.name.c_str(), tile_name(t), ms * 1e3f, nx.name.c_str());
+                if (ms < best) { best = ms; op.tail_tile = t; }
+            }
+            op.tail_on = best < ms_a + ms_b;
+            if (getenv("RTMODT_TUNE_LOG")) fprintf(stderr, "[tune] %-28s with tail %8.2f us vs two launches %8.2f us\n", op.name.c_str(), best * 1e3f, (ms_a + ms_b) * 1e3f);
+            TuneRec r; r.t0 = op.conv.tile; r.t1 = op.tail_tile; r.fused = op.tail_on;
+            cache[key] = r;
+            dirty = true;
+        }
+        if (const char *e = getenv("RTMODT_TAIL")) op.tail_on = atoi(e) != 0 && tile_shape(op.tail_tile).bn == op.conv.cout;   // A/B and test hook
+        nx.skip = op.tail_on;
+    }
     hipEventDestroy(e0); hipEventDestroy(e1);
     if (cache_path && dirty) {                            // whole file rewritten through a rename: readers never see half a file
         const std::string tmp = std::string(cache_path) + ".tmp." + std::to_string((long)getpid());
@@ -751,6 +810,7 @@ static int autotune_tiles(rtmodt_detector *d) {
         dst.conv.tile = src.conv.tile;
         dst.group_tile = src.group_tile;
         dst.fused = src.fused;
+        dst.tail_on = src.tail_on; dst.tail_tile = src.tail_tile; dst.skip = src.skip;
         for (size_t g = 0; g < dst.group.size(); ++g) dst.group[g].tile = src.group[g].tile;
     };
     if (d->n_chains > 1) {
@@ -1225,6 +1285,9 @@ int rtmodt_detector_debug_layer(rtmodt_detector *d, const char *name, int img, u
     auto it = d->layer_out.find(name);
     RT_CHECK(it != d->layer_out.end(), RTMODT_E_INVALID, "no fused conv named %s", name);
     const TensorView &v = it->second;
+    for (auto &op : d->ops)                               // a conv whose 1x1 tail runs in the same launch stores only the tail's output
+        if (op.kind == OP_CONV && op.tail_on && op.name == name)
+            return fail(RTMODT_E_UNSUPPORTED, "%s is consumed in LDS by the 1x1 conv fused into its launch", name);
     for (auto &op : d->ops)                               // the first conv of a fused Bottleneck never leaves the CU
         if (op.kind == OP_BNECK && op.fused && op.name == std::string(name).substr(0, std::string(name).rfind('.')) + " (cv1+cv2)" &&
             std::string(name).size() > 4 && std::string(name).compare(std::string(name).size() - 4, 4, ".cv1") == 0)
@@ -1266,9 +1329,11 @@ int rtmodt_detector_profile(rtmodt_detector *d, int iters, int max_entries, cons
     d->prof_names.clear();
     for (auto &op : d->ops) {
         char buf[160];
-        if (op.kind == OP_CONV) {
+        if (op.kind == OP_CONV && op.skip) {
+            snprintf(buf, sizeof(buf), "%s [runs as the tail of the previous launch]", op.name.c_str());
+        } else if (op.kind == OP_CONV) {
             snprintf(buf, sizeof(buf), "%s [M=%d N=%d K=%d k%d s%d tile %s]", op.name.c_str(), d->B * op.conv.out.H * op.conv.out.W,
-                     op.conv.cout, op.conv.ks * op.conv.ks * op.conv.cin, op.conv.ks, op.conv.stride, tile_name(op.conv.tile));
+                     op.conv.cout, op.conv.ks * op.conv.ks * op.conv.cin, op.conv.ks, op.conv.stride, tile_name(op.tail_on ? op.tail_tile : op.conv.tile));
         } else if (op.kind == OP_BNECK) {
             if (op.fused) snprintf(buf, sizeof(buf), "%s [fused bottleneck, c=%d, %dx%d]", op.name.c_str(), op.bneck.c, op.bneck.in.H, op.bneck.in.W);
             else snprintf(buf, sizeof(buf), "%s [two launches: %s, %s]", op.name.c_str(), tile_name(op.group[0].tile), tile_name(op.group[1].tile));

@@ -29,11 +29,13 @@ enum ConvTile {
     TILE_K64_64x64_S3 = 17, TILE_K64_64x64_S4 = 18, TILE_K64_256x64_S2 = 19, TILE_K64_256x128_S2 = 20, TILE_K64_128x128_S2W = 21,
     TILE_ROWS_128x64 = 22, TILE_ROWS_256x32 = 23, TILE_ROWS_128x32 = 24,                    // 3x3/s1 tap-reuse kernel, 32-deep chunks
     TILE_ROWS_K64_128x64 = 25, TILE_ROWS_K64_128x128 = 26, TILE_ROWS_K64_64x64 = 27, TILE_ROWS_K64_256x64 = 28,   // ... 64-deep
-    TILE_COUNT = 29
+    TILE_TAIL_128x64 = 29, TILE_TAIL_64x64 = 30, TILE_TAIL_K64_128x128 = 31, TILE_TAIL_K64_64x128 = 32,   // conv + fused 1x1 tail (BN == cout)
+    TILE_COUNT = 33
 };
 const char *tile_name(int tile);
 bool tile_needs_cin64(int tile);
 bool tile_is_rows(int tile);      // 3x3 stride-1 only, bordered input
+bool tile_is_tail(int tile);      // runs ConvLaunch::tail_* as well; needs cout == the tile's BN
 struct TileShape { int bm, bn; };
 TileShape tile_shape(int tile);
 
@@ -46,6 +48,8 @@ struct ConvLaunch {
     int cin = 0, cout = 0, ks = 1, stride = 1, act = 1;
     int kp = 0;                   // weight row stride (K rounded up to 32)
     int tile = TILE_128x128;
+    // optional fused tail: a 1x1 stride-1 conv over this conv's output, which is then never stored (TILE_TAIL_* only)
+    TensorView tail_out; const f16 *tail_wt = nullptr; const float *tail_bias = nullptr; int tail_cout = 0, tail_kp = 0, tail_act = 1;
     int epilogue = 1;             // 0: 8-byte stores from the accumulator layout; 1: 16-byte stores through LDS in the tile kernels; 2: also in the tap-reuse kernel
 };
 

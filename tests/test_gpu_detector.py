@@ -99,7 +99,7 @@ def fetch_layers(pkg, det, names, img=0):
         try:
             out[n] = det.debug_layer(n, img).astype(np.float32)
         except pkg._ffi.RtmodtError as e:
-            assert e.code == pkg._ffi.E_UNSUPPORTED and n.endswith(".cv1"), (n, str(e))
+            assert e.code == pkg._ffi.E_UNSUPPORTED and (n.endswith(".cv1") or "fused into its launch" in str(e)), (n, str(e))
     return out
 
 
@@ -559,3 +559,38 @@ def test_epilogue_variants_store_identical_values(pkg, wdir, monkeypatch):
         for i in range(2):
             for n in outs["0"][i]:
                 assert np.array_equal(outs["0"][i][n].view(np.uint16), outs[mode][i][n].view(np.uint16)), (mode, i, n)
+
+
+@pytest.mark.parametrize("size,batch", [(320, 2), (288, 1), (640, 1)])
+def test_conv_with_fused_1x1_tail(pkg, wdir, monkeypatch, size, batch):
+    """Backbone Conv -> C2f.cv1 pairs ("1" -> "2.cv1", "3" -> "4.cv1" of YOLOv8s) as ONE launch: the conv's output tile
+    stays in LDS, the 1x1 runs on it there, only the 1x1's output is stored.  Forced on / off with the tuner out of
+    the way (every conv on the 64x64 tile, so the k order is the same everywhere): every stored layer must be bit-identical
+    between the two and within tolerance of the oracle; the fused-away tensors are reported as such."""
+    monkeypatch.setenv("RTMODT_BNECK", "0")
+    monkeypatch.setenv("RTMODT_TILE", "2")
+    frames = list(pkg.synth.frames(batch, size, size, seed=71))
+    names = [c.name for c in pkg.weights.spec("s")]
+    outs = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("RTMODT_TAIL", mode)
+        det, w = make_detector(pkg, wdir, "s", size, autotune=False, batch=batch)
+        det.detect_batch(frames)
+        prof = [n for n, _, _ in det.profile(1)]
+        assert (sum("tail:" in n for n in prof) == 2) == (mode == "1"), prof[:8]
+        outs[mode] = []
+        for img in range(batch):
+            inp, _, _ = det.debug_fetch(img, want_heads=False, want_pred=False)
+            gpu = fetch_layers(pkg, det, names, img)
+            outs[mode].append(gpu)
+            if mode == "1":
+                assert "1" not in gpu and "3" not in gpu and "2.cv1" in gpu and "4.cv1" in gpu
+                taps = {}
+                Y.forward(inp.astype(np.float32), w, "s", taps=taps, force=gpu)
+                for n in gpu:
+                    tol = 2e-3 * np.abs(taps[n]).max() + 2e-3
+                    assert float(np.abs(taps[n] - gpu[n]).max()) <= tol, (img, n)
+        det.close()
+    for img in range(batch):                                         # every conv on the 64x64 tile: same k order everywhere
+        for n in outs["1"][img]:
+            assert np.array_equal(outs["0"][img][n], outs["1"][img][n]), (img, n)
