@@ -194,6 +194,10 @@ struct rtmodt_detector {
     int img_t = -1;
     f16 *d_zeros = nullptr;                           // 256 zero bytes (DMA source for out-of-tensor halo pixels)
     int head_t[3] = {-1, -1, -1};
+    // Detect's last 1x1 convs + decode as ONE launch (postprocess.hip: head_final); `stage2_op` = index of the grouped
+    // launch it replaces (kept for the debug paths that want the head tensors themselves)
+    bool head_final = false; int stage2_op = -1;
+    HeadFinalArgs hf{};
     int64_t flops_per_frame = 0;
     // frames
     // host frames land in a per-ring-slot staging area through their own copy stream: the H2D of batch
@@ -581,6 +585,27 @@ static int build_graph(rtmodt_detector *d, WeightFile &wf) {
         }
     }
     for (auto &kv : d->layer_out) rebase(kv.second);
+    for (size_t i = 0; i < d->ops.size(); ++i)
+        if (d->ops[i].kind == OP_GROUP && d->ops[i].name.rfind("22.stage2", 0) == 0) d->stage2_op = (int)i;
+    if (d->stage2_op >= 0 && !getenv("RTMODT_NO_HEAD_FINAL")) {
+        const Op &g = d->ops[d->stage2_op];                // members: cv2.l.2, cv3.l.2 for l = 0, 1, 2
+        const int cbox_in = g.group[0].cin, ccls_in = g.group[1].cin;
+        bool ok = g.group.size() == 6 && head_final_supported(cbox_in, ccls_in, d->nc) && g.group[0].cout == 64;
+        const int strides[3] = {8, 16, 32};
+        for (int l = 0; ok && l < 3; ++l) {
+            const ConvLaunch &cb = g.group[2 * l], &cc = g.group[2 * l + 1];
+            ok = cb.in.pad == 0 && cc.in.pad == 0 && cb.in.coff == 0 && cc.in.coff == 0 && cb.in.C == cbox_in && cc.in.C == ccls_in && cb.kp == cbox_in &&
+                 cc.kp == ccls_in && cb.act == 0 && cc.act == 0;
+            const Tensor &t = d->tensors[d->head_t[l]];
+            d->hf.lvl[l] = HeadFinalLevel{cb.in.base, cc.in.base, cb.wt, cc.wt, cb.bias, cc.bias, nullptr, t.H, t.W, strides[l], cdiv(t.H * t.W, 64)};
+        }
+        if (ok) {
+            d->hf.B = d->B; d->hf.nc = d->nc; d->hf.n_anchors = d->n_anchors; d->hf.cbox = cbox_in; d->hf.ccls = ccls_in;
+            d->hf.no = d->tensors[d->head_t[0]].C;
+            d->head_final = true;
+            d->ops[d->stage2_op].skip = true;
+        }
+    }
 
     // sub-batch chains (parallel graph branches)
     int chains = d->cfg.chains > 0 ? d->cfg.chains : 1;   // measured on MI355X: chains > 1 run slower (kernels of separate streams do not overlap here)
@@ -605,7 +630,7 @@ static int run_op_on(const Op &op, hipStream_t s) {
             c.tile = op.tail_tile;
             return launch_conv(c, s);
         }
-        case OP_GROUP: return launch_conv_group(op.group.data(), (int)op.group.size(), op.group_tile, s);
+        case OP_GROUP: return op.skip ? RTMODT_OK : launch_conv_group(op.group.data(), (int)op.group.size(), op.group_tile, s);
         case OP_BNECK:
             if (op.fused) return launch_bottleneck(op.bneck, s);
             RT_TRY(launch_conv(op.group[0], s));
@@ -618,6 +643,13 @@ static int run_op_on(const Op &op, hipStream_t s) {
 static int run_op(rtmodt_detector *d, const Op &op) { return run_op_on(op, d->stream); }
 
 static int run_decode(rtmodt_detector *d) {
+    if (d->head_final && !d->want_pred) {                  // the two last convs of Detect and the decode in one launch
+        HeadFinalArgs h = d->hf;
+        h.conf = d->cfg.conf; h.class_mask[0] = d->class_mask[0]; h.class_mask[1] = d->class_mask[1];
+        const rtmodt_detector::Dense &dn = d->dense[d->cur_dense];
+        h.box = dn.box; h.score = dn.score; h.cls = dn.cls;
+        return launch_head_final(h, d->stream);
+    }
     DecodeArgs a{};
     const int strides[3] = {8, 16, 32};
     for (int l = 0; l < 3; ++l) {
@@ -1243,6 +1275,19 @@ static int fetch_view(rtmodt_detector *d, const TensorView &v, int img, uint16_t
     return RTMODT_OK;
 }
 
+// head_final keeps the head rows in LDS: have it write them out this once -- the very rows it decodes, so a `pred`
+// derived from them is what the detections came from
+static int materialize_heads(rtmodt_detector *d) {
+    HeadFinalArgs h = d->hf;
+    h.conf = d->cfg.conf; h.class_mask[0] = d->class_mask[0]; h.class_mask[1] = d->class_mask[1];
+    const rtmodt_detector::Dense &dn = d->dense[d->cur_dense];
+    h.box = dn.box; h.score = dn.score; h.cls = dn.cls;
+    for (int l = 0; l < 3; ++l) h.lvl[l].heads = d->tensors[d->head_t[l]].ptr;
+    RT_TRY(launch_head_final(h, d->stream));
+    RT_HIP(hipStreamSynchronize(d->stream));
+    return RTMODT_OK;
+}
+
 int rtmodt_detector_debug_fetch(rtmodt_detector *d, int img, uint16_t *input_f16, uint16_t *heads_f16, float *pred) {
     RT_CHECK(d && img >= 0 && img < d->B, RTMODT_E_INVALID, "bad argument");
     RT_HIP(hipSetDevice(d->device));
@@ -1258,6 +1303,7 @@ int rtmodt_detector_debug_fetch(rtmodt_detector *d, int img, uint16_t *input_f16
         v.base = t.ptr; v.H = t.H; v.W = t.W; v.C = 4; v.pad = 1; v.coff = 0; v.c = 3;
         RT_TRY(fetch_view(d, v, img, input_f16));
     }
+    if (d->head_final && (heads_f16 || pred)) RT_TRY(materialize_heads(d));
     if (heads_f16) {
         uint16_t *o = heads_f16;
         for (int l = 0; l < 3; ++l) {
@@ -1285,6 +1331,12 @@ int rtmodt_detector_debug_layer(rtmodt_detector *d, const char *name, int img, u
     auto it = d->layer_out.find(name);
     RT_CHECK(it != d->layer_out.end(), RTMODT_E_INVALID, "no fused conv named %s", name);
     const TensorView &v = it->second;
+    if (d->head_final && strncmp(name, "22.cv", 5) == 0 && strlen(name) > 2 && strcmp(name + strlen(name) - 2, ".2") == 0) {
+        RT_HIP(hipSetDevice(d->device));
+        RT_HIP(hipDeviceSynchronize());
+        if (d->newest >= 0) d->cur_dense = d->newest;
+        RT_TRY(materialize_heads(d));                      // Detect's last convs live inside head_final
+    }
     for (auto &op : d->ops)                               // a conv whose 1x1 tail runs in the same launch stores only the tail's output
         if (op.kind == OP_CONV && op.tail_on && op.name == name)
             return fail(RTMODT_E_UNSUPPORTED, "%s is consumed in LDS by the 1x1 conv fused into its launch", name);
@@ -1337,6 +1389,8 @@ int rtmodt_detector_profile(rtmodt_detector *d, int iters, int max_entries, cons
         } else if (op.kind == OP_BNECK) {
             if (op.fused) snprintf(buf, sizeof(buf), "%s [fused bottleneck, c=%d, %dx%d]", op.name.c_str(), op.bneck.c, op.bneck.in.H, op.bneck.in.W);
             else snprintf(buf, sizeof(buf), "%s [two launches: %s, %s]", op.name.c_str(), tile_name(op.group[0].tile), tile_name(op.group[1].tile));
+        } else if (op.kind == OP_GROUP && op.skip) {
+            snprintf(buf, sizeof(buf), "%s [runs inside head_final]", op.name.c_str());
         } else if (op.kind == OP_GROUP) {
             snprintf(buf, sizeof(buf), "%s [group of %zu, tile %s]", op.name.c_str(), op.group.size(), tile_name(op.group_tile));
         } else if (op.kind == OP_STEM && d->last_fused) {
@@ -1346,7 +1400,7 @@ int rtmodt_detector_profile(rtmodt_detector *d, int iters, int max_entries, cons
         }
         d->prof_names.push_back(buf);
     }
-    d->prof_names.push_back("decode");
+    d->prof_names.push_back(d->head_final ? "22.stage2 + decode [head_final: one launch]" : "decode");
     *n_entries = n;
     for (int i = 0; i < n && i < max_entries; ++i) {
         if (names) names[i] = d->prof_names[i].c_str();

@@ -116,6 +116,25 @@ struct DecodeArgs {
 };
 int launch_decode(const DecodeArgs &a, hipStream_t s);
 
+// Detect's last 1x1 convs (cv2.l.2: cbox -> 64 DFL logits, cv3.l.2: ccls -> nc class logits, no activation) and the
+// decode above in ONE launch: the (64 + nc)-logit rows of 64 anchors are produced in LDS (fp16, as the head tensor
+// would hold them) and decoded there; the head tensor is written only when `heads` is given (debug).
+struct HeadFinalLevel {
+    const f16 *xb, *xc;            // [B][H*W][cbox], [B][H*W][ccls]: inputs of the two convs (no border)
+    const f16 *wb, *wc;            // weights [64 -> 128 rows][cbox], [nc -> 128 rows][ccls]
+    const float *bb, *bc;          // biases (128 entries)
+    f16 *heads;                    // optional [B][H*W][no]
+    int H, W, stride, tiles;       // tiles = ceil(H*W / 64) per image
+};
+struct HeadFinalArgs {
+    HeadFinalLevel lvl[3];
+    int B, nc, n_anchors, cbox, ccls, no;
+    float conf; uint64_t class_mask[2];
+    float4 *box; float *score; int32_t *cls;
+};
+bool head_final_supported(int cbox, int ccls, int nc);
+int launch_head_final(const HeadFinalArgs &a, hipStream_t s);
+
 struct NmsArgs {
     int B, n_anchors, max_det, agnostic;
     float iou;

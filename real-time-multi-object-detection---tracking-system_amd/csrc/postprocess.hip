@@ -39,23 +39,11 @@ constexpr float MAX_WH = 7680.0f;           // ultralytics max_wh (per-class coo
 // quad combines through two wave shuffles (best class: larger score, then LOWER class id =
 // first maximum).
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void decode_kernel(DecodeArgs a) {
-    const long gid = ((long)blockIdx.x * 256 + threadIdx.x) >> 2;
-    const int j = threadIdx.x & 3;
-    const long total = (long)a.B * a.n_anchors;
-    const bool live = gid < total;
-    const long g = live ? gid : total - 1;                  // dead quads shadow the last anchor (shuffles stay convergent)
-    int b = (int)(g / a.n_anchors), an = (int)(g - (long)b * a.n_anchors);
-    int l = 0, local = an;
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        int cnt = a.lvl[k].H * a.lvl[k].W;
-        if (l == k && local >= cnt) { local -= cnt; l = k + 1; }
-    }
-    const HeadLevel L = l == 0 ? a.lvl[0] : (l == 1 ? a.lvl[1] : a.lvl[2]);
-    const f16 *p = L.ptr + ((long)b * L.H * L.W + local) * a.no;
-    int gy = local / L.W, gx = local - gy * L.W;
-
+// One anchor's logits (row `p`: 64 box halves, then nc class halves) -> box, best class and score, by the quad of lanes
+// j = 0..3 that owns it (lane j: box side j and a quarter of the classes).  `pr`: optional pred dump of this anchor.
+struct DecodeCommon { int nc; float conf; uint64_t class_mask[2]; };
+__device__ __forceinline__ void decode_row(const f16 *p, const int j, const int gx, const int gy, const float st, const DecodeCommon &a, float *pr,
+                                           const long pr_stride, float4 &box_out, float &score_out, int &cls_out) {
     // ---- this lane's box side ----
     float v[16];
     {
@@ -78,7 +66,6 @@ __global__ __launch_bounds__(256) void decode_kernel(DecodeArgs a) {
     float dl = __shfl(dist, qbase + 0), dt = __shfl(dist, qbase + 1), dr = __shfl(dist, qbase + 2), db = __shfl(dist, qbase + 3);
     float ax = (float)gx + 0.5f, ay = (float)gy + 0.5f;
     float x1 = ax - dl, y1 = ay - dt, x2 = ax + dr, y2 = ay + db;
-    float st = (float)L.stride;
     float cx = ((x1 + x2) / 2.0f) * st, cy = ((y1 + y2) / 2.0f) * st;
     float bw = (x2 - x1) * st, bh = (y2 - y1) * st;
 
@@ -87,13 +74,12 @@ __global__ __launch_bounds__(256) void decode_kernel(DecodeArgs a) {
     const int c0 = j * per, c1 = min(c0 + per, a.nc);
     float best = -1.0f;
     int bj = c0;
-    float *pr = (a.pred && live) ? a.pred + (long)b * (4 + a.nc) * a.n_anchors + an : nullptr;
     // Fast path: the sigmoid is strictly increasing on the fp16 grid as long as it is far from saturating in
     // float32 (x < 8: neighbouring halves are >= 2^-8 apart and sigmoid' > 3e-4, far above an ulp), so the first
     // arg-max of the logits IS the first arg-max of the scores and one sigmoid per anchor replaces nc of them.
     // Anything else (a logit >= 8, the pred dump, a class count that does not split into half4s) takes the
     // score-by-score loop below; the quad decides together (xm is quad-uniform).
-    bool slow = a.pred != nullptr || (per & 3) != 0 || c1 - c0 != per;
+    bool slow = pr != nullptr || (per & 3) != 0 || c1 - c0 != per;
     if (!slow) {
         typedef _Float16 half4 __attribute__((ext_vector_type(4)));
         float xb = -INFINITY;
@@ -121,7 +107,7 @@ __global__ __launch_bounds__(256) void decode_kernel(DecodeArgs a) {
             float x = (float)p[64 + c];
             float sg = 1.0f / (1.0f + expf(-x));
             if (sg > best) { best = sg; bj = c; }              // first maximum inside the quarter
-            if (pr) pr[(long)(4 + c) * a.n_anchors] = sg;
+            if (pr) pr[(long)(4 + c) * pr_stride] = sg;
         }
 #pragma unroll
         for (int d = 1; d <= 2; d <<= 1) {
@@ -130,16 +116,39 @@ __global__ __launch_bounds__(256) void decode_kernel(DecodeArgs a) {
             if (ob > best || (ob == best && oj < bj)) { best = ob; bj = oj; }
         }
     }
-    if (!live || j != 0) return;
-    if (pr) {
-        pr[0] = cx; pr[(long)a.n_anchors] = cy; pr[2L * a.n_anchors] = bw; pr[3L * a.n_anchors] = bh;
+    if (pr && j == 0) { pr[0] = cx; pr[pr_stride] = cy; pr[2 * pr_stride] = bw; pr[3 * pr_stride] = bh; }
+    const bool allowed = (a.class_mask[bj >> 6] >> (bj & 63)) & 1ull;
+    const bool cand = best > a.conf && allowed;
+    const float hw = bw / 2.0f, hh = bh / 2.0f;          // xywh2xyxy
+    box_out = make_float4(cx - hw, cy - hh, cx + hw, cy + hh);
+    score_out = cand ? best : -1.0f;
+    cls_out = bj;
+}
+
+__global__ __launch_bounds__(256) void decode_kernel(DecodeArgs a) {
+    const long gid = ((long)blockIdx.x * 256 + threadIdx.x) >> 2;
+    const int j = threadIdx.x & 3;
+    const long total = (long)a.B * a.n_anchors;
+    const bool live = gid < total;
+    const long g = live ? gid : total - 1;                  // dead quads shadow the last anchor (shuffles stay convergent)
+    int b = (int)(g / a.n_anchors), an = (int)(g - (long)b * a.n_anchors);
+    int l = 0, local = an;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        int cnt = a.lvl[k].H * a.lvl[k].W;
+        if (l == k && local >= cnt) { local -= cnt; l = k + 1; }
     }
-    bool allowed = (a.class_mask[bj >> 6] >> (bj & 63)) & 1ull;
-    bool cand = best > a.conf && allowed;
-    float hw = bw / 2.0f, hh = bh / 2.0f;                // xywh2xyxy
-    a.box[gid] = make_float4(cx - hw, cy - hh, cx + hw, cy + hh);
-    a.score[gid] = cand ? best : -1.0f;
-    a.cls[gid] = bj;
+    const HeadLevel L = l == 0 ? a.lvl[0] : (l == 1 ? a.lvl[1] : a.lvl[2]);
+    const f16 *p = L.ptr + ((long)b * L.H * L.W + local) * a.no;
+    int gy = local / L.W, gx = local - gy * L.W;
+    float *pr = (a.pred && live) ? a.pred + (long)b * (4 + a.nc) * a.n_anchors + an : nullptr;
+    const DecodeCommon dc{a.nc, a.conf, {a.class_mask[0], a.class_mask[1]}};
+    float4 box; float score; int cls;
+    decode_row(p, j, gx, gy, (float)L.stride, dc, pr, (long)a.n_anchors, box, score, cls);
+    if (!live || j != 0) return;
+    a.box[gid] = box;
+    a.score[gid] = score;
+    a.cls[gid] = cls;
 }
 
 int launch_decode(const DecodeArgs &a, hipStream_t s) {
@@ -150,6 +159,142 @@ int launch_decode(const DecodeArgs &a, hipStream_t s) {
     RT_HIP(hipGetLastError());
     return RTMODT_OK;
 }
+
+// ---------------------------------------------------------------------------------------
+// head_final: cv2.l.2 + cv3.l.2 (1x1, no activation) + decode.  One 256-thread workgroup per 64 anchors of one
+// level of one image: the two input tiles and both weight matrices arrive by LDS-DMA (16-row x 64-byte pieces,
+// XOR-swizzled on the source address like conv.hip), each wave multiplies one 16-anchor tile on the matrix
+// cores, the logits are rounded to fp16 into an LDS row per anchor -- exactly what the head tensor would hold --
+// and decode_row runs on them, four lanes per anchor.
+// ---------------------------------------------------------------------------------------
+typedef _Float16 hf_half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 hf_half4 __attribute__((ext_vector_type(4)));
+typedef float hf_floatx4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ int hf_swz(int row) { return ((row >> 3) & 1) * 3; }
+__device__ __forceinline__ void hf_dma16(const f16 *src, unsigned char *dst) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src, (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+}
+
+template <int KCC, int NTC>      // ccls / 32, ceil(nc / 16)
+__global__ __launch_bounds__(256) void head_final_kernel(HeadFinalArgs a) {
+    constexpr int KCB = 2, NTB = 4;                       // cbox = 64: two 32-deep chunks; 64 box logits: four 16-wide tiles
+    constexpr int XB = 0, XC = XB + KCB * 4 * 1024, WB = XC + KCC * 4 * 1024, WC = WB + KCB * NTB * 1024, OUT = WC + KCC * NTC * 1024;
+    constexpr int ROWO = (64 + NTC * 16) * 2 + 16;
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[OUT + 64 * ROWO];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r = lane & 15, q = lane >> 4;
+    const int ld_row = lane >> 2, ld_chunk = (lane & 3) ^ hf_swz(ld_row), rd_off = r * 64 + ((q ^ hf_swz(r)) << 4);
+
+    // ---- which level / image / tile ----
+    int rest = blockIdx.x, l = 0, base_anchor = 0;
+    for (; l < 2; ++l) {
+        const int n = a.lvl[l].tiles * a.B;
+        if (rest < n) break;
+        rest -= n;
+        base_anchor += a.lvl[l].H * a.lvl[l].W;
+    }
+    const HeadFinalLevel L = l == 0 ? a.lvl[0] : (l == 1 ? a.lvl[1] : a.lvl[2]);
+    const int b = rest / L.tiles, tile = rest - b * L.tiles;
+    const int HW = L.H * L.W, a0 = tile * 64;
+
+    // ---- operands -> LDS ----
+    {
+        const int an = min(a0 + wave * 16 + ld_row, HW - 1);                  // tail tiles re-read the last anchor (never stored)
+        const f16 *xb = L.xb + ((long)b * HW + an) * a.cbox + ld_chunk * 8;
+        const f16 *xc = L.xc + ((long)b * HW + an) * a.ccls + ld_chunk * 8;
+#pragma unroll
+        for (int kc = 0; kc < KCB; ++kc) hf_dma16(xb + kc * 32, lds + XB + (kc * 4 + wave) * 1024);
+#pragma unroll
+        for (int kc = 0; kc < KCC; ++kc) hf_dma16(xc + kc * 32, lds + XC + (kc * 4 + wave) * 1024);
+        for (int pi = wave; pi < KCB * NTB; pi += 4) {
+            const int kc = pi / NTB, u = pi - kc * NTB;
+            hf_dma16(L.wb + ((u * 16 + ld_row) * a.cbox + kc * 32 + ld_chunk * 8), lds + WB + pi * 1024);
+        }
+        for (int pi = wave; pi < KCC * NTC; pi += 4) {
+            const int kc = pi / NTC, u = pi - kc * NTC;
+            hf_dma16(L.wc + ((u * 16 + ld_row) * a.ccls + kc * 32 + ld_chunk * 8), lds + WC + pi * 1024);
+        }
+    }
+    hf_floatx4 bb[NTB], bc[NTC];
+#pragma unroll
+    for (int u = 0; u < NTB; ++u) bb[u] = *(const hf_floatx4 *)(L.bb + u * 16 + q * 4);
+#pragma unroll
+    for (int u = 0; u < NTC; ++u) bc[u] = *(const hf_floatx4 *)(L.bc + u * 16 + q * 4);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    // ---- the two 1x1 convs: wave w owns anchors [16 w, 16 w + 16) ----
+    hf_floatx4 accb[NTB], accc[NTC];
+#pragma unroll
+    for (int u = 0; u < NTB; ++u) accb[u] = hf_floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < NTC; ++u) accc[u] = hf_floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kc = 0; kc < KCB; ++kc) {
+        const hf_half8 fa = *(const hf_half8 *)(lds + XB + (kc * 4 + wave) * 1024 + rd_off);
+#pragma unroll
+        for (int u = 0; u < NTB; ++u)
+            accb[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(*(const hf_half8 *)(lds + WB + (kc * NTB + u) * 1024 + rd_off), fa, accb[u], 0, 0, 0);
+    }
+#pragma unroll
+    for (int kc = 0; kc < KCC; ++kc) {
+        const hf_half8 fa = *(const hf_half8 *)(lds + XC + (kc * 4 + wave) * 1024 + rd_off);
+#pragma unroll
+        for (int u = 0; u < NTC; ++u)
+            accc[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(*(const hf_half8 *)(lds + WC + (kc * NTC + u) * 1024 + rd_off), fa, accc[u], 0, 0, 0);
+    }
+    // bias (no activation), one rounding to fp16: the row the head tensor would hold
+    unsigned char *row = lds + OUT + (wave * 16 + r) * ROWO;
+#pragma unroll
+    for (int u = 0; u < NTB; ++u) {
+        const hf_floatx4 v = accb[u] + bb[u];
+        *(hf_half4 *)(row + (u * 16 + q * 4) * 2) = hf_half4{(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
+    }
+#pragma unroll
+    for (int u = 0; u < NTC; ++u) {
+        const hf_floatx4 v = accc[u] + bc[u];
+        *(hf_half4 *)(row + (64 + u * 16 + q * 4) * 2) = hf_half4{(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
+    }
+    __syncthreads();
+
+    // ---- decode: four lanes per anchor ----
+    const int al = threadIdx.x >> 2, j = threadIdx.x & 3;
+    const int local = min(a0 + al, HW - 1);
+    const bool live = a0 + al < HW;
+    const int gy = local / L.W, gx = local - gy * L.W;
+    const DecodeCommon dc{a.nc, a.conf, {a.class_mask[0], a.class_mask[1]}};
+    float4 box; float score; int cls;
+    decode_row((const f16 *)(lds + OUT + al * ROWO), j, gx, gy, (float)L.stride, dc, nullptr, 0, box, score, cls);
+    if (live && j == 0) {
+        const long gid = (long)b * a.n_anchors + base_anchor + local;
+        a.box[gid] = box;
+        a.score[gid] = score;
+        a.cls[gid] = cls;
+    }
+    if (L.heads && live) {                                 // debug: the head rows themselves
+        f16 *hp = L.heads + ((long)b * HW + local) * a.no;
+        const f16 *sp = (const f16 *)(lds + OUT + al * ROWO);
+        for (int c = j * 8; c < a.no; c += 32) *(hf_half8 *)(hp + c) = *(const hf_half8 *)(sp + c);
+    }
+}
+
+bool head_final_supported(int cbox, int ccls, int nc) { return cbox == 64 && (ccls == 128 || ccls == 192) && nc >= 1 && nc <= 80 && nc % 4 == 0; }
+
+int launch_head_final(const HeadFinalArgs &a, hipStream_t s) {
+    RT_CHECK(head_final_supported(a.cbox, a.ccls, a.nc), RTMODT_E_UNSUPPORTED, "head_final: cbox %d ccls %d nc %d", a.cbox, a.ccls, a.nc);
+    RT_CHECK(a.no % 8 == 0 && a.no >= 64 + a.nc && a.no <= 64 + 80, RTMODT_E_INVALID, "head_final: head row stride %d", a.no);
+    int blocks = 0;
+    for (int l = 0; l < 3; ++l) {
+        RT_CHECK(a.lvl[l].tiles == cdiv(a.lvl[l].H * a.lvl[l].W, 64), RTMODT_E_INVALID, "head_final: tiles of level %d", l);
+        blocks += a.lvl[l].tiles * a.B;
+    }
+    if (a.ccls == 128) hipLaunchKernelGGL((head_final_kernel<4, 5>), dim3(blocks), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((head_final_kernel<6, 5>), dim3(blocks), dim3(256), 0, s, a);
+    RT_HIP(hipGetLastError());
+    return RTMODT_OK;
+}
+
 
 // pred (4+nc, A) float32 -> dense candidates
 __global__ __launch_bounds__(256) void pred_candidates_kernel(const float *__restrict__ pred, int nc, int A, float conf, uint64_t m0,

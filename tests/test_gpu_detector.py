@@ -594,3 +594,32 @@ def test_conv_with_fused_1x1_tail(pkg, wdir, monkeypatch, size, batch):
     for img in range(batch):                                         # every conv on the 64x64 tile: same k order everywhere
         for n in outs["1"][img]:
             assert np.array_equal(outs["0"][img][n], outs["1"][img][n]), (img, n)
+
+
+@pytest.mark.parametrize("scale,size,batch", [("s", 320, 2), ("m", 256, 1), ("s", 288, 3)])
+def test_head_final_equals_separate_launches(pkg, wdir, monkeypatch, scale, size, batch):
+    """Detect's last 1x1 convs + decode as one launch (head_final: logits rounded to fp16 in LDS, decoded there) against
+    the grouped 1x1 launch + decode kernel it replaces, every conv on the 64x64 tile so that the k order is the same:
+    head rows, pred, detections -- all bit-identical; 288 gives anchor counts that are not multiples of the 64-anchor tile."""
+    monkeypatch.setenv("RTMODT_TILE", "2")
+    monkeypatch.setenv("RTMODT_BNECK", "0")
+    frames = list(pkg.synth.frames(batch, size, size, seed=81))
+    res = {}
+    for mode in ("off", "on"):
+        if mode == "off":
+            monkeypatch.setenv("RTMODT_NO_HEAD_FINAL", "1")
+        else:
+            monkeypatch.delenv("RTMODT_NO_HEAD_FINAL")
+        det, _ = make_detector(pkg, wdir, scale, size, autotune=False, batch=batch, confidence=0.05, max_det=300)
+        dets = det.detect_batch(frames)
+        prof = [n for n, _, _ in det.profile(1)]
+        assert ("head_final" in prof[-1]) == (mode == "on"), prof[-2:]
+        res[mode] = (dets, [det.debug_fetch(i, want_input=False) for i in range(batch)])
+        det.close()
+    for i in range(batch):
+        a, b = res["off"][0][i], res["on"][0][i]
+        assert len(a) == len(b) > 0
+        assert np.array_equal(a.xyxy.view(np.int32), b.xyxy.view(np.int32)) and np.array_equal(a.class_id, b.class_id)
+        assert np.array_equal(a.confidence.view(np.int32), b.confidence.view(np.int32))
+        assert np.array_equal(res["off"][1][i][1].view(np.uint16), res["on"][1][i][1].view(np.uint16))       # head rows
+        assert np.array_equal(res["off"][1][i][2].view(np.int32), res["on"][1][i][2].view(np.int32))         # pred
