@@ -184,7 +184,7 @@ __device__ __forceinline__ int input_offset(const ConvArgs &p, int m) {
 // cache lines of the NHWC output (and of the nearest-2x copy).  bias / SiLU / residual are applied on the way in, in
 // fp32, exactly as store_tile does -- the stored values are identical.  `lds` = the (drained) stage buffers.
 // pix(pm, opix, rpix, opix2) -> false for a row of the tile that is not an output pixel.
-template <int BM, int BN, int TM, int TN, typename PixFn>
+template <int BM, int BN, int TM, int TN, int NTHREADS = 256, typename PixFn>
 __device__ __forceinline__ void epilogue_lds(const ConvArgs &p, const int n0, const floatx4 (&acc)[TM][TN], const floatx4 (&bv)[TN],
                                              unsigned char *lds, const int wm, const int wn, PixFn pix) {
     constexpr int ROWB = BN * 2 + 16;                      // +16: the b64 writes of a 16-pixel group land in distinct banks
@@ -209,7 +209,7 @@ __device__ __forceinline__ void epilogue_lds(const ConvArgs &p, const int n0, co
     }
     __syncthreads();
     constexpr int CPR = BN / 8;                            // 16-byte chunks per pixel
-    for (int c = threadIdx.x; c < BM * CPR; c += 256) {
+    for (int c = threadIdx.x; c < BM * CPR; c += NTHREADS) {
         const int pm = c / CPR, k8 = c - pm * CPR, n = n0 + k8 * 8;
         if (n >= p.cout) continue;
         long opix, rpix, opix2;
@@ -459,10 +459,13 @@ __device__ __forceinline__ void conv_mfma_body(const ConvArgs &p, const int bx, 
 // ---------------------------------------------------------------------------------------
 template <int BM, int BN, int WM, int WN, int NSTAGE, int N2T = 0>
 __device__ __forceinline__ void conv_mfma64_body(const ConvArgs &p, const int bx, const int by) {
-    static_assert(WM * WN == 4, "4 waves per workgroup");
+    constexpr int NW = WM * WN;                             // waves per workgroup: the DMA path sustains ~5 B/clk PER WAVE (tools/probes/dma_probe),
+    static_assert(NW == 4 || NW == 8, "4 or 8 waves");      // so the big tiles run 8 waves to issue their operands twice as fast
+    static_assert(N2T == 0 || NW == 4, "the fused tail is written for 4 waves");
     static_assert(BM % 32 == 0 && BN % 32 == 0, "tile shape");
     constexpr int NA = BM / 8, NB = BN / 8, NP = NA + NB;   // pieces per k-step
-    constexpr int LA = NA / 4, LBp = NB / 4;                 // per wave (NA, NB multiples of 4)
+    constexpr int LA = NA / NW, LBp = NB / NW;               // per wave
+    static_assert(NA % NW == 0 && NB % NW == 0, "pieces must split evenly over the waves");
     constexpr int DEPTH = NSTAGE - 1;
     constexpr int STAGE = NP * 1024;
     constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
@@ -487,12 +490,12 @@ __device__ __forceinline__ void conv_mfma64_body(const ConvArgs &p, const int bx
     int a_off[LA], b_off[LBp];
 #pragma unroll
     for (int i = 0; i < LA; ++i) {
-        int row = (wave + 4 * i) * 8 + ld_row8;              // row inside the BM tile
+        int row = (wave + NW * i) * 8 + ld_row8;             // row inside the BM tile
         a_off[i] = input_offset(p, m0 + row) + ((ld_slot ^ ((row >> 1) & 7)) << 3);
     }
 #pragma unroll
     for (int i = 0; i < LBp; ++i) {
-        int row = (wave + 4 * i) * 8 + ld_row8;
+        int row = (wave + NW * i) * 8 + ld_row8;
         b_off[i] = (n0 + row) * p.kp + ((ld_slot ^ ((row >> 1) & 7)) << 3);
     }
 
@@ -508,9 +511,9 @@ __device__ __forceinline__ void conv_mfma64_body(const ConvArgs &p, const int bx
         unsigned char *sbase = lds + stage * STAGE;
         const int tap_off = (kh * p.in_Wp + kw) * p.in_cs + c0;
 #pragma unroll
-        for (int i = 0; i < LA; ++i) glds16(p.in + (a_off[i] + tap_off), sbase + (wave + 4 * i) * 1024);
+        for (int i = 0; i < LA; ++i) glds16(p.in + (a_off[i] + tap_off), sbase + (wave + NW * i) * 1024);
 #pragma unroll
-        for (int i = 0; i < LBp; ++i) glds16(p.wt + (b_off[i] + kt * 64), sbase + (NA + wave + 4 * i) * 1024);
+        for (int i = 0; i < LBp; ++i) glds16(p.wt + (b_off[i] + kt * 64), sbase + (NA + wave + NW * i) * 1024);
         c0 += 64;
         if (c0 >= p.cin) { c0 = 0; if (++kw == p.ks) { kw = 0; ++kh; } }
     };
@@ -552,7 +555,7 @@ __device__ __forceinline__ void conv_mfma64_body(const ConvArgs &p, const int bx
         return;
     }
     if (p.epi16) {
-        epilogue_lds<BM, BN, TM, TN>(p, n0, acc, bv, lds, wm, wn, [&](int pm, long &o, long &rp, long &o2) { return pixel_offsets(p, m0 + pm, o, rp, o2); });
+        epilogue_lds<BM, BN, TM, TN, NW * 64>(p, n0, acc, bv, lds, wm, wn, [&](int pm, long &o, long &rp, long &o2) { return pixel_offsets(p, m0 + pm, o, rp, o2); });
         return;
     }
 #pragma unroll
@@ -841,6 +844,8 @@ __global__ __launch_bounds__(256) void conv_mfma_tail(ConvArgs p) { conv_mfma_bo
 template <int BM, int BN, int WM, int WN, int NSTAGE, int N2T>
 __global__ __launch_bounds__(256) void conv_mfma64_tail(ConvArgs p) { conv_mfma64_body<BM, BN, WM, WN, NSTAGE, N2T>(p, blockIdx.x, blockIdx.y); }
 template <int BM, int BN, int WM, int WN, int NSTAGE>
+__global__ __launch_bounds__(512) void conv_mfma64_w8(ConvArgs p) { conv_mfma64_body<BM, BN, WM, WN, NSTAGE>(p, blockIdx.x, blockIdx.y); }
+template <int BM, int BN, int WM, int WN, int NSTAGE>
 __global__ __launch_bounds__(256) void conv_mfma64(ConvArgs p) { conv_mfma64_body<BM, BN, WM, WN, NSTAGE>(p, blockIdx.x, blockIdx.y); }
 template <int BM, int BN, int WM, int WN, int NSTAGE>
 __global__ __launch_bounds__(256) void conv_mfma64_grp(ConvGroupArgs g) {
@@ -870,13 +875,14 @@ const char *tile_name(int tile) {
                                             "128x128s4", "128x64s5", "64x64s6", "64x128s5", "128x128s6",
                                             "k64:128x128s2", "k64:128x128s3", "k64:128x64s3", "k64:64x128s3", "k64:64x64s3", "k64:64x64s4", "k64:256x64s2", "k64:256x128s2", "k64:128x128s2w",
                                             "rows:128x64", "rows:256x32", "rows:128x32", "rows64:128x64", "rows64:128x128", "rows64:64x64", "rows64:256x64",
-                                            "tail:128x64", "tail:64x64", "tail:k64:128x128", "tail:k64:64x128"};
+                                            "tail:128x64", "tail:64x64", "tail:k64:128x128", "tail:k64:64x128",
+                                            "k64:128x128s2/8w", "k64:128x128s3/8w", "k64:256x128s2/8w", "k64:128x64s3/8w", "k64:256x64s2/8w"};
     return tile >= 0 && tile < TILE_COUNT ? names[tile] : "?";
 }
 
 bool tile_needs_cin64(int tile) {
     return (tile >= TILE_K64_128x128_S2 && tile <= TILE_K64_128x128_S2W) || (tile >= TILE_ROWS_K64_128x64 && tile <= TILE_ROWS_K64_256x64) ||
-           tile == TILE_TAIL_K64_128x128 || tile == TILE_TAIL_K64_64x128;
+           tile == TILE_TAIL_K64_128x128 || tile == TILE_TAIL_K64_64x128 || (tile >= TILE_K64_128x128_S2_W8 && tile <= TILE_K64_256x64_S2_W8);
 }
 bool tile_is_tail(int tile) { return tile >= TILE_TAIL_128x64 && tile <= TILE_TAIL_K64_64x128; }
 bool tile_is_rows(int tile) { return tile >= TILE_ROWS_128x64 && tile <= TILE_ROWS_K64_256x64; }
@@ -912,6 +918,10 @@ TileShape tile_shape(int tile) {
         case TILE_TAIL_64x64: return {64, 64};
         case TILE_TAIL_K64_128x128: return {128, 128};
         case TILE_TAIL_K64_64x128: return {64, 128};
+        case TILE_K64_128x128_S2_W8: case TILE_K64_128x128_S3_W8: return {128, 128};
+        case TILE_K64_256x128_S2_W8: return {256, 128};
+        case TILE_K64_128x64_S3_W8: return {128, 64};
+        case TILE_K64_256x64_S2_W8: return {256, 64};
     }
     return {0, 0};
 }
@@ -946,6 +956,13 @@ static void launch_k64(const LaunchPlan &l, hipStream_t s) {
         for (int i = 0; i < l.n; ++i) g.p[i] = l.a[i];
         hipLaunchKernelGGL((conv_mfma64_grp<BM, BN, WM, WN, NSTAGE>), grid, dim3(256), 0, s, g);
     }
+}
+
+template <int BM, int BN, int WM, int WN, int NSTAGE>
+static int launch_k64_w8(const LaunchPlan &l, hipStream_t s) {
+    RT_CHECK(l.n == 1, RTMODT_E_INVALID, "launch_conv: the 8-wave tiles run single problems");
+    hipLaunchKernelGGL((conv_mfma64_w8<BM, BN, WM, WN, NSTAGE>), l.grid(BM, BN), dim3(512), 0, s, l.a[0]);
+    return RTMODT_OK;
 }
 
 template <int BM, int BN, int WM, int WN, bool K64>
@@ -1084,6 +1101,11 @@ int launch_conv_group(const ConvLaunch *c, int n, int tile, hipStream_t s) {
         case TILE_ROWS_K64_128x128: launch_rows<128, 128, 2, 2, true>(l, s); break;
         case TILE_ROWS_K64_64x64: launch_rows<64, 64, 2, 2, true>(l, s); break;
         case TILE_ROWS_K64_256x64: launch_rows<256, 64, 4, 1, true>(l, s); break;
+        case TILE_K64_128x128_S2_W8: RT_TRY((launch_k64_w8<128, 128, 4, 2, 2>(l, s))); break;
+        case TILE_K64_128x128_S3_W8: RT_TRY((launch_k64_w8<128, 128, 4, 2, 3>(l, s))); break;
+        case TILE_K64_256x128_S2_W8: RT_TRY((launch_k64_w8<256, 128, 4, 2, 2>(l, s))); break;
+        case TILE_K64_128x64_S3_W8: RT_TRY((launch_k64_w8<128, 64, 4, 2, 3>(l, s))); break;
+        case TILE_K64_256x64_S2_W8: RT_TRY((launch_k64_w8<256, 64, 8, 1, 2>(l, s))); break;
         case TILE_TAIL_128x64: hipLaunchKernelGGL((conv_mfma_tail<128, 64, 2, 2, 3, 4>), l.grid(128, 64), dim3(256), 0, s, a[0]); break;
         case TILE_TAIL_64x64: hipLaunchKernelGGL((conv_mfma_tail<64, 64, 2, 2, 3, 4>), l.grid(64, 64), dim3(256), 0, s, a[0]); break;
         case TILE_TAIL_K64_128x128: hipLaunchKernelGGL((conv_mfma64_tail<128, 128, 4, 1, 2, 8>), l.grid(128, 128), dim3(256), 0, s, a[0]); break;

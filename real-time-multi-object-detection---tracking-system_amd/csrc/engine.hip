@@ -301,8 +301,8 @@ static int pick_tile(int M, int cout) {
         int t = atoi(e);
         if (t >= 0 && t < TILE_COUNT) return t;
     }
-    static const float eff[TILE_COUNT] = {1.0f, 0.85f, 0.62f, 0.75f, 0.85f, 0.5f, 0.4f, 0.4f, 1.05f, 0.9f, 0.65f, 0.9f, 1.0f, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    static const int occ[TILE_COUNT] = {3, 5, 8, 4, 5, 2, 3, 3, 2, 2, 3, 2, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1};
+    static const float eff[TILE_COUNT] = {1.0f, 0.85f, 0.62f, 0.75f, 0.85f, 0.5f, 0.4f, 0.4f, 1.05f, 0.9f, 0.65f, 0.9f, 1.0f, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    static const int occ[TILE_COUNT] = {3, 5, 8, 4, 5, 2, 3, 3, 2, 2, 3, 2, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1};
     int best = 0;
     double best_cost = 1e30;
     for (int t = 0; t < TILE_COUNT; ++t) {
@@ -360,6 +360,10 @@ static int make_conv(rtmodt_detector *d, WeightFile &wf, const std::vector<std::
     if (const char *e = getenv("RTMODT_EPI16")) c.epilogue = atoi(e);      // A/B and test hook
     int M = d->B * out.H * out.W;
     c.tile = pick_tile(M, cout_eff);
+    if (const char *e = getenv("RTMODT_TILE_K64")) {            // test hook: a 64-deep tile (incl. the 8-wave ones) wherever it is legal
+        const int t = atoi(e);
+        if (t >= 0 && t < TILE_COUNT && tile_needs_cin64(t) && !tile_is_rows(t) && !tile_is_tail(t) && c.cin % 64 == 0 && kp % 64 == 0 && !dst) c.tile = t;
+    }
     if (const char *e = getenv("RTMODT_TILE_3X3S1")) {          // test hook: force a tap-reuse tile wherever it is legal
         int t = atoi(e);
         if (t >= 0 && t < TILE_COUNT && tile_is_rows(t) && c.ks == 3 && c.stride == 1 && c.in.pad == 1 &&
@@ -723,6 +727,7 @@ static int tune_conv(rtmodt_detector *d, hipEvent_t e0, hipEvent_t e1, const std
         if (tile_needs_cin64(t) && !cin64) continue;
         if (tile_is_rows(t) && !rows_ok) continue;
         if (tile_is_tail(t)) continue;                     // only through tune_tails()
+        if (t >= TILE_K64_128x128_S2_W8 && t <= TILE_K64_256x64_S2_W8 && n != 1) continue;   // the 8-wave tiles have no group entry point
         float ms;
         RT_TRY(time_launch(d, e0, e1, [&]() { return launch_conv_group(c, n, t, d->stream); }, ms));
         if (getenv("RTMODT_TUNE_LOG")) fprintf(stderr, "[tune] %-28s %-16s %8.2f us\n", name.c_str(), tile_name(t), ms * 1e3f);

@@ -30,7 +30,8 @@ enum ConvTile {
     TILE_ROWS_128x64 = 22, TILE_ROWS_256x32 = 23, TILE_ROWS_128x32 = 24,                    // 3x3/s1 tap-reuse kernel, 32-deep chunks
     TILE_ROWS_K64_128x64 = 25, TILE_ROWS_K64_128x128 = 26, TILE_ROWS_K64_64x64 = 27, TILE_ROWS_K64_256x64 = 28,   // ... 64-deep
     TILE_TAIL_128x64 = 29, TILE_TAIL_64x64 = 30, TILE_TAIL_K64_128x128 = 31, TILE_TAIL_K64_64x128 = 32,   // conv + fused 1x1 tail (BN == cout)
-    TILE_COUNT = 33
+    TILE_K64_128x128_S2_W8 = 33, TILE_K64_128x128_S3_W8 = 34, TILE_K64_256x128_S2_W8 = 35, TILE_K64_128x64_S3_W8 = 36, TILE_K64_256x64_S2_W8 = 37,   // 8 waves per workgroup
+    TILE_COUNT = 38
 };
 const char *tile_name(int tile);
 bool tile_needs_cin64(int tile);

@@ -623,3 +623,31 @@ def test_head_final_equals_separate_launches(pkg, wdir, monkeypatch, scale, size
         assert np.array_equal(a.confidence.view(np.int32), b.confidence.view(np.int32))
         assert np.array_equal(res["off"][1][i][1].view(np.uint16), res["on"][1][i][1].view(np.uint16))       # head rows
         assert np.array_equal(res["off"][1][i][2].view(np.int32), res["on"][1][i][2].view(np.int32))         # pred
+
+
+@pytest.mark.parametrize("tile", [33, 34, 35, 36, 37])
+def test_eight_wave_tiles(pkg, wdir, monkeypatch, tile):
+    """The 64-deep tile kernel with EIGHT waves per workgroup (the global->LDS path sustains ~5 B/clk per wave, so the
+    big tiles issue their operands from twice as many waves): forced onto every single-launch conv with cin % 64 == 0,
+    all layers against the oracle, both epilogues."""
+    monkeypatch.setenv("RTMODT_TILE_K64", str(tile))
+    monkeypatch.setenv("RTMODT_BNECK", "0")
+    monkeypatch.setenv("RTMODT_TAIL", "0")
+    for epi in ("1", "0"):
+        monkeypatch.setenv("RTMODT_EPI16", epi)
+        det, w = make_detector(pkg, wdir, "s", 320, autotune=False, batch=2)
+        used = [n for n, _, _ in det.profile(1) if "/8w" in n]
+        assert len(used) >= 15, used
+        frames = list(pkg.synth.frames(2, 320, 320, seed=91))
+        det.detect_batch(frames)
+        names = [c.name for c in pkg.weights.spec("s")]
+        for img in (0, 1):
+            inp, _, _ = det.debug_fetch(img, want_heads=False, want_pred=False)
+            gpu = fetch_layers(pkg, det, names, img)
+            taps = {}
+            Y.forward(inp.astype(np.float32), w, "s", taps=taps, force=gpu)
+            for n in gpu:
+                tol = 2e-3 * np.abs(taps[n]).max() + 2e-3
+                err = float(np.abs(taps[n] - gpu[n]).max())
+                assert err <= tol, f"tile {tile} epi {epi} img {img} layer {n}: max err {err:.4g} > tol {tol:.4g}"
+        det.close()
