@@ -584,7 +584,8 @@ __device__ __forceinline__ void conv_mfma64_body(const ConvArgs &p, const int bx
 // ---------------------------------------------------------------------------------------
 template <int BM, int BN, int WM, int WN, bool K64>
 __device__ __forceinline__ void conv3x3_rows_body(const ConvArgs &p, const int bx, const int by) {
-    static_assert(WM * WN == 4, "4 waves per workgroup");
+    constexpr int NW = WM * WN;                     // 4 or 8 waves per workgroup (8: the DMA pieces of a super-step are issued by twice as many waves)
+    static_assert(NW == 4 || NW == 8, "4 or 8 waves");
     constexpr int RP = K64 ? 8 : 16;               // rows per DMA piece
     constexpr int RB = K64 ? 128 : 64;             // bytes per row in LDS
     constexpr int BK = K64 ? 64 : 32;
@@ -623,19 +624,19 @@ __device__ __forceinline__ void conv3x3_rows_body(const ConvArgs &p, const int b
     for (int kk = 0; kk < (K64 ? 2 : 1); ++kk) b_rd[kk] = lds_off(r, kk * 4 + q);
 
     // per-wave piece lists: strip pieces wave, wave+4, ...; weight pieces likewise over 3*NBT
-    constexpr int LA = (NAS + 3) / 4, LB = (3 * NBT + 3) / 4;
+    constexpr int LA = (NAS + NW - 1) / NW, LB = (3 * NBT + NW - 1) / NW;
     int a_off[LA], b_off[LB];
     const int last_pix = Mp - 1;
 #pragma unroll
     for (int i = 0; i < LA; ++i) {
-        int R = (wave + 4 * i) * RP + ld_row;                  // strip row
+        int R = (wave + NW * i) * RP + ld_row;                 // strip row
         int chunk = K64 ? (ld_slot ^ ((R >> 1) & 7)) : (ld_slot ^ swz16(R));
         // pixel index is clamped per tap row at issue time; keep row and chunk parts separate
         a_off[i] = (m0 + R) | (chunk << 28);
     }
 #pragma unroll
     for (int i = 0; i < LB; ++i) {
-        int pc = wave + 4 * i;                                  // 0 .. 3*NBT-1
+        int pc = wave + NW * i;                                 // 0 .. 3*NBT-1
         int kw = pc / NBT, R = (pc - kw * NBT) * RP + ld_row;   // cout row inside the BN tile
         int chunk = K64 ? (ld_slot ^ ((R >> 1) & 7)) : (ld_slot ^ swz16(R));
         b_off[i] = (n0 + R) * p.kp + kw * p.cin + chunk * 8;
@@ -660,14 +661,14 @@ __device__ __forceinline__ void conv3x3_rows_body(const ConvArgs &p, const int b
         const int row_shift = kh * p.in_Wp;
 #pragma unroll
         for (int i = 0; i < LA; ++i) {
-            if (wave + 4 * i < NAS) {
+            if (wave + NW * i < NAS) {
                 int pix = min((a_off[i] & 0x0FFFFFFF) + row_shift, last_pix);
-                glds16(p.in + ((long)pix * p.in_cs + c0 + (a_off[i] >> 28) * 8), sbase + (wave + 4 * i) * 1024);
+                glds16(p.in + ((long)pix * p.in_cs + c0 + (a_off[i] >> 28) * 8), sbase + (wave + NW * i) * 1024);
             }
         }
 #pragma unroll
         for (int i = 0; i < LB; ++i)
-            if (wave + 4 * i < 3 * NBT) glds16(p.wt + (b_off[i] + kh * 3 * p.cin + c0), sbase + (NAS + wave + 4 * i) * 1024);
+            if (wave + NW * i < 3 * NBT) glds16(p.wt + (b_off[i] + kh * 3 * p.cin + c0), sbase + (NAS + wave + NW * i) * 1024);
         c0 += BK;
         if (c0 >= p.cin) { c0 = 0; ++kh; }
     };
@@ -700,7 +701,7 @@ __device__ __forceinline__ void conv3x3_rows_body(const ConvArgs &p, const int b
     // ---- epilogue: padded position -> (b, y, x); border rows/columns are junk ----
     const int HW = p.in_Hp * p.in_Wp;
     if (p.epi16 > 1) {                                     // measured: the extra LDS round trip costs this MFMA-heavier kernel more than its stores do
-        epilogue_lds<BM, BN, TM, TN>(p, n0, acc, bv, lds, wm, wn, [&](int pm, long &opix, long &rpix, long &opix2) {
+        epilogue_lds<BM, BN, TM, TN, NW * 64>(p, n0, acc, bv, lds, wm, wn, [&](int pm, long &opix, long &rpix, long &opix2) {
             const int m = m0 + pm;
             if (m >= Mp) return false;
             const int b = m / HW, rem = m - b * HW;
@@ -854,6 +855,14 @@ __global__ __launch_bounds__(256) void conv_mfma64_grp(ConvGroupArgs g) {
     conv_mfma64_body<BM, BN, WM, WN, NSTAGE>(p, blockIdx.x, blockIdx.y);
 }
 template <int BM, int BN, int WM, int WN, bool K64>
+__global__ __launch_bounds__(512) void conv3x3_rows_w8(ConvArgs p) { conv3x3_rows_body<BM, BN, WM, WN, K64>(p, blockIdx.x, blockIdx.y); }
+template <int BM, int BN, int WM, int WN, bool K64>
+__global__ __launch_bounds__(512) void conv3x3_rows_w8_grp(ConvGroupArgs g) {
+    const ConvArgs &p = g.p[blockIdx.z];
+    if ((int)blockIdx.x * BM >= p.M || (int)blockIdx.y * BN >= p.cout) return;
+    conv3x3_rows_body<BM, BN, WM, WN, K64>(p, blockIdx.x, blockIdx.y);
+}
+template <int BM, int BN, int WM, int WN, bool K64>
 __global__ __launch_bounds__(256) void conv3x3_rows(ConvArgs p) { conv3x3_rows_body<BM, BN, WM, WN, K64>(p, blockIdx.x, blockIdx.y); }
 template <int BM, int BN, int WM, int WN, bool K64>
 __global__ __launch_bounds__(256) void conv3x3_rows_grp(ConvGroupArgs g) {
@@ -876,16 +885,18 @@ const char *tile_name(int tile) {
                                             "k64:128x128s2", "k64:128x128s3", "k64:128x64s3", "k64:64x128s3", "k64:64x64s3", "k64:64x64s4", "k64:256x64s2", "k64:256x128s2", "k64:128x128s2w",
                                             "rows:128x64", "rows:256x32", "rows:128x32", "rows64:128x64", "rows64:128x128", "rows64:64x64", "rows64:256x64",
                                             "tail:128x64", "tail:64x64", "tail:k64:128x128", "tail:k64:64x128",
-                                            "k64:128x128s2/8w", "k64:128x128s3/8w", "k64:256x128s2/8w", "k64:128x64s3/8w", "k64:256x64s2/8w"};
+                                            "k64:128x128s2/8w", "k64:128x128s3/8w", "k64:256x128s2/8w", "k64:128x64s3/8w", "k64:256x64s2/8w",
+                                            "rows:128x64/8w", "rows:256x64/8w", "rows64:128x128/8w", "rows64:256x64/8w"};
     return tile >= 0 && tile < TILE_COUNT ? names[tile] : "?";
 }
 
 bool tile_needs_cin64(int tile) {
     return (tile >= TILE_K64_128x128_S2 && tile <= TILE_K64_128x128_S2W) || (tile >= TILE_ROWS_K64_128x64 && tile <= TILE_ROWS_K64_256x64) ||
-           tile == TILE_TAIL_K64_128x128 || tile == TILE_TAIL_K64_64x128 || (tile >= TILE_K64_128x128_S2_W8 && tile <= TILE_K64_256x64_S2_W8);
+           tile == TILE_TAIL_K64_128x128 || tile == TILE_TAIL_K64_64x128 || (tile >= TILE_K64_128x128_S2_W8 && tile <= TILE_K64_256x64_S2_W8) ||
+           tile == TILE_ROWS_K64_128x128_W8 || tile == TILE_ROWS_K64_256x64_W8;
 }
 bool tile_is_tail(int tile) { return tile >= TILE_TAIL_128x64 && tile <= TILE_TAIL_K64_64x128; }
-bool tile_is_rows(int tile) { return tile >= TILE_ROWS_128x64 && tile <= TILE_ROWS_K64_256x64; }
+bool tile_is_rows(int tile) { return (tile >= TILE_ROWS_128x64 && tile <= TILE_ROWS_K64_256x64) || (tile >= TILE_ROWS_128x64_W8 && tile <= TILE_ROWS_K64_256x64_W8); }
 
 TileShape tile_shape(int tile) {
     switch (tile) {
@@ -922,6 +933,9 @@ TileShape tile_shape(int tile) {
         case TILE_K64_256x128_S2_W8: return {256, 128};
         case TILE_K64_128x64_S3_W8: return {128, 64};
         case TILE_K64_256x64_S2_W8: return {256, 64};
+        case TILE_ROWS_128x64_W8: return {128, 64};
+        case TILE_ROWS_256x64_W8: case TILE_ROWS_K64_256x64_W8: return {256, 64};
+        case TILE_ROWS_K64_128x128_W8: return {128, 128};
     }
     return {0, 0};
 }
@@ -955,6 +969,18 @@ static void launch_k64(const LaunchPlan &l, hipStream_t s) {
         ConvGroupArgs g;
         for (int i = 0; i < l.n; ++i) g.p[i] = l.a[i];
         hipLaunchKernelGGL((conv_mfma64_grp<BM, BN, WM, WN, NSTAGE>), grid, dim3(256), 0, s, g);
+    }
+}
+
+template <int BM, int BN, int WM, int WN, bool K64>
+static void launch_rows_w8(const LaunchPlan &l, hipStream_t s) {
+    dim3 grid = l.grid(BM, BN);
+    if (l.n == 1) {
+        hipLaunchKernelGGL((conv3x3_rows_w8<BM, BN, WM, WN, K64>), grid, dim3(512), 0, s, l.a[0]);
+    } else {
+        ConvGroupArgs g;
+        for (int i = 0; i < l.n; ++i) g.p[i] = l.a[i];
+        hipLaunchKernelGGL((conv3x3_rows_w8_grp<BM, BN, WM, WN, K64>), grid, dim3(512), 0, s, g);
     }
 }
 
@@ -1101,6 +1127,10 @@ int launch_conv_group(const ConvLaunch *c, int n, int tile, hipStream_t s) {
         case TILE_ROWS_K64_128x128: launch_rows<128, 128, 2, 2, true>(l, s); break;
         case TILE_ROWS_K64_64x64: launch_rows<64, 64, 2, 2, true>(l, s); break;
         case TILE_ROWS_K64_256x64: launch_rows<256, 64, 4, 1, true>(l, s); break;
+        case TILE_ROWS_128x64_W8: launch_rows_w8<128, 64, 4, 2, false>(l, s); break;
+        case TILE_ROWS_256x64_W8: launch_rows_w8<256, 64, 4, 2, false>(l, s); break;
+        case TILE_ROWS_K64_128x128_W8: launch_rows_w8<128, 128, 4, 2, true>(l, s); break;
+        case TILE_ROWS_K64_256x64_W8: launch_rows_w8<256, 64, 4, 2, true>(l, s); break;
         case TILE_K64_128x128_S2_W8: RT_TRY((launch_k64_w8<128, 128, 4, 2, 2>(l, s))); break;
         case TILE_K64_128x128_S3_W8: RT_TRY((launch_k64_w8<128, 128, 4, 2, 3>(l, s))); break;
         case TILE_K64_256x128_S2_W8: RT_TRY((launch_k64_w8<256, 128, 4, 2, 2>(l, s))); break;

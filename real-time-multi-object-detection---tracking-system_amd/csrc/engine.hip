@@ -301,8 +301,8 @@ static int pick_tile(int M, int cout) {
         int t = atoi(e);
         if (t >= 0 && t < TILE_COUNT) return t;
     }
-    static const float eff[TILE_COUNT] = {1.0f, 0.85f, 0.62f, 0.75f, 0.85f, 0.5f, 0.4f, 0.4f, 1.05f, 0.9f, 0.65f, 0.9f, 1.0f, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    static const int occ[TILE_COUNT] = {3, 5, 8, 4, 5, 2, 3, 3, 2, 2, 3, 2, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1};
+    static const float eff[TILE_COUNT] = {1.0f, 0.85f, 0.62f, 0.75f, 0.85f, 0.5f, 0.4f, 0.4f, 1.05f, 0.9f, 0.65f, 0.9f, 1.0f, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    static const int occ[TILE_COUNT] = {3, 5, 8, 4, 5, 2, 3, 3, 2, 2, 3, 2, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1};
     int best = 0;
     double best_cost = 1e30;
     for (int t = 0; t < TILE_COUNT; ++t) {

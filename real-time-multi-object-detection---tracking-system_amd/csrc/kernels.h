@@ -31,7 +31,8 @@ enum ConvTile {
     TILE_ROWS_K64_128x64 = 25, TILE_ROWS_K64_128x128 = 26, TILE_ROWS_K64_64x64 = 27, TILE_ROWS_K64_256x64 = 28,   // ... 64-deep
     TILE_TAIL_128x64 = 29, TILE_TAIL_64x64 = 30, TILE_TAIL_K64_128x128 = 31, TILE_TAIL_K64_64x128 = 32,   // conv + fused 1x1 tail (BN == cout)
     TILE_K64_128x128_S2_W8 = 33, TILE_K64_128x128_S3_W8 = 34, TILE_K64_256x128_S2_W8 = 35, TILE_K64_128x64_S3_W8 = 36, TILE_K64_256x64_S2_W8 = 37,   // 8 waves per workgroup
-    TILE_COUNT = 38
+    TILE_ROWS_128x64_W8 = 38, TILE_ROWS_256x64_W8 = 39, TILE_ROWS_K64_128x128_W8 = 40, TILE_ROWS_K64_256x64_W8 = 41,   // tap-reuse kernel, 8 waves
+    TILE_COUNT = 42
 };
 const char *tile_name(int tile);
 bool tile_needs_cin64(int tile);

@@ -161,7 +161,7 @@ def test_forward_layers_other_scales(pkg, wdir, scale, size):
     det.close()
 
 
-@pytest.mark.parametrize("tile", [22, 23, 24, 25, 26, 27, 28])
+@pytest.mark.parametrize("tile", [22, 23, 24, 25, 26, 27, 28, 38, 39, 40, 41])      # 38..41: the 8-wave variants
 def test_tap_reuse_conv_tiles(pkg, wdir, monkeypatch, tile):
     """conv3x3_rows (the 3x3/s1 tap-reuse kernel) in each of its tile shapes, forced onto every
     layer where it is legal; all layers are then checked one by one against the oracle."""
