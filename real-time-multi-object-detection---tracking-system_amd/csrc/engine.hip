@@ -601,7 +601,7 @@ static int build_graph(rtmodt_detector *d, WeightFile &wf) {
             ok = cb.in.pad == 0 && cc.in.pad == 0 && cb.in.coff == 0 && cc.in.coff == 0 && cb.in.C == cbox_in && cc.in.C == ccls_in && cb.kp == cbox_in &&
                  cc.kp == ccls_in && cb.act == 0 && cc.act == 0;
             const Tensor &t = d->tensors[d->head_t[l]];
-            d->hf.lvl[l] = HeadFinalLevel{cb.in.base, cc.in.base, cb.wt, cc.wt, cb.bias, cc.bias, nullptr, t.H, t.W, strides[l], cdiv(t.H * t.W, 64)};
+            d->hf.lvl[l] = HeadFinalLevel{cb.in.base, cc.in.base, cb.wt, cc.wt, cb.bias, cc.bias, nullptr, t.H, t.W, strides[l], cdiv(t.H * t.W, 128)};
         }
         if (ok) {
             d->hf.B = d->B; d->hf.nc = d->nc; d->hf.n_anchors = d->n_anchors; d->hf.cbox = cbox_in; d->hf.ccls = ccls_in;

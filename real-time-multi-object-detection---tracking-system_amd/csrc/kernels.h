@@ -126,7 +126,7 @@ struct HeadFinalLevel {
     const f16 *wb, *wc;            // weights [64 -> 128 rows][cbox], [nc -> 128 rows][ccls]
     const float *bb, *bc;          // biases (128 entries)
     f16 *heads;                    // optional [B][H*W][no]
-    int H, W, stride, tiles;       // tiles = ceil(H*W / 64) per image
+    int H, W, stride, tiles;       // tiles = ceil(H*W / 128) per image
 };
 struct HeadFinalArgs {
     HeadFinalLevel lvl[3];

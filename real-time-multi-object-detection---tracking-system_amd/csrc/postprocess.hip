@@ -161,7 +161,7 @@ int launch_decode(const DecodeArgs &a, hipStream_t s) {
 }
 
 // ---------------------------------------------------------------------------------------
-// head_final: cv2.l.2 + cv3.l.2 (1x1, no activation) + decode.  One 256-thread workgroup per 64 anchors of one
+// head_final: cv2.l.2 + cv3.l.2 (1x1, no activation) + decode.  One 512-thread workgroup per 128 anchors of one
 // level of one image: the two input tiles and both weight matrices arrive by LDS-DMA (16-row x 64-byte pieces,
 // XOR-swizzled on the source address like conv.hip), each wave multiplies one 16-anchor tile on the matrix
 // cores, the logits are rounded to fp16 into an LDS row per anchor -- exactly what the head tensor would hold --
@@ -176,12 +176,17 @@ __device__ __forceinline__ void hf_dma16(const f16 *src, unsigned char *dst) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src, (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
 }
 
+constexpr int HF_WAVES = 8, HF_ANCHORS = 16 * HF_WAVES;     // 8 waves: twice the DMA issue rate, weights amortised over 128 anchors
+
 template <int KCC, int NTC>      // ccls / 32, ceil(nc / 16)
-__global__ __launch_bounds__(256) void head_final_kernel(HeadFinalArgs a) {
+__global__ __launch_bounds__(64 * HF_WAVES) void head_final_kernel(HeadFinalArgs a) {
+    constexpr int NW = HF_WAVES;
     constexpr int KCB = 2, NTB = 4;                       // cbox = 64: two 32-deep chunks; 64 box logits: four 16-wide tiles
-    constexpr int XB = 0, XC = XB + KCB * 4 * 1024, WB = XC + KCC * 4 * 1024, WC = WB + KCB * NTB * 1024, OUT = WC + KCC * NTC * 1024;
+    constexpr int XB = 0, XC = XB + KCB * NW * 1024, WB = XC + KCC * NW * 1024, WC = WB + KCB * NTB * 1024, END = WC + KCC * NTC * 1024;
     constexpr int ROWO = (64 + NTC * 16) * 2 + 16;
-    __shared__ __attribute__((aligned(1024))) unsigned char lds[OUT + 64 * ROWO];
+    constexpr int OUT = 0;                                 // the logit rows reuse the (consumed) input tiles
+    static_assert(HF_ANCHORS * ROWO <= WB, "logit rows must fit the input-tile region");
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[END];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r = lane & 15, q = lane >> 4;
     const int ld_row = lane >> 2, ld_chunk = (lane & 3) ^ hf_swz(ld_row), rd_off = r * 64 + ((q ^ hf_swz(r)) << 4);
@@ -196,7 +201,7 @@ __global__ __launch_bounds__(256) void head_final_kernel(HeadFinalArgs a) {
     }
     const HeadFinalLevel L = l == 0 ? a.lvl[0] : (l == 1 ? a.lvl[1] : a.lvl[2]);
     const int b = rest / L.tiles, tile = rest - b * L.tiles;
-    const int HW = L.H * L.W, a0 = tile * 64;
+    const int HW = L.H * L.W, a0 = tile * HF_ANCHORS;
 
     // ---- operands -> LDS ----
     {
@@ -204,14 +209,14 @@ __global__ __launch_bounds__(256) void head_final_kernel(HeadFinalArgs a) {
         const f16 *xb = L.xb + ((long)b * HW + an) * a.cbox + ld_chunk * 8;
         const f16 *xc = L.xc + ((long)b * HW + an) * a.ccls + ld_chunk * 8;
 #pragma unroll
-        for (int kc = 0; kc < KCB; ++kc) hf_dma16(xb + kc * 32, lds + XB + (kc * 4 + wave) * 1024);
+        for (int kc = 0; kc < KCB; ++kc) hf_dma16(xb + kc * 32, lds + XB + (kc * NW + wave) * 1024);
 #pragma unroll
-        for (int kc = 0; kc < KCC; ++kc) hf_dma16(xc + kc * 32, lds + XC + (kc * 4 + wave) * 1024);
-        for (int pi = wave; pi < KCB * NTB; pi += 4) {
+        for (int kc = 0; kc < KCC; ++kc) hf_dma16(xc + kc * 32, lds + XC + (kc * NW + wave) * 1024);
+        for (int pi = wave; pi < KCB * NTB; pi += NW) {
             const int kc = pi / NTB, u = pi - kc * NTB;
             hf_dma16(L.wb + ((u * 16 + ld_row) * a.cbox + kc * 32 + ld_chunk * 8), lds + WB + pi * 1024);
         }
-        for (int pi = wave; pi < KCC * NTC; pi += 4) {
+        for (int pi = wave; pi < KCC * NTC; pi += NW) {
             const int kc = pi / NTC, u = pi - kc * NTC;
             hf_dma16(L.wc + ((u * 16 + ld_row) * a.ccls + kc * 32 + ld_chunk * 8), lds + WC + pi * 1024);
         }
@@ -232,18 +237,19 @@ __global__ __launch_bounds__(256) void head_final_kernel(HeadFinalArgs a) {
     for (int u = 0; u < NTC; ++u) accc[u] = hf_floatx4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int kc = 0; kc < KCB; ++kc) {
-        const hf_half8 fa = *(const hf_half8 *)(lds + XB + (kc * 4 + wave) * 1024 + rd_off);
+        const hf_half8 fa = *(const hf_half8 *)(lds + XB + (kc * NW + wave) * 1024 + rd_off);
 #pragma unroll
         for (int u = 0; u < NTB; ++u)
             accb[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(*(const hf_half8 *)(lds + WB + (kc * NTB + u) * 1024 + rd_off), fa, accb[u], 0, 0, 0);
     }
 #pragma unroll
     for (int kc = 0; kc < KCC; ++kc) {
-        const hf_half8 fa = *(const hf_half8 *)(lds + XC + (kc * 4 + wave) * 1024 + rd_off);
+        const hf_half8 fa = *(const hf_half8 *)(lds + XC + (kc * NW + wave) * 1024 + rd_off);
 #pragma unroll
         for (int u = 0; u < NTC; ++u)
             accc[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(*(const hf_half8 *)(lds + WC + (kc * NTC + u) * 1024 + rd_off), fa, accc[u], 0, 0, 0);
     }
+    __syncthreads();                                       // every wave has consumed its input tiles: their space becomes the logit rows
     // bias (no activation), one rounding to fp16: the row the head tensor would hold
     unsigned char *row = lds + OUT + (wave * 16 + r) * ROWO;
 #pragma unroll
@@ -286,11 +292,11 @@ int launch_head_final(const HeadFinalArgs &a, hipStream_t s) {
     RT_CHECK(a.no % 8 == 0 && a.no >= 64 + a.nc && a.no <= 64 + 80, RTMODT_E_INVALID, "head_final: head row stride %d", a.no);
     int blocks = 0;
     for (int l = 0; l < 3; ++l) {
-        RT_CHECK(a.lvl[l].tiles == cdiv(a.lvl[l].H * a.lvl[l].W, 64), RTMODT_E_INVALID, "head_final: tiles of level %d", l);
+        RT_CHECK(a.lvl[l].tiles == cdiv(a.lvl[l].H * a.lvl[l].W, HF_ANCHORS), RTMODT_E_INVALID, "head_final: tiles of level %d", l);
         blocks += a.lvl[l].tiles * a.B;
     }
-    if (a.ccls == 128) hipLaunchKernelGGL((head_final_kernel<4, 5>), dim3(blocks), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((head_final_kernel<6, 5>), dim3(blocks), dim3(256), 0, s, a);
+    if (a.ccls == 128) hipLaunchKernelGGL((head_final_kernel<4, 5>), dim3(blocks), dim3(64 * HF_WAVES), 0, s, a);
+    else hipLaunchKernelGGL((head_final_kernel<6, 5>), dim3(blocks), dim3(64 * HF_WAVES), 0, s, a);
     RT_HIP(hipGetLastError());
     return RTMODT_OK;
 }

@@ -227,7 +227,8 @@ def test_end_to_end_vs_fp32_oracle(pkg, wdir):
     _, _, pred = det.debug_fetch(0, want_input=False, want_heads=False)
     # (1) pre-NMS tensors agree to fp16 tolerance
     cand = im["pred"][4:].max(0) > 0.2
-    assert np.abs(pred[:4, cand] - im["pred"][:4, cand]).max() < 3.0          # pixels; P5 boxes are ~480 px wide (stride 32)
+    extent = np.maximum(im["pred"][2, cand], im["pred"][3, cand])             # box size in pixels (P5 boxes are ~480 px wide)
+    assert np.all(np.abs(pred[:4, cand] - im["pred"][:4, cand]) <= 0.01 * extent + 0.5)      # fp16 net vs fp32 net: 1 % of the box + half a pixel
     assert np.abs(pred[4:] - im["pred"][4:]).max() < 0.03
     # (2) NMS on the engine's tensor is exact
     dets, _ = Y.non_max_suppression(pred, 0.35, 0.45, [0, 1, 2, 3, 5, 7, 17, 18], False, 300)
