@@ -47,6 +47,10 @@ struct BneckArgs {
     int res_Hp, res_Wp, res_cs, res_pad;
     int kp;                                  // weight row stride (= 9 * CH)
     int tiles_x, tiles_y;
+    // optional C2f.cv2 tail: a 1x1 conv over [t_in (K1 channels, the earlier chunks of the C2f concat) | this bottleneck's output];
+    // only the tail's output is stored
+    const f16 *t_in, *t_wt; const float *t_bias; f16 *t_out;
+    int t_k1, t_cout, t_kp, t_act, t_in_Hp, t_in_Wp, t_in_cs, t_out_Hp, t_out_Wp, t_out_cs, t_out_pad;
 };
 
 constexpr int BN_THREADS = 512, BN_WAVES = 8;
@@ -70,6 +74,8 @@ struct BneckGeom {
     static constexpr int PATCH_BYTES = NCH * P_ROWS * CB, T_BYTES = NCH * T_ROWS * CB;
     static constexpr int LDS_BYTES = PATCH_BYTES + T_BYTES + 2 * W_STEP;
     static_assert(M2 % 16 == 0, "tile must hold whole 16-pixel MFMA tiles");
+    // tail variant (C2f.cv2 fused): y tile + 2 CH channels of the concat for the tile's pixels + the 1x1's weights, or its output tile
+    static constexpr int LDS_TAIL = 152 * 1024;
 };
 
 // byte offset of 16-byte chunk c16 of row R inside a piece-structured, swizzled plane
@@ -124,7 +130,7 @@ __device__ __forceinline__ void gemm_from_lds(const unsigned char *src, unsigned
     }
 }
 
-template <int CH, int TH, int TW>
+template <int CH, int TH, int TW, int N2T = 0>   // N2T > 0: C2f.cv2 fused as a tail with 16 * N2T output channels, K1 = 2 * CH
 __global__ __launch_bounds__(BN_THREADS) void bottleneck_fused(BneckArgs p) {
     using G = BneckGeom<CH, TH, TW>;
     constexpr int CB = G::CB, NCH = G::NCH, RPP = G::RPP, NT = G::NT;
@@ -237,30 +243,107 @@ __global__ __launch_bounds__(BN_THREADS) void bottleneck_fused(BneckArgs p) {
                 *(half4 *)(patch + m * ROWB + n * 2) = half4{(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
             }
         }
-        __syncthreads();
-        constexpr int CPR = CH / 8;
-        for (int c = threadIdx.x; c < G::M2 * CPR; c += BN_THREADS) {
-            const int m = c / CPR, k8 = c - m * CPR;
-            const int oy = m / TW, ox = m - oy * TW;
-            const int gy = y0 + oy, gx = x0 + ox;
-            if (gy >= p.H || gx >= p.W) continue;
-            const long opix = ((long)(b * p.out_Hp + gy + p.out_pad) * p.out_Wp + gx + p.out_pad) * p.out_cs;
-            *(half8 *)(p.out + opix + k8 * 8) = *(const half8 *)(patch + m * ROWB + k8 * 16);
+        if constexpr (N2T == 0) {
+            __syncthreads();
+            constexpr int CPR = CH / 8;
+            for (int c = threadIdx.x; c < G::M2 * CPR; c += BN_THREADS) {
+                const int m = c / CPR, k8 = c - m * CPR;
+                const int oy = m / TW, ox = m - oy * TW;
+                const int gy = y0 + oy, gx = x0 + ox;
+                if (gy >= p.H || gx >= p.W) continue;
+                const long opix = ((long)(b * p.out_Hp + gy + p.out_pad) * p.out_Wp + gx + p.out_pad) * p.out_cs;
+                *(half8 *)(p.out + opix + k8 * 8) = *(const half8 *)(patch + m * ROWB + k8 * 16);
+            }
+        } else {
+            // ---- 3. C2f.cv2 as a tail: out = act(W2 . [t_in (K1 = 2 CH channels from HBM) | y (CH channels, the tile above)] + b2) ----
+            // LDS from here on: [y tile M2 x ROWB][A: K1/32 x M2T pieces][W2: K2/32 x N2T pieces]; conv1/conv2 buffers are dead
+            constexpr int K1C = 2 * CH / 32, KYC = CH / 32, K2C = K1C + KYC, M2T = G::M2T;
+            constexpr int A_OFF = (G::M2 * ROWB + 1023) / 1024 * 1024, W_OFF = A_OFF + K1C * M2T * 1024;
+            constexpr int ROWO = N2T * 32 + 16;
+            static_assert(W_OFF + K2C * N2T * 1024 <= G::LDS_TAIL && G::M2 * ROWO <= G::LDS_TAIL, "tail buffers");
+            static_assert(M2T % BN_WAVES == 0, "pixel tiles must split over the waves");
+            __syncthreads();                                   // y tile complete; tbuf / weight ring free
+            {
+                const int ld_row = lane >> 2, ld_chunk = (lane & 3) ^ (((ld_row >> 3) & 1) * 3);
+                for (int pi = wave; pi < K1C * M2T; pi += BN_WAVES) {       // earlier C2f chunks of this tile's pixels
+                    const int kc = pi / M2T, mt = pi - kc * M2T;
+                    const int m = mt * 16 + ld_row;
+                    const int gy = min(y0 + m / TW, p.H - 1), gx = min(x0 + m % TW, p.W - 1);   // outside the image: any valid pixel (never stored)
+                    dma16(p.t_in + (((long)(b * p.t_in_Hp + gy + 1) * p.t_in_Wp + gx + 1) * p.t_in_cs + kc * 32 + ld_chunk * 8), lds + A_OFF + pi * 1024);
+                }
+                for (int pi = wave; pi < K2C * N2T; pi += BN_WAVES) {       // the tail's weights, K order = concat order
+                    const int kc = pi / N2T, u = pi - kc * N2T;
+                    dma16(p.t_wt + ((long)(u * 16 + ld_row) * p.t_kp + kc * 32 + ld_chunk * 8), lds + W_OFF + pi * 1024);
+                }
+            }
+            constexpr int TMT = M2T / BN_WAVES;
+            floatx4 acc2[TMT][N2T], b2v[N2T];
+#pragma unroll
+            for (int u = 0; u < N2T; ++u) {
+                b2v[u] = *(const floatx4 *)(p.t_bias + u * 16 + q * 4);
+#pragma unroll
+                for (int i = 0; i < TMT; ++i) acc2[i][u] = floatx4{0.f, 0.f, 0.f, 0.f};
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            const int rd_off = r * 64 + ((q ^ (((r >> 3) & 1) * 3)) << 4);
+#pragma unroll
+            for (int kc = 0; kc < K2C; ++kc) {
+                half8 fa[TMT], fb[N2T];
+#pragma unroll
+                for (int i = 0; i < TMT; ++i) {
+                    const int mt = wave + BN_WAVES * i;
+                    fa[i] = kc < K1C ? *(const half8 *)(lds + A_OFF + (kc * M2T + mt) * 1024 + rd_off)
+                                     : *(const half8 *)(lds + (mt * 16 + r) * ROWB + ((kc - K1C) * 4 + q) * 16);
+                }
+#pragma unroll
+                for (int u = 0; u < N2T; ++u) fb[u] = *(const half8 *)(lds + W_OFF + (kc * N2T + u) * 1024 + rd_off);
+#pragma unroll
+                for (int i = 0; i < TMT; ++i)
+#pragma unroll
+                    for (int u = 0; u < N2T; ++u) acc2[i][u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[u], fa[i], acc2[i][u], 0, 0, 0);
+            }
+            __syncthreads();                                   // every wave is done with the y tile and the operands
+#pragma unroll
+            for (int i = 0; i < TMT; ++i) {
+                const int m = (wave + BN_WAVES * i) * 16 + r;
+#pragma unroll
+                for (int u = 0; u < N2T; ++u) {
+                    floatx4 v = acc2[i][u] + b2v[u];
+                    if (p.t_act) { v[0] = silu_b(v[0]); v[1] = silu_b(v[1]); v[2] = silu_b(v[2]); v[3] = silu_b(v[3]); }
+                    *(half4 *)(lds + m * ROWO + (u * 16 + q * 4) * 2) = half4{(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
+                }
+            }
+            __syncthreads();
+            constexpr int CPR = N2T * 2;
+            for (int c = threadIdx.x; c < G::M2 * CPR; c += BN_THREADS) {
+                const int m = c / CPR, k8 = c - m * CPR;
+                if (k8 * 8 >= p.t_cout) continue;
+                const int gy = y0 + m / TW, gx = x0 + m % TW;
+                if (gy >= p.H || gx >= p.W) continue;
+                const long opix = ((long)(b * p.t_out_Hp + gy + p.t_out_pad) * p.t_out_Wp + gx + p.t_out_pad) * p.t_out_cs;
+                *(half8 *)(p.t_out + opix + k8 * 8) = *(const half8 *)(lds + m * ROWO + k8 * 16);
+            }
         }
     }
 }
 
-template <int CH, int TH, int TW>
+template <int CH, int TH, int TW, int N2T = 0>
 int launch_one(const BneckArgs &a0, int H, int W, int B, hipStream_t s) {
     using G = BneckGeom<CH, TH, TW>;
+    constexpr int ROWB = CH * 2 + 16;
+    constexpr int A_OFF = (G::M2 * ROWB + 1023) / 1024 * 1024, TAIL_END = A_OFF + (2 * CH / 32) * G::M2T * 1024 + (3 * CH / 32) * N2T * 1024;
+    constexpr int TAIL_OUT = G::M2 * (N2T * 32 + 16);
+    constexpr int LDS = N2T == 0 ? G::LDS_BYTES : std::max(G::LDS_BYTES, std::max(TAIL_END, TAIL_OUT));
+    static_assert(LDS <= G::LDS_TAIL, "LDS budget");
     BneckArgs a = a0;
     a.tiles_x = cdiv(W, TW); a.tiles_y = cdiv(H, TH);
     static size_t attr = 0;
-    if ((size_t)G::LDS_BYTES > attr) {
-        RT_HIP(hipFuncSetAttribute((const void *)bottleneck_fused<CH, TH, TW>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES));
-        attr = G::LDS_BYTES;
+    if ((size_t)LDS > attr) {
+        RT_HIP(hipFuncSetAttribute((const void *)bottleneck_fused<CH, TH, TW, N2T>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        attr = LDS;
     }
-    hipLaunchKernelGGL((bottleneck_fused<CH, TH, TW>), dim3(a.tiles_x * a.tiles_y * B), dim3(BN_THREADS), G::LDS_BYTES, s, a);
+    hipLaunchKernelGGL((bottleneck_fused<CH, TH, TW, N2T>), dim3(a.tiles_x * a.tiles_y * B), dim3(BN_THREADS), LDS, s, a);
     RT_HIP(hipGetLastError());
     return RTMODT_OK;
 }
@@ -275,6 +358,8 @@ int launch_bottleneck(const BottleneckLaunch &l, hipStream_t s) {
     RT_CHECK(in.pad == 1 && in.c == l.c && out.c == l.c && in.H == out.H && in.W == out.W && l.kp == 9 * l.c, RTMODT_E_INVALID,
              "launch_bottleneck: shapes");
     RT_CHECK(in.coff % 8 == 0 && in.C % 8 == 0 && out.coff % 8 == 0 && out.C % 8 == 0 && l.zeros, RTMODT_E_INVALID, "launch_bottleneck: alignment");
+    for (const TensorView *v : {&in, &out, &res})
+        RT_CHECK(!v->base || (uintptr_t)v->base >= (1ull << 32), RTMODT_E_INVALID, "launch_bottleneck: view base %p is not a device address", (void *)v->base);
     BneckArgs a{};
     a.in = in.base + in.coff; a.w1 = l.w1; a.w2 = l.w2; a.b1 = l.b1; a.b2 = l.b2; a.zeros = l.zeros;
     a.out = out.base + out.coff;
@@ -285,6 +370,22 @@ int launch_bottleneck(const BottleneckLaunch &l, hipStream_t s) {
     a.res_Hp = res.H + 2 * res.pad; a.res_Wp = res.W + 2 * res.pad; a.res_cs = res.C; a.res_pad = res.pad;
     a.kp = l.kp;
     if (a.res) RT_CHECK(res.H == out.H && res.W == out.W && res.c == l.c && res.coff % 4 == 0, RTMODT_E_INVALID, "launch_bottleneck: residual shape");
+    if (l.tail_wt) {                                       // C2f.cv2 fused as a tail (c = 32 -> 64 outputs, c = 64 -> 128 outputs)
+        const TensorView &ti = l.tail_in, &to = l.tail_out;
+        RT_CHECK((l.c == 32 || l.c == 64) && l.tail_cout == 2 * l.c && l.tail_kp == 3 * l.c && l.tail_bias, RTMODT_E_INVALID,
+                 "launch_bottleneck: tail shapes (c %d, tail cout %d kp %d)", l.c, l.tail_cout, l.tail_kp);
+        RT_CHECK(ti.base && ti.pad == 1 && ti.c == 2 * l.c && ti.H == in.H && ti.W == in.W && ti.coff % 8 == 0 && ti.C % 8 == 0 && to.base && to.H == in.H &&
+                     to.W == in.W && to.c == l.tail_cout && to.coff % 8 == 0 && to.C % 8 == 0,
+                 RTMODT_E_INVALID, "launch_bottleneck: tail views");
+        for (const TensorView *v : {&ti, &to})
+            RT_CHECK((uintptr_t)v->base >= (1ull << 32), RTMODT_E_INVALID, "launch_bottleneck: view base %p is not a device address", (void *)v->base);
+        a.t_in = ti.base + ti.coff; a.t_wt = l.tail_wt; a.t_bias = l.tail_bias; a.t_out = to.base + to.coff;
+        a.t_k1 = 2 * l.c; a.t_cout = l.tail_cout; a.t_kp = l.tail_kp; a.t_act = l.tail_act;
+        a.t_in_Hp = ti.H + 2; a.t_in_Wp = ti.W + 2; a.t_in_cs = ti.C;
+        a.t_out_Hp = to.H + 2 * to.pad; a.t_out_Wp = to.W + 2 * to.pad; a.t_out_cs = to.C; a.t_out_pad = to.pad;
+        if (l.c == 32) return launch_one<32, 16, 16, 4>(a, in.H, in.W, l.B, s);
+        return launch_one<64, 16, 16, 8>(a, in.H, in.W, l.B, s);
+    }
     switch (l.c) {
         case 32: return launch_one<32, 16, 16>(a, in.H, in.W, l.B, s);
         case 64: return launch_one<64, 16, 16>(a, in.H, in.W, l.B, s);

@@ -290,7 +290,7 @@ static Op sub_batch(const Op &op, int b0, int nb) {
     if (o.kind == OP_CONV) { shift(o.conv.in); shift(o.conv.out); shift(o.conv.res); shift(o.conv.out2); shift(o.conv.tail_out); o.conv.B = nb; }
     else if (o.kind == OP_GROUP || o.kind == OP_BNECK) {
         for (auto &c : o.group) { shift(c.in); shift(c.out); shift(c.res); c.B = nb; }
-        if (o.kind == OP_BNECK) { shift(o.bneck.in); shift(o.bneck.out); shift(o.bneck.res); o.bneck.B = nb; }
+        if (o.kind == OP_BNECK) { shift(o.bneck.in); shift(o.bneck.out); shift(o.bneck.res); shift(o.bneck.tail_in); shift(o.bneck.tail_out); o.bneck.B = nb; }
     }
     else for (auto &v : o.v) shift(v);
     return o;
@@ -424,6 +424,17 @@ static int build_graph(rtmodt_detector *d, WeightFile &wf) {
             conv(m + ".cv2", V(tmp), V(cat, (2 + j) * c, c), shortcut ? &r : nullptr);
         }
         conv(i + ".cv2", V(cat, 0, (2 + n) * c), out);
+        // C2f with ONE Bottleneck of 32 / 64 channels run as a fused launch: cv2 can ride along as its tail (bottleneck.hip),
+        // reading the two earlier chunks from the concat tensor and this Bottleneck's output from LDS
+        if (rc == RTMODT_OK && n == 1 && (c == 32 || c == 64) && d->ops.size() >= 2 && !getenv("RTMODT_NO_BNECK_TAIL")) {
+            Op &bn = d->ops[d->ops.size() - 2], &cv = d->ops.back();
+            if (bn.kind == OP_BNECK && cv.kind == OP_CONV && cv.conv.cout == 2 * c && cv.conv.kp == 3 * c && !cv.conv.res.base && cv.conv.out.coff % 8 == 0 &&
+                cv.conv.out.C % 8 == 0) {
+                bn.bneck.tail_in = V(cat, 0, 2 * c); bn.bneck.tail_out = cv.conv.out; bn.bneck.tail_wt = cv.conv.wt; bn.bneck.tail_bias = cv.conv.bias;
+                bn.bneck.tail_cout = cv.conv.cout; bn.bneck.tail_kp = cv.conv.kp; bn.bneck.tail_act = cv.conv.act;
+                if (const char *e = getenv("RTMODT_BNECK_TAIL")) { bn.tail_on = atoi(e) != 0; cv.skip = bn.tail_on && bn.fused; }   // test hook (no autotune)
+            }
+        }
     };
 
     const int H = d->in_h, W = d->in_w;
@@ -482,11 +493,17 @@ static int build_graph(rtmodt_detector *d, WeightFile &wf) {
     TensorView out9 = V(cat20, c4, c5);
     conv("9.cv2", V(cat9), out9);
     const bool fold_up = getenv("RTMODT_NO_UPFOLD") == nullptr;   // A/B switch: separate upsample2 launches instead
-    if (fold_up) d->ops.back().conv.out2 = V(cat11, 0, c5);   // layer 10 (Upsample) + 11 (Concat) folded into 9.cv2's epilogue
+    // a conv that also writes the nearest-2x copy cannot run as the tail of the Bottleneck before it
+    auto fold_into_last = [&](const TensorView &up) {
+        d->ops.back().conv.out2 = up;
+        d->ops.back().skip = false;
+        if (d->ops.size() >= 2) { Op &bn = d->ops[d->ops.size() - 2]; if (bn.kind == OP_BNECK) { bn.bneck.tail_wt = nullptr; bn.tail_on = false; } }
+    };
+    if (fold_up) fold_into_last(V(cat11, 0, c5));             // layer 10 (Upsample) + 11 (Concat) folded into 9.cv2's epilogue
     else { Op op; op.kind = OP_UP; op.name = "10.up"; op.v[0] = out9; op.v[1] = V(cat11, 0, c5); d->ops.push_back(op); }
     TensorView out12 = V(cat17, c3, c4);
     c2f("12", V(cat11), c4, rep(3), false, out12);
-    if (fold_up) d->ops.back().conv.out2 = V(cat14, 0, c4);   // layer 13 (Upsample) + 14 (Concat) folded into 12.cv2's epilogue
+    if (fold_up) fold_into_last(V(cat14, 0, c4));             // layer 13 (Upsample) + 14 (Concat) folded into 12.cv2's epilogue
     else { Op op; op.kind = OP_UP; op.name = "13.up"; op.v[0] = out12; op.v[1] = V(cat14, 0, c4); d->ops.push_back(op); }
     int t15 = T(H / 8, W / 8, c3, 1);
     c2f("15", V(cat14), c3, rep(3), false, V(t15));
@@ -583,7 +600,11 @@ static int build_graph(rtmodt_detector *d, WeightFile &wf) {
             if (op.conv.tail_out.c) rebase(op.conv.tail_out);
         } else if (op.kind == OP_GROUP || op.kind == OP_BNECK) {
             for (auto &c : op.group) { rebase(c.in); rebase(c.out); if (c.res.c) rebase(c.res); }
-            if (op.kind == OP_BNECK) { rebase(op.bneck.in); rebase(op.bneck.out); if (op.bneck.res.c) rebase(op.bneck.res); }
+            if (op.kind == OP_BNECK) {
+                rebase(op.bneck.in); rebase(op.bneck.out);
+                if (op.bneck.res.c) rebase(op.bneck.res);
+                if (op.bneck.tail_in.c) { rebase(op.bneck.tail_in); rebase(op.bneck.tail_out); }
+            }
         } else {
             for (auto &v : op.v) if (v.c) rebase(v);
         }
@@ -636,7 +657,12 @@ static int run_op_on(const Op &op, hipStream_t s) {
         }
         case OP_GROUP: return op.skip ? RTMODT_OK : launch_conv_group(op.group.data(), (int)op.group.size(), op.group_tile, s);
         case OP_BNECK:
-            if (op.fused) return launch_bottleneck(op.bneck, s);
+            if (op.fused) {
+                if (op.tail_on) return launch_bottleneck(op.bneck, s);       // with C2f.cv2 as its tail
+                BottleneckLaunch b = op.bneck;
+                b.tail_wt = nullptr;
+                return launch_bottleneck(b, s);
+            }
             RT_TRY(launch_conv(op.group[0], s));
             return launch_conv(op.group[1], s);
         case OP_POOL: return launch_sppf_pool(op.v[0], op.v[1], op.v[2], op.v[3], op.B, s);
@@ -775,7 +801,7 @@ static int autotune_ops(rtmodt_detector *d, std::vector<Op> &ops) {
             const TuneRec &r = hit->second;
             if (op.kind == OP_CONV) { op.conv.tile = r.t0; if (op.conv.tail_wt) { op.tail_tile = r.t1; op.tail_on = r.fused != 0; } }
             else if (op.kind == OP_GROUP) op.group_tile = r.t0;
-            else { op.group[0].tile = r.t0; op.group[1].tile = r.t1; op.fused = r.fused != 0; }
+            else { op.group[0].tile = r.t0; op.group[1].tile = r.t1; op.fused = r.fused != 0; op.tail_on = r.fused == 2 && op.bneck.tail_wt; }
             continue;
         }
         float ms;
@@ -790,7 +816,9 @@ static int autotune_ops(rtmodt_detector *d, std::vector<Op> &ops) {
             float ms1, ms2, msf;
             RT_TRY(tune_conv(d, e0, e1, op.group[0].in.c ? op.name + ".cv1" : op.name, &op.group[0], 1, op.group[0].tile, ms1));
             RT_TRY(tune_conv(d, e0, e1, op.name + ".cv2", &op.group[1], 1, op.group[1].tile, ms2));
-            RT_TRY(time_launch(d, e0, e1, [&]() { return launch_bottleneck(op.bneck, d->stream); }, msf));
+            BottleneckLaunch plain = op.bneck;
+            plain.tail_wt = nullptr;
+            RT_TRY(time_launch(d, e0, e1, [&]() { return launch_bottleneck(plain, d->stream); }, msf));
             if (getenv("RTMODT_TUNE_LOG")) fprintf(stderr, "[tune] %-28s fused %8.2f us vs two launches %8.2f us\n", op.name.c_str(), msf * 1e3f, (ms1 + ms2) * 1e3f);
             op.fused = msf < ms1 + ms2;
             if (const char *e = getenv("RTMODT_BNECK")) op.fused = atoi(e) != 0;      // A/B and test hook
@@ -826,6 +854,30 @@ static int autotune_ops(rtmodt_detector *d, std::vector<Op> &ops) {
             dirty = true;
         }
         if (const char *e = getenv("RTMODT_TAIL")) op.tail_on = atoi(e) != 0 && tile_shape(op.tail_tile).bn == op.conv.cout;   // A/B and test hook
+        nx.skip = op.tail_on;
+    }
+    // fused Bottleneck + C2f.cv2 as its tail against the fused Bottleneck followed by cv2's own launch
+    for (size_t i = 0; i + 1 < ops.size(); ++i) {
+        Op &op = ops[i], &nx = ops[i + 1];
+        if (op.kind != OP_BNECK || !op.bneck.tail_wt) continue;
+        const std::string key = tune_key(d, op);
+        auto hit = cache.find(key);
+        const bool decided = hit != cache.end() && hit->second.fused >= 2;      // 2 = fused with tail, 3 = tail timed and rejected
+        if (!decided && op.fused) {
+            float ms_plain, ms_cv2, ms_tail;
+            BottleneckLaunch plain = op.bneck;
+            plain.tail_wt = nullptr;
+            RT_TRY(time_launch(d, e0, e1, [&]() { return launch_bottleneck(plain, d->stream); }, ms_plain));
+            RT_TRY(time_launch(d, e0, e1, [&]() { return launch_conv(nx.conv, d->stream); }, ms_cv2));
+            RT_TRY(time_launch(d, e0, e1, [&]() { return launch_bottleneck(op.bneck, d->stream); }, ms_tail));
+            op.tail_on = ms_tail < ms_plain + ms_cv2;
+            if (getenv("RTMODT_TUNE_LOG")) fprintf(stderr, "[tune] %-28s with cv2 tail %8.2f us vs fused + cv2 %8.2f us\n", op.name.c_str(), ms_tail * 1e3f, (ms_plain + ms_cv2) * 1e3f);
+            TuneRec r; r.t0 = op.group[0].tile; r.t1 = op.group[1].tile; r.fused = op.tail_on ? 2 : 3;
+            cache[key] = r;
+            dirty = true;
+        }
+        if (const char *e = getenv("RTMODT_BNECK_TAIL")) op.tail_on = atoi(e) != 0;      // A/B and test hook
+        op.tail_on = op.tail_on && op.fused;
         nx.skip = op.tail_on;
     }
     hipEventDestroy(e0); hipEventDestroy(e1);
@@ -1345,6 +1397,9 @@ int rtmodt_detector_debug_layer(rtmodt_detector *d, const char *name, int img, u
     for (auto &op : d->ops)                               // a conv whose 1x1 tail runs in the same launch stores only the tail's output
         if (op.kind == OP_CONV && op.tail_on && op.name == name)
             return fail(RTMODT_E_UNSUPPORTED, "%s is consumed in LDS by the 1x1 conv fused into its launch", name);
+    for (auto &op : d->ops)                               // ... and so does a fused Bottleneck whose C2f.cv2 runs as its tail
+        if (op.kind == OP_BNECK && op.fused && op.tail_on && op.name == std::string(name).substr(0, std::string(name).rfind('.')) + " (cv1+cv2)")
+            return fail(RTMODT_E_UNSUPPORTED, "%s is consumed in LDS by the 1x1 conv fused into its launch", name);
     for (auto &op : d->ops)                               // the first conv of a fused Bottleneck never leaves the CU
         if (op.kind == OP_BNECK && op.fused && op.name == std::string(name).substr(0, std::string(name).rfind('.')) + " (cv1+cv2)" &&
             std::string(name).size() > 4 && std::string(name).compare(std::string(name).size() - 4, 4, ".cv1") == 0)
@@ -1392,7 +1447,7 @@ int rtmodt_detector_profile(rtmodt_detector *d, int iters, int max_entries, cons
             snprintf(buf, sizeof(buf), "%s [M=%d N=%d K=%d k%d s%d tile %s]", op.name.c_str(), d->B * op.conv.out.H * op.conv.out.W,
                      op.conv.cout, op.conv.ks * op.conv.ks * op.conv.cin, op.conv.ks, op.conv.stride, tile_name(op.tail_on ? op.tail_tile : op.conv.tile));
         } else if (op.kind == OP_BNECK) {
-            if (op.fused) snprintf(buf, sizeof(buf), "%s [fused bottleneck, c=%d, %dx%d]", op.name.c_str(), op.bneck.c, op.bneck.in.H, op.bneck.in.W);
+            if (op.fused) snprintf(buf, sizeof(buf), "%s [fused bottleneck%s, c=%d, %dx%d]", op.name.c_str(), op.tail_on ? " + C2f.cv2 tail" : "", op.bneck.c, op.bneck.in.H, op.bneck.in.W);
             else snprintf(buf, sizeof(buf), "%s [two launches: %s, %s]", op.name.c_str(), tile_name(op.group[0].tile), tile_name(op.group[1].tile));
         } else if (op.kind == OP_GROUP && op.skip) {
             snprintf(buf, sizeof(buf), "%s [runs inside head_final]", op.name.c_str());

@@ -67,6 +67,9 @@ struct BottleneckLaunch {
     const float *b1 = nullptr, *b2 = nullptr;
     const f16 *zeros = nullptr;   // >= 16 bytes of zeros in device memory
     int B = 1, c = 0, kp = 0;
+    // optional C2f.cv2 tail (last Bottleneck of a C2f with n = 1, c in {32, 64}): out2 = act(W . [tail_in (2c channels) | this output] + b);
+    // only tail_out is stored
+    TensorView tail_in, tail_out; const f16 *tail_wt = nullptr; const float *tail_bias = nullptr; int tail_cout = 0, tail_kp = 0, tail_act = 1;
 };
 bool bottleneck_supported(int c);
 int launch_bottleneck(const BottleneckLaunch &l, hipStream_t s);

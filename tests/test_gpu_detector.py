@@ -652,3 +652,39 @@ def test_eight_wave_tiles(pkg, wdir, monkeypatch, tile):
                 err = float(np.abs(taps[n] - gpu[n]).max())
                 assert err <= tol, f"tile {tile} epi {epi} img {img} layer {n}: max err {err:.4g} > tol {tol:.4g}"
         det.close()
+
+
+@pytest.mark.parametrize("size,batch", [(320, 2), (288, 1), (640, 1)])
+def test_bottleneck_with_c2f_cv2_tail(pkg, wdir, monkeypatch, size, batch):
+    """C2f with one Bottleneck (layers 2 and 15 of YOLOv8s): the fused Bottleneck launch also runs C2f.cv2 on
+    [the two earlier concat chunks from HBM | its own output tile in LDS]; the Bottleneck's output tensor is never
+    stored.  Forced on / off with every other conv on the 64x64 tile: stored layers bit-identical between the two
+    (same k order: concat order) and within tolerance of the oracle; partial 16x16 tiles at 288."""
+    monkeypatch.setenv("RTMODT_BNECK", "1")
+    monkeypatch.setenv("RTMODT_TILE", "2")
+    monkeypatch.setenv("RTMODT_TAIL", "0")
+    frames = list(pkg.synth.frames(batch, size, size, seed=101))
+    names = [c.name for c in pkg.weights.spec("s")]
+    outs = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("RTMODT_BNECK_TAIL", mode)
+        det, w = make_detector(pkg, wdir, "s", size, autotune=False, batch=batch)
+        det.detect_batch(frames)
+        prof = [n for n, _, _ in det.profile(1)]
+        assert (sum("C2f.cv2 tail" in n for n in prof) == 2) == (mode == "1"), [n for n in prof if "bottleneck" in n]
+        outs[mode] = []
+        for img in range(batch):
+            inp, _, _ = det.debug_fetch(img, want_heads=False, want_pred=False)
+            gpu = fetch_layers(pkg, det, names, img)
+            outs[mode].append(gpu)
+            if mode == "1":
+                assert "2.m.0.cv2" not in gpu and "15.m.0.cv2" not in gpu and "2.cv2" in gpu and "15.cv2" in gpu and "4.m.1.cv2" in gpu
+                taps = {}
+                Y.forward(inp.astype(np.float32), w, "s", taps=taps, force=gpu)
+                for n in gpu:
+                    tol = (4e-3 if n in ("2.cv2", "15.cv2") else 2e-3) * np.abs(taps[n]).max() + 2e-3      # two fp16 intermediates live in LDS
+                    assert float(np.abs(taps[n] - gpu[n]).max()) <= tol, (img, n)
+        det.close()
+    for img in range(batch):
+        for n in outs["1"][img]:
+            assert np.array_equal(outs["0"][img][n], outs["1"][img][n]), (img, n)
