@@ -73,7 +73,8 @@ typedef struct rtmodt_det_cfg {
     int32_t max_src_w, max_src_h; /* largest source frame accepted (staging), 0 = in_w/in_h                */
     int32_t use_graph;         /* 1: replay the forward pass as one captured hipGraph                      */
     int32_t autotune;          /* 1: time every conv tile configuration at create and keep the fastest      */
-    int32_t chains;            /* sub-batches run as separate graphs on separate streams; 0 = 1 (more measured slower) */
+    int32_t chains;            /* sub-batches that run as independent chains (stem -> graph -> decode) on their own streams;
+                                * 0 = automatic: 2 once the batch holds 8 frames or more (measured faster), else 1 */
     int32_t rect;              /* 1: minimal-rectangle letterbox of `predict` on a .pt model (LetterBox auto=True): the scale is
                                 * min(S/h, S/w) with S = max(in_w, in_h) and in_w x in_h is the rectangle (1080p: 640 x 384) */
 } rtmodt_det_cfg;
@@ -106,6 +107,8 @@ int rtmodt_detector_fetch(rtmodt_detector *det, float *xyxy, float *conf, int32_
 /* Introspection used by the parity tests and bench.py */
 int rtmodt_detector_info(rtmodt_detector *det, int32_t *scale_id, int32_t *nc, int32_t *n_anchors,
                          int32_t *n_convs, int64_t *conv_flops_per_frame, int64_t *arena_bytes);
+/* Number of sub-batch chains this detector runs its batch as (see rtmodt_det_cfg.chains). */
+int rtmodt_detector_chains(rtmodt_detector *det, int32_t *n_chains);
 /* Copies out, for frame `img` of the last batch: the letterboxed network input as fp16 NHWC(3)
  * [in_h*in_w*3] (may be NULL), the three Detect maps as fp16 [A_i*(64+nc)] concatenated
  * P3,P4,P5 (may be NULL) and the decoded pre-NMS tensor pred[(4+nc)*A] float32 (may be NULL). */

@@ -186,6 +186,7 @@ struct rtmodt_detector {
     // are small and latency-bound, so independent chains in flight hide each other's launch
     // gaps, first-load latency and epilogue tails.
     int n_chains = 1;
+    bool chain_free_run = true;                       // chains never wait for each other (RTMODT_CHAIN_JOIN=1: join on the main stream per batch)
     std::vector<std::vector<Op>> chain_ops;
     std::vector<hipStream_t> aux_streams;             // fork targets during capture
     std::vector<hipEvent_t> aux_events;
@@ -228,7 +229,9 @@ struct rtmodt_detector {
         float *h_xyxy = nullptr, *h_conf = nullptr; int32_t *h_cls = nullptr, *h_n = nullptr;                        // pinned host
         hipEvent_t ev0 = nullptr, evp = nullptr, ev1 = nullptr, ev2 = nullptr, done = nullptr, decoded = nullptr;   // evp: letterbox done
         hipEvent_t copied = nullptr;       // this slot's frames have arrived in its staging area
+        std::vector<hipEvent_t> chain_done; // [n_chains] (entry 0 unused): chain c has finished this slot's sub-batch
         bool staged = false;               // the staging area has been read by a letterbox launch (evp is meaningful)
+        bool chained = false, joined = false;   // this slot's batch ran as sub-batch chains; the main stream has waited for all of them
         int n = 0;
     };
     static constexpr int RING_SLOTS = 2;
@@ -633,8 +636,10 @@ static int build_graph(rtmodt_detector *d, WeightFile &wf) {
     }
 
     // sub-batch chains (parallel graph branches)
-    int chains = d->cfg.chains > 0 ? d->cfg.chains : 1;   // measured on MI355X: chains > 1 run slower (kernels of separate streams do not overlap here)
+    // measured on MI355X (s @ 640): 2 x 4 frames +4.5 % over 1 x 8, 2 x 8 +7 % over 1 x 16, 2 x 16 +8.6 % over 1 x 32; 4 x 8 -12 % against 1 x 32
+    int chains = d->cfg.chains > 0 ? d->cfg.chains : (d->B >= 8 && d->B % 2 == 0 ? 2 : 1);
     if (const char *e = getenv("RTMODT_CHAINS")) chains = atoi(e);
+    if (const char *e = getenv("RTMODT_CHAIN_JOIN")) d->chain_free_run = atoi(e) == 0;
     chains = std::max(1, std::min(chains, d->B));
     while (d->B % chains) --chains;
     d->n_chains = chains;
@@ -672,39 +677,47 @@ static int run_op_on(const Op &op, hipStream_t s) {
 }
 static int run_op(rtmodt_detector *d, const Op &op) { return run_op_on(op, d->stream); }
 
-static int run_decode(rtmodt_detector *d) {
+// Detect's tail for images [b0, b0 + nb) on stream `st`
+static int run_decode_sub(rtmodt_detector *d, int b0, int nb, hipStream_t st) {
+    const rtmodt_detector::Dense &dn = d->dense[d->cur_dense];
+    const size_t a0 = (size_t)b0 * d->n_anchors;
     if (d->head_final && !d->want_pred) {                  // the two last convs of Detect and the decode in one launch
         HeadFinalArgs h = d->hf;
         h.conf = d->cfg.conf; h.class_mask[0] = d->class_mask[0]; h.class_mask[1] = d->class_mask[1];
-        const rtmodt_detector::Dense &dn = d->dense[d->cur_dense];
-        h.box = dn.box; h.score = dn.score; h.cls = dn.cls;
-        return launch_head_final(h, d->stream);
+        for (int l = 0; l < 3; ++l) {
+            const size_t hw = (size_t)h.lvl[l].H * h.lvl[l].W * b0;
+            h.lvl[l].xb += hw * h.cbox; h.lvl[l].xc += hw * h.ccls;
+        }
+        h.B = nb;
+        h.box = dn.box + a0; h.score = dn.score + a0; h.cls = dn.cls + a0;
+        return launch_head_final(h, st);
     }
     DecodeArgs a{};
     const int strides[3] = {8, 16, 32};
     for (int l = 0; l < 3; ++l) {
         const Tensor &t = d->tensors[d->head_t[l]];
-        a.lvl[l] = HeadLevel{t.ptr, t.H, t.W, strides[l]};
+        a.lvl[l] = HeadLevel{t.ptr + t.per_image * b0, t.H, t.W, strides[l]};
     }
-    a.B = d->B; a.nc = d->nc; a.n_anchors = d->n_anchors; a.conf = d->cfg.conf;
+    a.B = nb; a.nc = d->nc; a.n_anchors = d->n_anchors; a.conf = d->cfg.conf;
     a.no = d->tensors[d->head_t[0]].C;
     a.class_mask[0] = d->class_mask[0]; a.class_mask[1] = d->class_mask[1];
-    const rtmodt_detector::Dense &dn = d->dense[d->cur_dense];
-    a.box = dn.box; a.score = dn.score; a.cls = dn.cls;
-    a.pred = d->want_pred ? d->d_pred : nullptr;
-    return launch_decode(a, d->stream);
+    a.box = dn.box + a0; a.score = dn.score + a0; a.cls = dn.cls + a0;
+    a.pred = d->want_pred ? d->d_pred + a0 * (4 + d->nc) : nullptr;
+    return launch_decode(a, st);
 }
+static int run_decode(rtmodt_detector *d) { return run_decode_sub(d, 0, d->B, d->stream); }
 
 // the stem conv of every chain, on the main stream: straight from the frames' bytes (fused) or from the
 // letterboxed image tensor
+static int run_stem_chain(rtmodt_detector *d, int c, bool fused, hipStream_t st) {
+    const Op &op = d->chain_ops[c][0];
+    RT_CHECK(op.kind == OP_STEM, RTMODT_E_INVALID, "op 0 is not the stem");
+    if (fused) return launch_stem_fused(d->fptrs, c * op.B, d->last_pitch, d->last_lg, d->in_h, d->in_w, d->lut255, op.v[1], op.stem_w,
+                                        op.stem_b, op.B, op.v[1].c, st);
+    return run_op_on(op, st);
+}
 static int run_stems(rtmodt_detector *d, bool fused) {
-    for (int c = 0; c < d->n_chains; ++c) {
-        const Op &op = d->chain_ops[c][0];
-        RT_CHECK(op.kind == OP_STEM, RTMODT_E_INVALID, "op 0 is not the stem");
-        if (fused) RT_TRY(launch_stem_fused(d->fptrs, c * op.B, d->last_pitch, d->last_lg, d->in_h, d->in_w, d->lut255, op.v[1], op.stem_w,
-                                            op.stem_b, op.B, op.v[1].c, d->stream));
-        else RT_TRY(run_op_on(op, d->stream));
-    }
+    for (int c = 0; c < d->n_chains; ++c) RT_TRY(run_stem_chain(d, c, fused, d->stream));
     return RTMODT_OK;
 }
 // every launch after the stem, eagerly, on the main stream
@@ -988,20 +1001,36 @@ static int capture_graph(rtmodt_detector *d) {
     return RTMODT_OK;
 }
 
-// letterboxed input -> dense per-anchor candidates, on the main stream (+ chain streams)
+// stem output -> dense per-anchor candidates of a single-chain detector, on the main stream
 static int forward_graphs(rtmodt_detector *d) {
-    const int C = d->n_chains;
-    for (int c = 1; c < C; ++c) {
-        RT_HIP(hipEventRecord(d->chain_fork[c], d->stream));
-        RT_HIP(hipStreamWaitEvent(d->chain_streams[c], d->chain_fork[c], 0));
-    }
     const int inst = getenv("RTMODT_ONE_EXEC") ? 0 : (d->cur_dense & 1);   // ring slot parity
-    for (int c = 0; c < C; ++c) RT_HIP(hipGraphLaunch(d->graph_execs[2 * c + inst], d->chain_streams[c]));
-    for (int c = 1; c < C; ++c) {
-        RT_HIP(hipEventRecord(d->chain_join[c], d->chain_streams[c]));
-        RT_HIP(hipStreamWaitEvent(d->stream, d->chain_join[c], 0));
-    }
+    RT_HIP(hipGraphLaunch(d->graph_execs[inst], d->stream));
     return run_decode(d);
+}
+
+// Two (or more) sub-batch chains, each on its OWN stream from the stem to the decoded candidates: stem -> graph ->
+// Detect's tail of images [c * nb, (c + 1) * nb).  Nothing orders one chain against another -- chain c of batch t + 1
+// queues behind chain c of batch t only -- so the kernels of one chain fill the CUs the other's launch tails leave
+// idle (measured on MI355X, YOLOv8s @ 640, 16 frames: two chains of 8 run 5-8 % faster than one of 16).  The
+// post-processing stream waits for every chain of the slot.  `join_main`: the main stream waits for the other chains too
+// (needed when the next batch's whole-batch letterbox would overwrite an image tensor a lagging chain still reads).
+static int forward_chains(rtmodt_detector *d, rtmodt_detector::Slot &sl, bool host_frames, bool join_main) {
+    const int C = d->n_chains, nb = d->B / C;
+    const int inst = getenv("RTMODT_ONE_EXEC") ? 0 : (d->cur_dense & 1);
+    for (int c = 0; c < C; ++c) {
+        hipStream_t st = d->chain_streams[c];
+        if (c > 0) {
+            if (host_frames) RT_HIP(hipStreamWaitEvent(st, sl.copied, 0));
+            if (!d->last_fused) RT_HIP(hipStreamWaitEvent(st, sl.evp, 0));           // the whole-batch letterbox on the main stream
+        }
+        RT_TRY(run_stem_chain(d, c, d->last_fused, st));
+        if (c == 0 && d->last_fused) RT_HIP(hipEventRecord(sl.evp, d->stream));
+        RT_HIP(hipGraphLaunch(d->graph_execs[2 * c + inst], st));
+        RT_TRY(run_decode_sub(d, c * nb, nb, st));
+        if (c > 0) RT_HIP(hipEventRecord(sl.chain_done[c], st));
+    }
+    if (join_main) for (int c = 1; c < C; ++c) RT_HIP(hipStreamWaitEvent(d->stream, sl.chain_done[c], 0));
+    return RTMODT_OK;
 }
 
 static int run_nms(rtmodt_detector *d, const LbHost &g, int h, int w, rtmodt_detector::Slot &sl) {
@@ -1100,6 +1129,7 @@ void rtmodt_detector_destroy(rtmodt_detector *d) {
         hipFree(sl.o_xyxy); hipFree(sl.o_conf); hipFree(sl.o_cls); hipFree(sl.o_anchor); hipFree(sl.o_n);
         hipHostFree(sl.h_xyxy); hipHostFree(sl.h_conf); hipHostFree(sl.h_cls); hipHostFree(sl.h_n);
         for (hipEvent_t e : {sl.ev0, sl.evp, sl.ev1, sl.ev2, sl.done, sl.decoded, sl.copied}) if (e) hipEventDestroy(e);
+        for (hipEvent_t e : sl.chain_done) if (e) hipEventDestroy(e);
     }
     if (d->stream) hipStreamDestroy(d->stream);
     delete d;
@@ -1167,6 +1197,8 @@ static int detector_create_impl(const rtmodt_det_cfg *cfg, rtmodt_detector *d) {
         RT_HIP(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
         RT_HIP(hipEventCreateWithFlags(&sl.decoded, hipEventDisableTiming));
         RT_HIP(hipEventCreateWithFlags(&sl.copied, hipEventDisableTiming));
+        sl.chain_done.assign(d->n_chains, nullptr);
+        for (int c = 1; c < d->n_chains; ++c) RT_HIP(hipEventCreate(&sl.chain_done[c]));
     }
 
     {   // c / 255 in fp16 exactly as the letterbox kernel computes it (IEEE float division, then round to half)
@@ -1212,7 +1244,10 @@ int rtmodt_detector_enqueue_batch(rtmodt_detector *d, const uint8_t *const *fram
         RT_CHECK((size_t)h * stride_bytes <= d->stage_per, RTMODT_E_CAPACITY, "frame %dx%d exceeds max_src %dx%d", w, h, d->cfg.max_src_w,
                  d->cfg.max_src_h);
         uint8_t *area = d->stage + d->stage_per * d->B * d->head;
-        if (sl.staged) RT_HIP(hipStreamWaitEvent(d->copy_stream, sl.evp, 0));    // the letterbox that last read this area is done
+        if (sl.staged) {                                   // the launches that last read this area are done
+            RT_HIP(hipStreamWaitEvent(d->copy_stream, sl.evp, 0));
+            if (sl.chained) for (int c = 1; c < d->n_chains; ++c) RT_HIP(hipStreamWaitEvent(d->copy_stream, sl.chain_done[c], 0));
+        }
         for (int i = 0; i < n; ++i) {
             RT_HIP(hipMemcpyAsync(area + d->stage_per * i, frames[i], (size_t)h * stride_bytes, hipMemcpyHostToDevice, d->copy_stream));
             d->fptrs.p[i] = area + d->stage_per * i;
@@ -1247,17 +1282,36 @@ int rtmodt_detector_enqueue_batch(rtmodt_detector *d, const uint8_t *const *fram
     d->cur_dense = d->head;                            // ring slot == dense set == graph
     d->last_lg = lg; d->last_pitch = stride_bytes;
     d->last_fused = d->stem_fuse && !g.resize;
+    const bool graphs = !d->graph_execs.empty() && !d->want_pred;
+    const bool chained = graphs && d->n_chains > 1;
+    // a lagging chain of the previous batch may still be reading what the main stream is about to overwrite or time
+    if (!chained || !d->last_fused || !d->chain_free_run)
+        for (int k = 0; k < rtmodt_detector::RING_SLOTS; ++k)
+            if (d->slots[k].chained && !d->slots[k].joined) {
+                for (int c = 1; c < d->n_chains; ++c) RT_HIP(hipStreamWaitEvent(d->stream, d->slots[k].chain_done[c], 0));
+                d->slots[k].joined = true;
+            }
     RT_HIP(hipEventRecord(sl.ev0, d->stream));
-    if (!d->last_fused) RT_TRY(launch_letterbox(d->fptrs, stride_bytes, lg, d->tabs, img, d->B, d->stream));
-    RT_TRY(run_stems(d, d->last_fused));
-    RT_HIP(hipEventRecord(sl.evp, d->stream));              // the frames have been consumed (letterbox [+ stem])
-    if (!d->graph_execs.empty() && !d->want_pred) RT_TRY(forward_graphs(d));
-    else RT_TRY(forward_eager(d));
+    if (!d->last_fused) {
+        RT_TRY(launch_letterbox(d->fptrs, stride_bytes, lg, d->tabs, img, d->B, d->stream));
+        if (chained) RT_HIP(hipEventRecord(sl.evp, d->stream));
+    }
+    sl.chained = chained; sl.joined = false;
+    if (chained) {
+        sl.joined = !d->last_fused || !d->chain_free_run;
+        RT_TRY(forward_chains(d, sl, mem_kind == RTMODT_MEM_HOST, sl.joined));
+    } else {
+        RT_TRY(run_stems(d, d->last_fused));
+        RT_HIP(hipEventRecord(sl.evp, d->stream));          // the frames have been consumed (letterbox [+ stem])
+        if (graphs) RT_TRY(forward_graphs(d));
+        else RT_TRY(forward_eager(d));
+    }
     RT_HIP(hipEventRecord(sl.ev1, d->stream));
     RT_HIP(hipEventRecord(sl.decoded, d->stream));
     // post-processing on its own stream: one small workgroup per image, latency-bound -- it runs
     // underneath the next batch's forward pass instead of in front of it
     RT_HIP(hipStreamWaitEvent(d->post_stream, sl.decoded, 0));
+    if (chained && !sl.joined) for (int c = 1; c < d->n_chains; ++c) RT_HIP(hipStreamWaitEvent(d->post_stream, sl.chain_done[c], 0));
     RT_TRY(run_nms(d, g, h, w, sl));
     RT_HIP(hipEventRecord(sl.ev2, d->post_stream));
     // results travel to pinned host memory right behind the kernels; fetch() only waits for `done`
@@ -1322,6 +1376,12 @@ int rtmodt_detector_info(rtmodt_detector *d, int32_t *scale_id, int32_t *nc, int
 }
 
 // dense copy of a channel-slice view of image `img`
+int rtmodt_detector_chains(rtmodt_detector *d, int32_t *n_chains) {
+    RT_CHECK(d && n_chains, RTMODT_E_INVALID, "null argument");
+    *n_chains = d->n_chains;
+    return RTMODT_OK;
+}
+
 static int fetch_view(rtmodt_detector *d, const TensorView &v, int img, uint16_t *out) {
     size_t per = (size_t)(v.H + 2 * v.pad) * (v.W + 2 * v.pad) * v.C;
     std::vector<uint16_t> tmp(per);
@@ -1407,7 +1467,7 @@ int rtmodt_detector_debug_layer(rtmodt_detector *d, const char *name, int img, u
     if (hwc) { hwc[0] = v.H; hwc[1] = v.W; hwc[2] = v.c; }
     if (!out) return RTMODT_OK;
     RT_HIP(hipSetDevice(d->device));
-    RT_HIP(hipStreamSynchronize(d->stream));
+    RT_HIP(hipDeviceSynchronize());                        // every chain stream
     return fetch_view(d, v, img, out);
 }
 
@@ -1415,20 +1475,24 @@ int rtmodt_detector_profile(rtmodt_detector *d, int iters, int max_entries, cons
                             int32_t *n_entries) {
     RT_CHECK(d && iters >= 1 && n_entries, RTMODT_E_INVALID, "bad argument");
     RT_HIP(hipSetDevice(d->device));
-    const int n = (int)d->ops.size() + 1;
+    // with sub-batch chains the launches that run are those of one chain (its sub-batch), timed here alone on the device
+    const std::vector<Op> &ops = d->n_chains > 1 ? d->chain_ops[0] : d->ops;
+    const int PB = d->B / d->n_chains;
+    const int n = (int)ops.size() + 1;
     std::vector<hipEvent_t> ev((size_t)n + 1);
     for (auto &e : ev) RT_HIP(hipEventCreate(&e));
     std::vector<double> acc(n, 0.0);
+    RT_HIP(hipDeviceSynchronize());
     for (int it = 0; it < iters; ++it) {
         RT_HIP(hipEventRecord(ev[0], d->stream));
         for (int i = 0; i < n - 1; ++i) {
-            if (d->ops[i].kind == OP_STEM && d->last_fused)
-                RT_TRY(launch_stem_fused(d->fptrs, 0, d->last_pitch, d->last_lg, d->in_h, d->in_w, d->lut255, d->ops[i].v[1], d->ops[i].stem_w,
-                                         d->ops[i].stem_b, d->B, d->ops[i].v[1].c, d->stream));
-            else RT_TRY(run_op(d, d->ops[i]));
+            if (ops[i].kind == OP_STEM && d->last_fused)
+                RT_TRY(launch_stem_fused(d->fptrs, 0, d->last_pitch, d->last_lg, d->in_h, d->in_w, d->lut255, ops[i].v[1], ops[i].stem_w,
+                                         ops[i].stem_b, PB, ops[i].v[1].c, d->stream));
+            else RT_TRY(run_op(d, ops[i]));
             RT_HIP(hipEventRecord(ev[i + 1], d->stream));
         }
-        RT_TRY(run_decode(d));
+        RT_TRY(run_decode_sub(d, 0, PB, d->stream));
         RT_HIP(hipEventRecord(ev[n], d->stream));
         RT_HIP(hipStreamSynchronize(d->stream));
         for (int i = 0; i < n; ++i) {
@@ -1439,12 +1503,12 @@ int rtmodt_detector_profile(rtmodt_detector *d, int iters, int max_entries, cons
     }
     for (auto &e : ev) hipEventDestroy(e);
     d->prof_names.clear();
-    for (auto &op : d->ops) {
+    for (auto &op : ops) {
         char buf[160];
         if (op.kind == OP_CONV && op.skip) {
             snprintf(buf, sizeof(buf), "%s [runs as the tail of the previous launch]", op.name.c_str());
         } else if (op.kind == OP_CONV) {
-            snprintf(buf, sizeof(buf), "%s [M=%d N=%d K=%d k%d s%d tile %s]", op.name.c_str(), d->B * op.conv.out.H * op.conv.out.W,
+            snprintf(buf, sizeof(buf), "%s [M=%d N=%d K=%d k%d s%d tile %s]", op.name.c_str(), PB * op.conv.out.H * op.conv.out.W,
                      op.conv.cout, op.conv.ks * op.conv.ks * op.conv.cin, op.conv.ks, op.conv.stride, tile_name(op.tail_on ? op.tail_tile : op.conv.tile));
         } else if (op.kind == OP_BNECK) {
             if (op.fused) snprintf(buf, sizeof(buf), "%s [fused bottleneck%s, c=%d, %dx%d]", op.name.c_str(), op.tail_on ? " + C2f.cv2 tail" : "", op.bneck.c, op.bneck.in.H, op.bneck.in.W);
@@ -1465,7 +1529,7 @@ int rtmodt_detector_profile(rtmodt_detector *d, int iters, int max_entries, cons
     for (int i = 0; i < n && i < max_entries; ++i) {
         if (names) names[i] = d->prof_names[i].c_str();
         if (ms) ms[i] = (float)(acc[i] / iters);
-        if (flops) flops[i] = i < n - 1 ? d->ops[i].flops * d->B : 0;
+        if (flops) flops[i] = i < n - 1 ? ops[i].flops * PB : 0;
     }
     return RTMODT_OK;
 }
@@ -1476,7 +1540,15 @@ int rtmodt_detector_last_timing(rtmodt_detector *d, float *total_ms, float *forw
     const rtmodt_detector::Slot &sl = d->slots[d->last_fetched];          // the batch fetch() returned last
     RT_HIP(hipEventSynchronize(sl.ev2));
     if (total_ms) RT_HIP(hipEventElapsedTime(total_ms, sl.ev0, sl.ev2));
-    if (forward_ms) RT_HIP(hipEventElapsedTime(forward_ms, sl.ev0, sl.ev1));
+    if (forward_ms) {
+        RT_HIP(hipEventElapsedTime(forward_ms, sl.ev0, sl.ev1));
+        if (sl.chained && !sl.joined)                         // free-running chains: the batch is decoded when the last of them is
+            for (int c = 1; c < d->n_chains; ++c) {
+                float t = 0;
+                RT_HIP(hipEventElapsedTime(&t, sl.ev0, sl.chain_done[c]));
+                *forward_ms = std::max(*forward_ms, t);
+            }
+    }
     if (getenv("RTMODT_DEBUG_GAPS")) {                    // idle time of the main stream between two batches
         static hipEvent_t base = nullptr;
         static float prev_end = -1.f;

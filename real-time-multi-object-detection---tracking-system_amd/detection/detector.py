@@ -158,6 +158,9 @@ class Detector:
             _ffi.check(L.rtmodt_detector_info(h, C.byref(sid), C.byref(nc), C.byref(na), C.byref(ncv), C.byref(fl), C.byref(ar)))
             m = _NativeModel(h, chosen, sid.value, nc.value, na.value, ncv.value, fl.value, ar.value)
             m.input_hw = (in_h, in_w)
+            nch = C.c_int32()
+            _ffi.check(L.rtmodt_detector_chains(h, C.byref(nch)))
+            m.chains = nch.value             # sub-batch chains the batch runs as (own streams, joined by the post-processing stream)
             self._models[(in_h, in_w)] = m
         return m
 

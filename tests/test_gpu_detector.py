@@ -688,3 +688,51 @@ def test_bottleneck_with_c2f_cv2_tail(pkg, wdir, monkeypatch, size, batch):
     for img in range(batch):
         for n in outs["1"][img]:
             assert np.array_equal(outs["0"][img][n], outs["1"][img][n]), (img, n)
+
+
+@pytest.mark.parametrize("src_hw,host", [((320, 320), False), ((320, 320), True), ((240, 416), True)])
+def test_free_running_chains_match_one_chain(pkg, wdir, monkeypatch, src_hw, host):
+    """A 16-frame launch set runs as two sub-batch chains on their own streams (stem -> graph -> Detect's tail per chain,
+    joined only by the post-processing stream).  With every conv forced onto one tile the detections of pipelined
+    batches (two in flight) must equal those of the single-chain engine and of the per-batch-joined variant, for
+    device frames, host frames through the copy stream, and frames that take the unfused letterbox (resize)."""
+    monkeypatch.setenv("RTMODT_TILE", "2")
+    monkeypatch.setenv("RTMODT_BNECK", "0")
+    B, steps = 16, 5
+    h, w = src_hw
+    frames = pkg.synth.frames(B * steps, h, w, seed=77).reshape(steps, B, h, w, 3)
+    buf = None
+    if not host:
+        buf = pkg._ffi.DeviceBuffer(frames.nbytes)
+        buf.upload(frames)
+    per = h * w * 3
+
+    def run(chains, join):
+        monkeypatch.setenv("RTMODT_CHAINS", str(chains))
+        monkeypatch.setenv("RTMODT_CHAIN_JOIN", "1" if join else "0")
+        det, _ = make_detector(pkg, wdir, "s", 320, batch=B, autotune=False, confidence=0.02)
+        outs = []
+        for t in range(steps):                                       # two batches in flight, as the pipeline runs them
+            if host:
+                det.enqueue(list(frames[t]))
+            else:
+                det.enqueue([buf.ptr + (t * B + i) * per for i in range(B)], height=h, width=w)
+            if t:
+                outs.append(det.fetch())
+        outs.append(det.fetch())
+        names = [n for n, _, _ in det.profile(1)]
+        det.close()
+        return outs, names
+
+    ref, _ = run(1, False)
+    assert sum(len(d) for batch in ref for d in batch) > 0
+    for chains, join in ((2, False), (2, True), (4, False)):
+        got, names = run(chains, join)
+        assert any(f"M={B // chains * 80 * 80} " in n for n in names), names[:3]      # the profile lists one chain's launches
+        for t in range(steps):
+            for i in range(B):
+                a, b = got[t][i], ref[t][i]
+                assert np.array_equal(a.xyxy.view(np.int32), b.xyxy.view(np.int32)) and np.array_equal(a.class_id, b.class_id) and \
+                    np.array_equal(a.confidence.view(np.int32), b.confidence.view(np.int32)), (chains, join, t, i)
+    if buf is not None:
+        buf.free()
