@@ -189,6 +189,7 @@ struct rtmodt_detector {
     bool chain_free_run = true;                       // chains never wait for each other (RTMODT_CHAIN_JOIN=1: join on the main stream per batch)
     std::vector<std::vector<Op>> chain_ops;
     std::vector<hipStream_t> aux_streams;             // fork targets during capture
+    std::vector<hipStream_t> pad_streams;             // RTMODT_PAD_STREAMS test hook
     std::vector<hipEvent_t> aux_events;
     std::map<std::string, TensorView> layer_out;     // fused conv name -> output view
     std::vector<void *> dev_allocs;                   // weights etc.
@@ -735,6 +736,7 @@ static int forward_eager_all(rtmodt_detector *d) {
 // best of a few launches) and keeps the fastest: the GEMM shapes of this net are small and
 // skinny, so the best tile depends on how M x N fills 256 CUs, not on a rule.
 // best-of-3 time (ms per launch) of `launch` issued 4 times back to back on the detector's stream
+// best-of-3 time (ms per launch) of `launch` issued 4 times back to back on the detector's stream
 template <typename F>
 static int time_launch(rtmodt_detector *d, hipEvent_t e0, hipEvent_t e1, F &&launch, float &ms_out) {
     for (int w = 0; w < 2; ++w) RT_TRY(launch());
@@ -974,22 +976,94 @@ static int capture_chain(rtmodt_detector *d, int c) {
     return RTMODT_OK;
 }
 
-static int capture_graph(rtmodt_detector *d) {
-    const int C = d->n_chains;
-    for (auto g : d->graph_execs) if (g) hipGraphExecDestroy(g);
-    for (auto g : d->graphs) if (g) hipGraphDestroy(g);
-    d->graphs.assign(C, nullptr); d->graph_execs.assign(2 * C, nullptr);
-    while ((int)d->chain_streams.size() < C) {
+// One stream per chain (chain 0 runs on the main stream).  The runtime maps streams onto a few hardware queues in creation
+// order (4 per process here: with one, two or five streams created in front of it, chain 1's stream shared the main or the
+// post-processing stream's queue and the bench lost 20-30 %), and kernels of streams that share a queue run back to back.
+// What else the process has created (torch, RCCL, other detectors) is not ours to know, so every candidate stream is
+// PROBED: two 40 us spin kernels, one on the candidate and one on each stream it must overlap with, have to finish in
+// the time of one.  Candidates that fail are destroyed at the end; if none passes, the detector falls back to one chain.
+__global__ void spin_kernel(long long ticks) {
+    const long long t0 = wall_clock64();                  // 100 MHz constant clock: the loop ends after `ticks` whatever else happens
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(16);
+}
+static int streams_overlap(hipStream_t a, hipStream_t b, hipEvent_t e0, hipEvent_t e1, hipEvent_t ej, bool &overlap, float &ms_out) {
+    const long long ticks = 4000;                         // 40 us
+    float best = 1e30f;
+    for (int rep = 0; rep < 3; ++rep) {
+        RT_HIP(hipEventRecord(e0, a));
+        RT_HIP(hipStreamWaitEvent(b, e0, 0));
+        hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, a, ticks);
+        hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, b, ticks);
+        RT_HIP(hipEventRecord(ej, b));
+        RT_HIP(hipStreamWaitEvent(a, ej, 0));
+        RT_HIP(hipEventRecord(e1, a));
+        RT_HIP(hipEventSynchronize(e1));
+        float ms = 0;
+        RT_HIP(hipEventElapsedTime(&ms, e0, e1));
+        best = std::min(best, ms);
+    }
+    ms_out = best;
+    overlap = best < 0.082f;                              // measured: 62-68 us when the two spins overlap, 102 us when they queue up
+    return RTMODT_OK;
+}
+static int ensure_chain_streams(rtmodt_detector *d) {
+    if ((int)d->chain_streams.size() >= d->n_chains) return RTMODT_OK;
+    hipEvent_t e0, e1, ej;
+    RT_HIP(hipEventCreate(&e0)); RT_HIP(hipEventCreate(&e1)); RT_HIP(hipEventCreateWithFlags(&ej, hipEventDisableTiming));
+    if (const char *e = getenv("RTMODT_PAD_STREAMS"))      // test hook: streams created ahead of ours shift the queue mapping
+        for (int i = 0; i < atoi(e); ++i) { hipStream_t st; RT_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking)); d->pad_streams.push_back(st); }
+    std::vector<hipStream_t> rejected;
+    int rc = RTMODT_OK;
+    while (rc == RTMODT_OK && (int)d->chain_streams.size() < d->n_chains) {
         hipStream_t st = d->stream;
-        if (!d->chain_streams.empty()) RT_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        if (!d->chain_streams.empty()) {
+            st = nullptr;
+            for (int attempt = 0; attempt < 12 && !st && rc == RTMODT_OK; ++attempt) {
+                hipStream_t cand;
+                RT_HIP(hipStreamCreateWithFlags(&cand, hipStreamNonBlocking));
+                bool ok = true;
+                std::vector<hipStream_t> others = d->chain_streams;
+                others.push_back(d->post_stream);
+                others.push_back(d->copy_stream);            // its event waits would hold up a chain that shared its queue
+                for (hipStream_t o : others) {
+                    bool ov = false; float ms = 0;
+                    rc = streams_overlap(o, cand, e0, e1, ej, ov, ms);
+                    if (getenv("RTMODT_TUNE_LOG")) fprintf(stderr, "[streams] candidate %d for chain %zu against stream %p: %.1f us -> %s\n", attempt, d->chain_streams.size(), (void *)o, ms * 1e3f, ov ? "own queue" : "shared queue");
+                    ok = ok && ov && rc == RTMODT_OK;
+                    if (!ok) break;
+                }
+                if (ok) st = cand; else rejected.push_back(cand);
+            }
+            if (!st) break;                               // no stream of this process runs beside ours
+        }
         d->chain_streams.push_back(st);
         hipEvent_t a, b;
         RT_HIP(hipEventCreateWithFlags(&a, hipEventDisableTiming)); RT_HIP(hipEventCreateWithFlags(&b, hipEventDisableTiming));
         d->chain_fork.push_back(a); d->chain_join.push_back(b);
     }
+    for (hipStream_t st : rejected) hipStreamDestroy(st);
+    hipEventDestroy(e0); hipEventDestroy(e1); hipEventDestroy(ej);
+    RT_TRY(rc);
+    if ((int)d->chain_streams.size() < d->n_chains) {      // fall back to the single-chain engine
+        for (size_t c = 1; c < d->chain_streams.size(); ++c) hipStreamDestroy(d->chain_streams[c]);
+        d->chain_streams.resize(1);
+        d->n_chains = 1;
+        d->chain_ops.assign(1, d->ops);
+    }
+    return RTMODT_OK;
+}
+
+static int capture_graph(rtmodt_detector *d) {
+    const int C = d->n_chains;
+    for (auto g : d->graph_execs) if (g) hipGraphExecDestroy(g);
+    for (auto g : d->graphs) if (g) hipGraphDestroy(g);
+    d->graphs.assign(C, nullptr); d->graph_execs.assign(2 * C, nullptr);
+    RT_TRY(ensure_chain_streams(d));
+    bool forks = false;
+    for (auto &op : d->ops) forks = forks || op.head_level >= 0;
     while ((int)d->aux_streams.size() < 2 * C) {
-        hipStream_t st;
-        RT_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        hipStream_t st = nullptr;
+        if (forks) RT_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
         d->aux_streams.push_back(st);
     }
     while ((int)d->aux_events.size() < 4 * C) {
@@ -1119,7 +1193,8 @@ void rtmodt_detector_destroy(rtmodt_detector *d) {
     for (auto e : d->chain_join) hipEventDestroy(e);
     if (d->post_stream) hipStreamDestroy(d->post_stream);
     if (d->copy_stream) hipStreamDestroy(d->copy_stream);
-    for (auto st : d->aux_streams) hipStreamDestroy(st);
+    for (auto st : d->aux_streams) if (st) hipStreamDestroy(st);
+    for (auto st : d->pad_streams) hipStreamDestroy(st);
     for (auto e : d->aux_events) hipEventDestroy(e);
     for (void *p : d->dev_allocs) hipFree(p);
     hipFree(d->arena); hipFree(d->stage); hipFree(d->d_tab); hipFree(d->d_zeros); hipFree(d->lut255);
@@ -1160,15 +1235,16 @@ static int detector_create_impl(const rtmodt_det_cfg *cfg, rtmodt_detector *d) {
     RT_HIP(hipSetDevice(d->device));
     RT_HIP(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking));
     RT_HIP(hipStreamCreateWithFlags(&d->post_stream, hipStreamNonBlocking));
+    RT_HIP(hipStreamCreateWithFlags(&d->copy_stream, hipStreamNonBlocking));
     RT_HIP(hipMalloc((void **)&d->d_zeros, 256));
     RT_HIP(hipMemset(d->d_zeros, 0, 256));
     RT_TRY(build_graph(d, wf));
+    RT_TRY(ensure_chain_streams(d));                       // may fall back to one chain: before anything is sized by n_chains
 
     int msw = cfg->max_src_w > 0 ? cfg->max_src_w : d->in_w, msh = cfg->max_src_h > 0 ? cfg->max_src_h : d->in_h;
     d->cfg.max_src_w = msw; d->cfg.max_src_h = msh;
     d->stage_per = align_up((size_t)msw * msh * 3 + 64, 256);
     RT_HIP(hipMalloc((void **)&d->stage, d->stage_per * d->B * rtmodt_detector::RING_SLOTS));
-    RT_HIP(hipStreamCreateWithFlags(&d->copy_stream, hipStreamNonBlocking));
     d->tab_cap = (size_t)(d->in_w + d->in_h) * 3;
     RT_HIP(hipMalloc((void **)&d->d_tab, d->tab_cap * sizeof(int32_t)));
 

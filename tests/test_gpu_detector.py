@@ -698,6 +698,8 @@ def test_free_running_chains_match_one_chain(pkg, wdir, monkeypatch, src_hw, hos
     device frames, host frames through the copy stream, and frames that take the unfused letterbox (resize)."""
     monkeypatch.setenv("RTMODT_TILE", "2")
     monkeypatch.setenv("RTMODT_BNECK", "0")
+    if host:
+        monkeypatch.setenv("RTMODT_PAD_STREAMS", "1")     # chain 1's first candidate stream then shares the main stream's hardware queue: the probe must move on
     B, steps = 16, 5
     h, w = src_hw
     frames = pkg.synth.frames(B * steps, h, w, seed=77).reshape(steps, B, h, w, 3)

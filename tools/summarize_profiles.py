@@ -32,6 +32,11 @@ if st:
     shutil.copy(st, os.path.join(dst, "kernel_stats.csv"))
 
 
+CHAINS = 1                                               # sub-batch chains per step: that many stem launches per step
+if os.path.exists(os.path.join(src, "stats_bench.json")):
+    CHAINS = json.loads(open(os.path.join(src, "stats_bench.json")).read().strip().splitlines()[-1])["roofline"].get("chains", 1)
+
+
 def per_step(dirname, counters, steps=10):
     f = one(f"{dirname}/*/*_counter_collection.csv")
     if not f:
@@ -43,8 +48,8 @@ def per_step(dirname, counters, steps=10):
         d[r["Counter_Name"]] = float(r["Counter_Value"])
         d["dur"] = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
     ids = sorted(per, key=int)
-    lb = [i for i in ids if "letterbox" in per[i]["name"] or "stem_fused" in per[i]["name"]]      # first launch of a step
-    a, b = int(lb[-steps - 1]), int(lb[-1])
+    lb = [i for i in ids if "letterbox" in per[i]["name"] or "stem_fused" in per[i]["name"]]      # first launch of a chain's step
+    a, b = int(lb[-steps * CHAINS - 1]), int(lb[-1])
     sel = [per[i] for i in ids if a <= int(i) < b]
     agg = collections.defaultdict(lambda: collections.defaultdict(float))
     for d in sel:
