@@ -1279,36 +1279,43 @@ __global__ __launch_bounds__(256) void stem_fused(StemSrc src, const f16 *__rest
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int p = lane & 15, q = lane >> 4;
     const int b = blockIdx.x / Ho, oy = blockIdx.x - b * Ho;
-    lut[threadIdx.x] = lut_g[threadIdx.x];
+    (void)lut_g;                                           // (the c/255 table of the first version; kept in the signature)
     // ---- assemble the three rows ----
     const uint8_t *f = src.frames.p[src.frame0 + b];
     const int ndw = rowb >> 2;
-    for (int i = threadIdx.x; i < 3 * ndw; i += 256) {
-        const int r = i / ndw, dwi = i - r * ndw;
-        const int y = 2 * oy - 1 + r, sy = y - src.top;
-        unsigned v = 0x72727272u;                          // 114 everywhere the canvas has no image
-        if (y >= 0 && y < src.in_h && sy >= 0 && sy < src.new_h) {
+    const uintptr_t fend = ((uintptr_t)f + src.frame_bytes + 3) & ~(uintptr_t)3;   // dwords that hold frame bytes
+    const uintptr_t fbeg = (uintptr_t)f & ~(uintptr_t)3;
+    // every load of a pass is issued before the first one is used: one trip to memory per pass instead of one per dword
+    constexpr int PF = 6;                                  // 3 rows x 480 dwords at 640 wide = 5.6 per thread
+    for (int base = 0; base < 3 * ndw; base += 256 * PF) {
+        unsigned lo[PF], hi[PF], keep[PF];
+        int shv[PF];
+#pragma unroll
+        for (int k = 0; k < PF; ++k) {
+            const int i = base + k * 256 + threadIdx.x;
+            const int r = (i >= ndw) + (i >= 2 * ndw), dwi = i - r * ndw;
+            const int y = 2 * oy - 1 + r, sy = y - src.top;
             // canvas bytes [4 dwi, 4 dwi + 4) <- source row bytes [4 dwi - 3 left, ...) where inside [0, 3 new_w)
             const int s0 = 4 * dwi - 3 * src.left;
-            if (s0 > -4 && s0 < 3 * src.new_w) {
-                const long rowoff = (long)sy * src.pitch;
-                const uintptr_t a = (uintptr_t)(f + rowoff + s0);
-                const uintptr_t al = a & ~(uintptr_t)3;
-                const int sh = (int)(a & 3) * 8;
-                const uintptr_t fend = ((uintptr_t)f + src.frame_bytes + 3) & ~(uintptr_t)3;   // dwords that hold frame bytes
-                const uintptr_t fbeg = (uintptr_t)f & ~(uintptr_t)3;
-                unsigned lo = al >= fbeg && al < fend ? *(const unsigned *)al : 0u;
-                unsigned hi = (sh != 0 && al + 4 < fend && al + 4 >= fbeg) ? *(const unsigned *)(al + 4) : 0u;
-                unsigned w = sh ? (lo >> sh) | (hi << (32 - sh)) : lo;
-                // bytes of this dword that fall outside the source row keep 114
-                unsigned m = 0u;
+            const bool live = i < 3 * ndw && y >= 0 && y < src.in_h && sy >= 0 && sy < src.new_h && s0 > -4 && s0 < 3 * src.new_w;
+            const uintptr_t a = (uintptr_t)(f + (long)sy * src.pitch + s0);
+            const uintptr_t al = a & ~(uintptr_t)3;
+            shv[k] = (int)(a & 3) * 8;
+            lo[k] = live && al >= fbeg && al < fend ? *(const unsigned *)al : 0u;
+            hi[k] = (live && shv[k] != 0 && al + 4 < fend && al + 4 >= fbeg) ? *(const unsigned *)(al + 4) : 0u;
+            unsigned m = 0u;                               // bytes of this dword that fall inside the source row
 #pragma unroll
-                for (int k = 0; k < 4; ++k)
-                    if (s0 + k >= 0 && s0 + k < 3 * src.new_w) m |= 0xFFu << (8 * k);
-                v = (w & m) | (v & ~m);
-            }
+            for (int j = 0; j < 4; ++j)
+                if (live && s0 + j >= 0 && s0 + j < 3 * src.new_w) m |= 0xFFu << (8 * j);
+            keep[k] = m;
         }
-        *(unsigned *)(rows + r * rowb + 4 * dwi) = v;
+#pragma unroll
+        for (int k = 0; k < PF; ++k) {
+            const int i = base + k * 256 + threadIdx.x;
+            if (i >= 3 * ndw) continue;
+            const unsigned w = shv[k] ? (lo[k] >> shv[k]) | (hi[k] << (32 - shv[k])) : lo[k];
+            ((unsigned *)rows)[i] = (w & keep[k]) | (0x72727272u & ~keep[k]);      // 114 everywhere the canvas has no image
+        }
     }
     half8 wf[NT][2];
 #pragma unroll
@@ -1320,17 +1327,24 @@ __global__ __launch_bounds__(256) void stem_fused(StemSrc src, const f16 *__rest
     for (int u = 0; u < NT; ++u) bv[u] = *(const floatx4 *)(bias + u * 16 + q * 4);
     __syncthreads();
     // ---- bytes -> (R, G, B, 0) fp16 pixels; canvas column x sits at index x + 1, zeros outside the canvas ----
+    // Four pixels = three aligned dwords per work item; byte -> float -> * (1/255) -> half equals the letterbox kernel's
+    // (half)(c / 255.f) for all 256 byte values (checked exhaustively: tests/test_oracle_yolo.py), so no table is needed.
     const int pw = src.in_w + 2;
-    for (int i = threadIdx.x; i < 3 * pw; i += 256) {
-        const int r = i / pw, x = i - r * pw - 1;
+    const int qpr = src.in_w >> 2;                         // groups of four pixels per row
+    for (int i = threadIdx.x; i < 3 * qpr; i += 256) {
+        const int r = i / qpr, g = i - r * qpr;
         const int y = 2 * oy - 1 + r;
-        half4 h = {(f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f};
-        if (x >= 0 && x < src.in_w && y >= 0 && y < src.in_h) {
-            const unsigned char *rp = rows + r * rowb + 3 * x;
-            h[0] = lut[rp[2]]; h[1] = lut[rp[1]]; h[2] = lut[rp[0]];
-        }
-        pix[i] = h;
+        const unsigned *rp = (const unsigned *)(rows + r * rowb) + 3 * g;
+        const unsigned d0 = rp[0], d1 = rp[1], d2 = rp[2];
+        const float k = y >= 0 && y < src.in_h ? 1.0f / 255.0f : 0.0f;
+        auto cv = [&](unsigned byte) -> f16 { return (f16)((float)byte * k); };
+        half4 *dst = pix + r * pw + 1 + 4 * g;
+        dst[0] = half4{cv((d0 >> 16) & 255u), cv((d0 >> 8) & 255u), cv(d0 & 255u), (f16)0.f};
+        dst[1] = half4{cv((d1 >> 8) & 255u), cv(d1 & 255u), cv(d0 >> 24), (f16)0.f};
+        dst[2] = half4{cv(d2 & 255u), cv(d1 >> 24), cv((d1 >> 16) & 255u), (f16)0.f};
+        dst[3] = half4{cv(d2 >> 24), cv((d2 >> 16) & 255u), cv((d2 >> 8) & 255u), (f16)0.f};
     }
+    if (threadIdx.x < 6) pix[(threadIdx.x >> 1) * pw + (threadIdx.x & 1) * (src.in_w + 1)] = half4{(f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f};
     __syncthreads();
 
     auto pair = [&](int r, int x0) -> half8 {              // pixels (x0, x0 + 1) of canvas row 2oy - 1 + r as {R,G,B,0,R,G,B,0}
@@ -1398,7 +1412,7 @@ __device__ __forceinline__ half8 hmax8(half8 a, half8 b) {
     return o;
 }
 
-__global__ __launch_bounds__(256) void sppf_pool(const f16 *__restrict__ y, int Hp, int Wp, int cs, int pad, int H, int W,
+__global__ __launch_bounds__(512) void sppf_pool(const f16 *__restrict__ y, int Hp, int Wp, int cs, int pad, int H, int W,
                                                  f16 *__restrict__ o1, f16 *__restrict__ o2, f16 *__restrict__ o3, int ocs,
                                                  int chunks) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1406,13 +1420,21 @@ __global__ __launch_bounds__(256) void sppf_pool(const f16 *__restrict__ y, int 
     half8 *r5 = tile + H * W;                  // row maxima radius 2
     half8 *r9 = r5 + H * W;                    // radius 4
     half8 *r13 = r9 + H * W;                   // radius 6
-    int b = blockIdx.x / chunks, ch = (blockIdx.x % chunks) * 8;
-    for (int i = threadIdx.x; i < H * W; i += 256) {
+    // A workgroup owns 8 channels (16 B) of every pixel; the 8 workgroups that share a 128-byte line of the tensor are
+    // placed on ONE XCD (workgroups go round-robin over the 8 XCDs), so their partial-line reads and writes meet in one L2
+    // instead of eight.
+    int work = blockIdx.x;
+    if (chunks % 8 == 0 && (gridDim.x / 8) % 8 == 0) {
+        const int xcd = work & 7, t = work >> 3;
+        work = ((t >> 3) * 8 + xcd) * 8 + (t & 7);           // (line group, chunk within the line)
+    }
+    int b = work / chunks, ch = (work % chunks) * 8;
+    for (int i = threadIdx.x; i < H * W; i += 512) {
         int yy = i / W, xx = i - yy * W;
         tile[i] = *(const half8 *)(y + ((long)(b * Hp + yy + pad) * Wp + xx + pad) * cs + ch);
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < H * W; i += 256) {
+    for (int i = threadIdx.x; i < H * W; i += 512) {
         int yy = i / W, xx = i - yy * W;
         half8 m = tile[i];
         for (int d = 1; d <= 2; ++d) {
@@ -1432,7 +1454,7 @@ __global__ __launch_bounds__(256) void sppf_pool(const f16 *__restrict__ y, int 
         r13[i] = m;
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < H * W; i += 256) {
+    for (int i = threadIdx.x; i < H * W; i += 512) {
         int yy = i / W, xx = i - yy * W;
         half8 a = r5[i], bq = r9[i], c = r13[i];
         for (int d = 1; d <= 6; ++d) {
@@ -1466,7 +1488,8 @@ int launch_sppf_pool(const TensorView &y, const TensorView &p1, const TensorView
         RT_HIP(hipFuncSetAttribute((const void *)sppf_pool, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         attr_bytes = smem;
     }
-    hipLaunchKernelGGL(sppf_pool, dim3(B * chunks), dim3(256), smem, s, y.base + y.coff, y.H + 2 * y.pad, y.W + 2 * y.pad, y.C,
+    hipLaunchKernelGGL(sppf_pool, dim3(B * chunks), dim3(512), smem, s,      // 20x20 pixels at P5: one pass of 512 threads per phase
+                       y.base + y.coff, y.H + 2 * y.pad, y.W + 2 * y.pad, y.C,
                        y.pad, y.H, y.W, p1.base + p1.coff, p2.base + p2.coff, p3.base + p3.coff, y.C, chunks);
     RT_HIP(hipGetLastError());
     return RTMODT_OK;

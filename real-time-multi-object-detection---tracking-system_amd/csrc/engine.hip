@@ -300,6 +300,14 @@ static Op sub_batch(const Op &op, int b0, int nb) {
     return o;
 }
 
+static void set_chains(rtmodt_detector *d, int chains) {
+    d->n_chains = chains;
+    d->chain_ops.assign(chains, {});
+    const int nb = d->B / chains;
+    for (int c = 0; c < chains; ++c)
+        for (auto &op : d->ops) d->chain_ops[c].push_back(sub_batch(op, c * nb, nb));
+}
+
 static int pick_tile(int M, int cout) {
     if (const char *e = getenv("RTMODT_TILE")) {
         int t = atoi(e);
@@ -643,11 +651,7 @@ static int build_graph(rtmodt_detector *d, WeightFile &wf) {
     if (const char *e = getenv("RTMODT_CHAIN_JOIN")) d->chain_free_run = atoi(e) == 0;
     chains = std::max(1, std::min(chains, d->B));
     while (d->B % chains) --chains;
-    d->n_chains = chains;
-    d->chain_ops.assign(chains, {});
-    const int nb = d->B / chains;
-    for (int c = 0; c < chains; ++c)
-        for (auto &op : d->ops) d->chain_ops[c].push_back(sub_batch(op, c * nb, nb));
+    set_chains(d, chains);
     return RTMODT_OK;
 }
 
@@ -1022,6 +1026,8 @@ static int ensure_chain_streams(rtmodt_detector *d) {
                 hipStream_t cand;
                 RT_HIP(hipStreamCreateWithFlags(&cand, hipStreamNonBlocking));
                 bool ok = true;
+                const char *pe = getenv("RTMODT_CHAIN_PROBE");      // 0: trust the creation order (counter-collecting profilers serialise every kernel, the probe would see no overlap)
+                if (pe && atoi(pe) == 0) { st = cand; break; }
                 std::vector<hipStream_t> others = d->chain_streams;
                 others.push_back(d->post_stream);
                 others.push_back(d->copy_stream);            // its event waits would hold up a chain that shared its queue
@@ -1044,11 +1050,12 @@ static int ensure_chain_streams(rtmodt_detector *d) {
     for (hipStream_t st : rejected) hipStreamDestroy(st);
     hipEventDestroy(e0); hipEventDestroy(e1); hipEventDestroy(ej);
     RT_TRY(rc);
-    if ((int)d->chain_streams.size() < d->n_chains) {      // fall back to the single-chain engine
-        for (size_t c = 1; c < d->chain_streams.size(); ++c) hipStreamDestroy(d->chain_streams[c]);
-        d->chain_streams.resize(1);
-        d->n_chains = 1;
-        d->chain_ops.assign(1, d->ops);
+    if ((int)d->chain_streams.size() < d->n_chains) {      // fewer queues than chains: as many chains as found streams (dividing the batch)
+        int c = (int)d->chain_streams.size();
+        while (d->B % c) --c;
+        for (size_t k = c; k < d->chain_streams.size(); ++k) hipStreamDestroy(d->chain_streams[k]);
+        d->chain_streams.resize(c);
+        set_chains(d, c);
     }
     return RTMODT_OK;
 }

@@ -723,14 +723,16 @@ def test_free_running_chains_match_one_chain(pkg, wdir, monkeypatch, src_hw, hos
                 outs.append(det.fetch())
         outs.append(det.fetch())
         names = [n for n, _, _ in det.profile(1)]
+        actual = det.model.chains                                    # fewer than asked for when the process has no more hardware queues to itself
         det.close()
-        return outs, names
+        return outs, names, actual
 
-    ref, _ = run(1, False)
-    assert sum(len(d) for batch in ref for d in batch) > 0
+    ref, _, one = run(1, False)
+    assert one == 1 and sum(len(d) for batch in ref for d in batch) > 0
     for chains, join in ((2, False), (2, True), (4, False)):
-        got, names = run(chains, join)
-        assert any(f"M={B // chains * 80 * 80} " in n for n in names), names[:3]      # the profile lists one chain's launches
+        got, names, actual = run(chains, join)
+        assert actual == chains or (chains == 4 and actual in (2, 4)), (chains, actual)
+        assert any(f"M={B // actual * 80 * 80} " in n for n in names), names[:3]      # the profile lists one chain's launches
         for t in range(steps):
             for i in range(B):
                 a, b = got[t][i], ref[t][i]

@@ -190,3 +190,16 @@ def test_bn_folding_matches_torch(pkg):
                                bn.running_mean.numpy(), bn.running_var.numpy())
     got = Y.conv2d_nhwc(x[0].permute(1, 2, 0).numpy(), w, b, 1, act=0)
     np.testing.assert_allclose(got, ref[0].permute(1, 2, 0).numpy(), rtol=1e-4, atol=1e-5)
+
+
+def test_byte_scale_by_multiplication_matches_division_in_fp16():
+    """The fused stem (conv.hip: stem_fused) turns a byte into fp16 as half(float(c) * (1/255)); the reference
+    preprocess divides (detector.py's letterboxed tensor / 255 -> .half()).  The two differ in fp32 for about half
+    of the byte values but round to the same fp16 for all 256 of them."""
+    c = np.arange(256, dtype=np.float32)
+    by_div = (c / np.float32(255.0)).astype(np.float16)
+    by_mul = (c * np.float32(1.0 / 255.0)).astype(np.float16)
+    assert np.array_equal(by_div.view(np.uint16), by_mul.view(np.uint16))
+    frame = np.arange(256, dtype=np.uint8).reshape(16, 16, 1).repeat(3, axis=2)
+    ref = Y.preprocess(frame, 16, 16).astype(np.float16)                # (3, 16, 16) or (16, 16, 3): every byte value once per channel
+    assert np.array_equal(np.sort(ref.reshape(-1).view(np.uint16)), np.sort(np.repeat(by_mul, 3).view(np.uint16)))

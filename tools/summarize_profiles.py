@@ -22,7 +22,7 @@ def one(pattern):
 
 
 for name in ("bench_default.json", "bench_host_frames.json", "bench_host_frames_pageable.json", "bench_streams16.json",
-             "bench_streams32.json", "bench_frames1.json", "bench_frames4.json", "stats_bench.json", "pipeline_640.json", "pipeline_1080p.json", "layers.txt", "step_gaps.txt",
+             "bench_streams32.json", "bench_frames1.json", "bench_frames4.json", "bench_chains1.json", "stats_bench.json", "stats_chains1_bench.json", "layers_chains1.txt", "step_gaps_chains1.txt", "pipeline_640.json", "pipeline_1080p.json", "layers.txt", "step_gaps.txt",
              "bandwidth_probe.txt", "tracker_modes.json"):
     p = os.path.join(src, name)
     if os.path.exists(p):
@@ -30,6 +30,9 @@ for name in ("bench_default.json", "bench_host_frames.json", "bench_host_frames_
 st = one("stats/*/*_kernel_stats.csv")
 if st:
     shutil.copy(st, os.path.join(dst, "kernel_stats.csv"))
+st1 = one("stats_chains1/*/*_kernel_stats.csv")
+if st1:
+    shutil.copy(st1, os.path.join(dst, "kernel_stats_chains1.csv"))
 
 
 CHAINS = 1                                               # sub-batch chains per step: that many stem launches per step
