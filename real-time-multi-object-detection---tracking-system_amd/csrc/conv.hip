@@ -1312,38 +1312,47 @@ __global__ __launch_bounds__(256) void stem_fused(StemSrc src, const f16 *__rest
     // ---- assemble the three rows ----
     const uint8_t *f = src.frames.p[src.frame0 + b];
     const int ndw = rowb >> 2;
-    const uintptr_t fend = ((uintptr_t)f + src.frame_bytes + 3) & ~(uintptr_t)3;   // dwords that hold frame bytes
-    const uintptr_t fbeg = (uintptr_t)f & ~(uintptr_t)3;
+    // the frame as aligned dwords: fw[0] holds the frame's first byte at byte offset fa (all address arithmetic stays on
+    // the global pointer -- going through uintptr_t turned these loads into flat loads inside branches)
+    const int fa = (int)((uintptr_t)f & 3);
+    const unsigned *fw = (const unsigned *)(f - fa);
+    const int fdw = (fa + src.frame_bytes + 3) >> 2;      // dwords that hold frame bytes
     // every load of a pass is issued before the first one is used: one trip to memory per pass instead of one per dword
     constexpr int PF = 6;                                  // 3 rows x 480 dwords at 640 wide = 5.6 per thread
     for (int base = 0; base < 3 * ndw; base += 256 * PF) {
-        unsigned lo[PF], hi[PF], keep[PF];
-        int shv[PF];
-#pragma unroll
-        for (int k = 0; k < PF; ++k) {
-            const int i = base + k * 256 + threadIdx.x;
+        unsigned v0[PF], v1[PF];
+        // canvas bytes [4 dwi, 4 dwi + 4) <- source row bytes [4 dwi - 3 left, ...) where inside [0, 3 new_w)
+        auto locate = [&](int k, int &i, int &s0, int &a) -> bool {
+            i = base + k * 256 + threadIdx.x;
             const int r = (i >= ndw) + (i >= 2 * ndw), dwi = i - r * ndw;
             const int y = 2 * oy - 1 + r, sy = y - src.top;
-            // canvas bytes [4 dwi, 4 dwi + 4) <- source row bytes [4 dwi - 3 left, ...) where inside [0, 3 new_w)
-            const int s0 = 4 * dwi - 3 * src.left;
+            s0 = 4 * dwi - 3 * src.left;
             const bool live = i < 3 * ndw && y >= 0 && y < src.in_h && sy >= 0 && sy < src.new_h && s0 > -4 && s0 < 3 * src.new_w;
-            const uintptr_t a = (uintptr_t)(f + (long)sy * src.pitch + s0);
-            const uintptr_t al = a & ~(uintptr_t)3;
-            shv[k] = (int)(a & 3) * 8;
-            lo[k] = live && al >= fbeg && al < fend ? *(const unsigned *)al : 0u;
-            hi[k] = (live && shv[k] != 0 && al + 4 < fend && al + 4 >= fbeg) ? *(const unsigned *)(al + 4) : 0u;
+            a = live ? sy * src.pitch + s0 + fa : 0;      // byte offset from fw (>= -3; the frame is < 2^31 bytes)
+            return live;
+        };
+#pragma unroll
+        for (int k = 0; k < PF; ++k) {                     // loads only (clamped addresses, always legal)
+            int i, s0, a;
+            locate(k, i, s0, a);
+            const int w0 = a >> 2;                         // arithmetic shift: floor
+            v0[k] = fw[min(max(w0, 0), fdw - 1)];
+            v1[k] = fw[min(max(w0 + 1, 0), fdw - 1)];
+        }
+#pragma unroll
+        for (int k = 0; k < PF; ++k) {
+            int i, s0, a;
+            const bool live = locate(k, i, s0, a);
+            if (i >= 3 * ndw) continue;
+            const int w0 = a >> 2, sh = (a & 3) * 8;
+            const unsigned lo = live && w0 >= 0 && w0 < fdw ? v0[k] : 0u;
+            const unsigned hi = live && sh != 0 && w0 + 1 >= 0 && w0 + 1 < fdw ? v1[k] : 0u;
+            const unsigned w = sh ? (lo >> sh) | (hi << (32 - sh)) : lo;
             unsigned m = 0u;                               // bytes of this dword that fall inside the source row
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 if (live && s0 + j >= 0 && s0 + j < 3 * src.new_w) m |= 0xFFu << (8 * j);
-            keep[k] = m;
-        }
-#pragma unroll
-        for (int k = 0; k < PF; ++k) {
-            const int i = base + k * 256 + threadIdx.x;
-            if (i >= 3 * ndw) continue;
-            const unsigned w = shv[k] ? (lo[k] >> shv[k]) | (hi[k] << (32 - shv[k])) : lo[k];
-            ((unsigned *)rows)[i] = (w & keep[k]) | (0x72727272u & ~keep[k]);      // 114 everywhere the canvas has no image
+            ((unsigned *)rows)[i] = (w & m) | (0x72727272u & ~m);      // 114 everywhere the canvas has no image
         }
     }
     half8 wf[NT][2];
