@@ -47,6 +47,7 @@ def parse():
     ap.add_argument("--max-det", type=int, default=100)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true")
+    ap.add_argument("--depth", type=int, default=0, help="batches in flight after a submit (0: 2, or 3 in the staged mode)")
     ap.add_argument("--no-compare", action="store_true", help="skip the extra one-frame-per-stream run (profiler passes: one workload per process)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend: nccl (= RCCL, default) or gloo (rehearsal on a 1-GPU box)")
@@ -153,8 +154,8 @@ def main():
                 trk.update_from_detector(det, f * S, S)
 
         def step(t):
-            """Steady state of a 2-deep pipeline: submit batch t, then collect batch t-1 (whose
-            copy to the host overlapped the GPU's work on batch t)."""
+            """Steady state of the pipeline: submit batch t, then collect the oldest batch in flight (whose
+            copy to the host overlapped the GPU's work on the newer ones)."""
             submit(t)
             return det.fetch()
 
@@ -163,8 +164,12 @@ def main():
         gc.collect()
         gc.freeze()
         gc.disable()
-        submit(0)                                       # prime the pipeline: one batch always in flight
-        for t in range(1, warmup + 1):
+        # prime the pipeline: one batch always in flight (two in the staged mode, whose front stage of batch t + 2 would
+        # otherwise wait for the host to see the results of batch t)
+        depth = args.depth if args.depth > 0 else (3 if getattr(det.model, "stages", 1) > 1 else 2)
+        for t in range(depth - 1):
+            submit(t)
+        for t in range(depth - 1, warmup + depth - 1):
             step(t)
         sync_all(det)
         if collective:
@@ -174,7 +179,7 @@ def main():
         n_det = 0
         t0 = time.perf_counter()
         for t in range(steps):
-            out = step(warmup + 1 + t)                # submits one batch, retires one batch: K batches per K steps
+            out = step(warmup + depth - 1 + t)        # submits one batch, retires one batch: K batches per K steps
             a, b = det.last_timing()                   # HIP events on the detector's stream, already complete
             tot_ms += a
             fwd_ms += b
@@ -185,7 +190,8 @@ def main():
             sync_all(det)
         elapsed = time.perf_counter() - t0
         gc.enable()
-        det.fetch()                                      # drain the batch still in flight (outside the timed region)
+        for _ in range(depth - 1):
+            det.fetch()                                  # drain the batches still in flight (outside the timed region)
         return {"elapsed": elapsed, "fwd_ms": fwd_ms, "tot_ms": tot_ms, "n_det": n_det, "det": det, "trk": trk}
 
     m = measure(F, args.steps, args.warmup)
@@ -207,7 +213,8 @@ def main():
     chains = getattr(det.model, "chains", 1)
     # free-running sub-batch chains of consecutive batches overlap: the event span of one batch (first launch -> its last
     # chain done) can then exceed the step period, which bounds the forward time of a steady state from above
-    fwd_ms_step = min(fwd_ms_step, elapsed / args.steps * 1e3) if chains > 1 else fwd_ms_step
+    stages = getattr(det.model, "stages", 1)
+    fwd_ms_step = min(fwd_ms_step, elapsed / args.steps * 1e3) if chains > 1 or stages > 1 else fwd_ms_step
     achieved = flops_step / (fwd_ms_step * 1e-3) / 1e12
     res = {
         "metric": "frames/sec whole-node, YOLOv8s 640x640 fp16 detect + ByteTrack",
@@ -224,8 +231,9 @@ def main():
         "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_F16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(achieved / MFMA_F16_DENSE_PEAK_TFLOPS, 4), "traffic": None,
                      "kernel": "forward pass = conv_mfma<*> launches (+ stem, SPPF pool, decode); " +
-                               (f"{chains} sub-batch chains of {S * F // chains} frames on their own streams, one hipGraph each" if chains > 1 else "one hipGraph"),
-                     "chains": chains,
+                               (f"{chains} sub-batch chains of {S * F // chains} frames on their own streams, one hipGraph each" if chains > 1 else
+                                "two stages (backbone | neck + Detect) on two streams, consecutive batches overlapped, one hipGraph per stage" if stages > 1 else "one hipGraph"),
+                     "chains": chains, "stages": stages,
                      "flops_per_step": int(flops_step), "forward_ms_per_step": round(fwd_ms_step, 4),
                      "device_ms_per_step": round(tot_ms / args.steps, 4)},
         "detections_per_frame": round(n_det / frames_total, 2), "live_tracks_node": n_tracks_node,

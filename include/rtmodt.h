@@ -74,7 +74,11 @@ typedef struct rtmodt_det_cfg {
     int32_t use_graph;         /* 1: replay the forward pass as one captured hipGraph                      */
     int32_t autotune;          /* 1: time every conv tile configuration at create and keep the fastest      */
     int32_t chains;            /* sub-batches that run as independent chains (stem -> graph -> decode) on their own streams;
-                                * 0 = automatic: 2 once the batch holds 8 frames or more (measured faster), else 1 */
+                                * -1 = STAGED: the whole batch per launch, net cut after SPPF into two stages on two
+                                * streams, stage 1 of batch t + 1 overlapping stage 2 of batch t (two arena copies;
+                                * keep three batches in flight: enqueue t + 2 before fetching t);
+                                * 0 = automatic: staged for batch >= 2, the plain single-stream engine for batch 1;
+                                * 1 = plain engine; n > 1 = n sub-batch chains */
     int32_t rect;              /* 1: minimal-rectangle letterbox of `predict` on a .pt model (LetterBox auto=True): the scale is
                                 * min(S/h, S/w) with S = max(in_w, in_h) and in_w x in_h is the rectangle (1080p: 640 x 384) */
 } rtmodt_det_cfg;
@@ -109,6 +113,8 @@ int rtmodt_detector_info(rtmodt_detector *det, int32_t *scale_id, int32_t *nc, i
                          int32_t *n_convs, int64_t *conv_flops_per_frame, int64_t *arena_bytes);
 /* Number of sub-batch chains this detector runs its batch as (see rtmodt_det_cfg.chains). */
 int rtmodt_detector_chains(rtmodt_detector *det, int32_t *n_chains);
+/* 2 when the detector runs in the staged mode (rtmodt_det_cfg.chains = -1) and found a hardware queue for it, else 1. */
+int rtmodt_detector_stages(rtmodt_detector *det, int32_t *n_stages);
 /* Copies out, for frame `img` of the last batch: the letterboxed network input as fp16 NHWC(3)
  * [in_h*in_w*3] (may be NULL), the three Detect maps as fp16 [A_i*(64+nc)] concatenated
  * P3,P4,P5 (may be NULL) and the decoded pre-NMS tensor pred[(4+nc)*A] float32 (may be NULL). */

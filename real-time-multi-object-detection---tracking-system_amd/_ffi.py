@@ -78,6 +78,7 @@ def lib() -> C.CDLL:
         "rtmodt_detector_info": (C.c_int, [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), C.POINTER(i32),
                                            C.POINTER(i64), C.POINTER(i64)]),
         "rtmodt_detector_chains": (C.c_int, [vp, C.POINTER(i32)]),
+        "rtmodt_detector_stages": (C.c_int, [vp, C.POINTER(i32)]),
         "rtmodt_detector_debug_fetch": (C.c_int, [vp, C.c_int, vp, vp, vp]),
         "rtmodt_detector_debug_layer": (C.c_int, [vp, C.c_char_p, C.c_int, vp, C.POINTER(i32)]),
         "rtmodt_detector_profile": (C.c_int, [vp, C.c_int, C.c_int, C.POINTER(C.c_char_p), C.POINTER(f32),

@@ -186,6 +186,18 @@ struct rtmodt_detector {
     // are small and latency-bound, so independent chains in flight hide each other's launch
     // gaps, first-load latency and epilogue tails.
     int n_chains = 1;
+    // STAGED mode (cfg.chains = -1): the net is cut after SPPF into a front stage (stem .. layer 9) on the main stream and
+    // a back stage (neck, Detect, decode) on a second stream with a hardware queue of its own; each stage runs the WHOLE
+    // batch (the bigger GEMMs of a 16-frame launch) and the front of batch t + 1 overlaps the back of batch t.  The
+    // stages of consecutive batches work in alternate copies of the activation arena (ring slot parity).
+    bool pipe = false;
+    size_t arena_stride = 0;                          // bytes between the two arena copies
+    int split_op = -1;                                // first op of the back stage
+    int run_par = 0, last_par = 0;                    // arena copy the launches being issued use / the newest batch used
+    std::vector<Op> par_ops[2];                       // d->ops shifted into each arena copy
+    hipGraph_t pipe_graph[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};       // [parity][stage]
+    hipGraphExec_t pipe_exec[2][2][2] = {};           // [parity][stage][instance]: a copy's successive uses alternate instances
+    hipStream_t back_stream = nullptr;
     bool chain_free_run = true;                       // chains never wait for each other (RTMODT_CHAIN_JOIN=1: join on the main stream per batch)
     std::vector<std::vector<Op>> chain_ops;
     std::vector<hipStream_t> aux_streams;             // fork targets during capture
@@ -219,23 +231,25 @@ struct rtmodt_detector {
     // decode's dense per-anchor outputs, one set per ring slot: NMS of batch t (post stream) reads
     // set t%2 while the forward pass of batch t+1 (main stream) fills the other one
     struct Dense { float4 *box = nullptr; float *score = nullptr; int32_t *cls = nullptr; };
-    Dense dense[2];
+    Dense dense[3];                                   // [RING_SLOTS]
     int cur_dense = 0;
+    uint64_t batch_no = 0;                            // batches enqueued so far (graph instance / arena copy = parity)
     float *d_pred = nullptr;
     hipStream_t post_stream = nullptr;                // NMS + D2H + tracker run here, overlapped with the next forward
     uint64_t *d_keys = nullptr; float4 *d_sbox = nullptr; int32_t *d_sidx = nullptr;
-    // results: a ring of RING_SLOTS batches may be in flight (enqueue t+1 before fetching t)
+    // results: a ring of RING_SLOTS batches may be in flight (enqueue t+1 [, t+2] before fetching t)
     struct Slot {
         float *o_xyxy = nullptr, *o_conf = nullptr; int32_t *o_cls = nullptr, *o_anchor = nullptr, *o_n = nullptr;   // device
         float *h_xyxy = nullptr, *h_conf = nullptr; int32_t *h_cls = nullptr, *h_n = nullptr;                        // pinned host
         hipEvent_t ev0 = nullptr, evp = nullptr, ev1 = nullptr, ev2 = nullptr, done = nullptr, decoded = nullptr;   // evp: letterbox done
         hipEvent_t copied = nullptr;       // this slot's frames have arrived in its staging area
         std::vector<hipEvent_t> chain_done; // [n_chains] (entry 0 unused): chain c has finished this slot's sub-batch
+        hipEvent_t front_done = nullptr;   // staged mode: the front stage of this slot's batch is done
         bool staged = false;               // the staging area has been read by a letterbox launch (evp is meaningful)
         bool chained = false, joined = false;   // this slot's batch ran as sub-batch chains; the main stream has waited for all of them
         int n = 0;
     };
-    static constexpr int RING_SLOTS = 2;
+    static constexpr int RING_SLOTS = 3;
     Slot slots[RING_SLOTS];
     int head = 0, n_pending = 0;          // next slot to fill; batches enqueued but not fetched
     int newest = -1, last_fetched = -1;
@@ -295,6 +309,19 @@ static Op sub_batch(const Op &op, int b0, int nb) {
     else if (o.kind == OP_GROUP || o.kind == OP_BNECK) {
         for (auto &c : o.group) { shift(c.in); shift(c.out); shift(c.res); c.B = nb; }
         if (o.kind == OP_BNECK) { shift(o.bneck.in); shift(o.bneck.out); shift(o.bneck.res); shift(o.bneck.tail_in); shift(o.bneck.tail_out); o.bneck.B = nb; }
+    }
+    else for (auto &v : o.v) shift(v);
+    return o;
+}
+
+// the same launch in the other copy of the arena
+static Op shift_arena(const Op &op, size_t bytes) {
+    Op o = op;
+    auto shift = [&](TensorView &v) { if (v.c) v.base = (f16 *)((char *)v.base + bytes); };
+    if (o.kind == OP_CONV) { shift(o.conv.in); shift(o.conv.out); shift(o.conv.res); shift(o.conv.out2); shift(o.conv.tail_out); }
+    else if (o.kind == OP_GROUP || o.kind == OP_BNECK) {
+        for (auto &c : o.group) { shift(c.in); shift(c.out); shift(c.res); }
+        if (o.kind == OP_BNECK) { shift(o.bneck.in); shift(o.bneck.out); shift(o.bneck.res); shift(o.bneck.tail_in); shift(o.bneck.tail_out); }
     }
     else for (auto &v : o.v) shift(v);
     return o;
@@ -600,8 +627,19 @@ static int build_graph(rtmodt_detector *d, WeightFile &wf) {
 
     // one arena for every activation; zeroed once (the zero borders are never written again)
     d->arena_bytes = bld.arena_used + 4096;
-    RT_HIP(hipMalloc((void **)&d->arena, d->arena_bytes));
-    RT_HIP(hipMemset(d->arena, 0, d->arena_bytes));
+    // automatic (chains = 0): staged for every multi-frame batch -- measured against the best chain count at 1 / 2 / 4 / 8 /
+    // 16 / 32 frames per launch set: +48 / +43 / +30 / +31 / +10 / +3 % throughput with three batches in flight; a single
+    // frame run synchronously (detect(), batch 1) keeps the plain engine, whose latency is 7 % lower
+    d->pipe = d->cfg.chains == -1 || (d->cfg.chains == 0 && d->B >= 2);
+    if (getenv("RTMODT_CHAINS")) d->pipe = false;
+    if (const char *e = getenv("RTMODT_PIPE")) d->pipe = atoi(e) != 0;
+    d->pipe = d->pipe && d->cfg.use_graph;
+    for (size_t i = 0; d->pipe && i < d->ops.size(); ++i)
+        if (d->ops[i].name.rfind("12.", 0) == 0) { d->split_op = (int)i; break; }      // the neck starts at layer 12 (10 / 11 are folded away)
+    d->pipe = d->pipe && d->split_op > 1;
+    d->arena_stride = align_up(d->arena_bytes, 4096);
+    RT_HIP(hipMalloc((void **)&d->arena, d->arena_stride * (d->pipe ? 2 : 1)));
+    RT_HIP(hipMemset(d->arena, 0, d->arena_stride * (d->pipe ? 2 : 1)));
     auto rebase = [&](TensorView &v) { if (v.base || v.c) v.base = (f16 *)(d->arena + (uintptr_t)v.base); };
     for (auto &t : d->tensors) t.ptr = (f16 *)(d->arena + (uintptr_t)t.ptr);
     for (auto &op : d->ops) {
@@ -648,6 +686,7 @@ static int build_graph(rtmodt_detector *d, WeightFile &wf) {
     // measured on MI355X (s @ 640): 2 x 4 frames +4.5 % over 1 x 8, 2 x 8 +7 % over 1 x 16, 2 x 16 +8.6 % over 1 x 32; 4 x 8 -12 % against 1 x 32
     int chains = d->cfg.chains > 0 ? d->cfg.chains : (d->B >= 8 && d->B % 2 == 0 ? 2 : 1);
     if (const char *e = getenv("RTMODT_CHAINS")) chains = atoi(e);
+    if (d->pipe) chains = 1;                               // the stages run the whole batch
     if (const char *e = getenv("RTMODT_CHAIN_JOIN")) d->chain_free_run = atoi(e) == 0;
     chains = std::max(1, std::min(chains, d->B));
     while (d->B % chains) --chains;
@@ -689,9 +728,10 @@ static int run_decode_sub(rtmodt_detector *d, int b0, int nb, hipStream_t st) {
     if (d->head_final && !d->want_pred) {                  // the two last convs of Detect and the decode in one launch
         HeadFinalArgs h = d->hf;
         h.conf = d->cfg.conf; h.class_mask[0] = d->class_mask[0]; h.class_mask[1] = d->class_mask[1];
+        const size_t par = (size_t)d->run_par * d->arena_stride / sizeof(f16);
         for (int l = 0; l < 3; ++l) {
             const size_t hw = (size_t)h.lvl[l].H * h.lvl[l].W * b0;
-            h.lvl[l].xb += hw * h.cbox; h.lvl[l].xc += hw * h.ccls;
+            h.lvl[l].xb += hw * h.cbox + par; h.lvl[l].xc += hw * h.ccls + par;
         }
         h.B = nb;
         h.box = dn.box + a0; h.score = dn.score + a0; h.cls = dn.cls + a0;
@@ -701,7 +741,7 @@ static int run_decode_sub(rtmodt_detector *d, int b0, int nb, hipStream_t st) {
     const int strides[3] = {8, 16, 32};
     for (int l = 0; l < 3; ++l) {
         const Tensor &t = d->tensors[d->head_t[l]];
-        a.lvl[l] = HeadLevel{t.ptr + t.per_image * b0, t.H, t.W, strides[l]};
+        a.lvl[l] = HeadLevel{t.ptr + t.per_image * b0 + (size_t)d->run_par * d->arena_stride / sizeof(f16), t.H, t.W, strides[l]};
     }
     a.B = nb; a.nc = d->nc; a.n_anchors = d->n_anchors; a.conf = d->cfg.conf;
     a.no = d->tensors[d->head_t[0]].C;
@@ -1011,14 +1051,15 @@ static int streams_overlap(hipStream_t a, hipStream_t b, hipEvent_t e0, hipEvent
     return RTMODT_OK;
 }
 static int ensure_chain_streams(rtmodt_detector *d) {
-    if ((int)d->chain_streams.size() >= d->n_chains) return RTMODT_OK;
+    const int want = d->pipe ? 2 : d->n_chains;            // staged mode: the back stage's stream is found like a chain's
+    if ((int)d->chain_streams.size() >= want || d->back_stream) return RTMODT_OK;
     hipEvent_t e0, e1, ej;
     RT_HIP(hipEventCreate(&e0)); RT_HIP(hipEventCreate(&e1)); RT_HIP(hipEventCreateWithFlags(&ej, hipEventDisableTiming));
     if (const char *e = getenv("RTMODT_PAD_STREAMS"))      // test hook: streams created ahead of ours shift the queue mapping
         for (int i = 0; i < atoi(e); ++i) { hipStream_t st; RT_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking)); d->pad_streams.push_back(st); }
     std::vector<hipStream_t> rejected;
     int rc = RTMODT_OK;
-    while (rc == RTMODT_OK && (int)d->chain_streams.size() < d->n_chains) {
+    while (rc == RTMODT_OK && (int)d->chain_streams.size() < want) {
         hipStream_t st = d->stream;
         if (!d->chain_streams.empty()) {
             st = nullptr;
@@ -1050,6 +1091,12 @@ static int ensure_chain_streams(rtmodt_detector *d) {
     for (hipStream_t st : rejected) hipStreamDestroy(st);
     hipEventDestroy(e0); hipEventDestroy(e1); hipEventDestroy(ej);
     RT_TRY(rc);
+    if (d->pipe) {
+        if (d->chain_streams.size() == 2) { d->back_stream = d->chain_streams[1]; hipEventDestroy(d->chain_fork[1]); hipEventDestroy(d->chain_join[1]); }
+        else d->pipe = false;                              // no queue to spare: plain single-chain engine (the second arena copy stays unused)
+        d->chain_streams.resize(1); d->chain_fork.resize(1); d->chain_join.resize(1);
+        return RTMODT_OK;
+    }
     if ((int)d->chain_streams.size() < d->n_chains) {      // fewer queues than chains: as many chains as found streams (dividing the batch)
         int c = (int)d->chain_streams.size();
         while (d->B % c) --c;
@@ -1060,7 +1107,31 @@ static int ensure_chain_streams(rtmodt_detector *d) {
     return RTMODT_OK;
 }
 
+// staged mode: per arena copy, one graph for the front stage (captured on the main stream) and one for the back stage
+static int capture_pipe(rtmodt_detector *d) {
+    for (int par = 0; par < 2; ++par) {
+        d->par_ops[par].clear();
+        for (auto &op : d->chain_ops[0]) d->par_ops[par].push_back(shift_arena(op, par * d->arena_stride));
+        for (int stage = 0; stage < 2; ++stage) {
+            for (int k = 0; k < 2; ++k) if (d->pipe_exec[par][stage][k]) { hipGraphExecDestroy(d->pipe_exec[par][stage][k]); d->pipe_exec[par][stage][k] = nullptr; }
+            if (d->pipe_graph[par][stage]) hipGraphDestroy(d->pipe_graph[par][stage]);
+            hipStream_t st = stage == 0 ? d->stream : d->back_stream;
+            const size_t lo = stage == 0 ? 0 : (size_t)d->split_op, hi = stage == 0 ? (size_t)d->split_op : d->par_ops[par].size();
+            RT_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed));
+            int rc = RTMODT_OK;
+            for (size_t i = lo; i < hi && rc == RTMODT_OK; ++i)
+                if (d->par_ops[par][i].kind != OP_STEM) rc = run_op_on(d->par_ops[par][i], st);      // the stem is launched by enqueue_batch (fresh frame pointers)
+            hipError_t e = hipStreamEndCapture(st, &d->pipe_graph[par][stage]);
+            RT_TRY(rc);
+            RT_HIP(e);
+            for (int k = 0; k < 2; ++k) RT_HIP(hipGraphInstantiate(&d->pipe_exec[par][stage][k], d->pipe_graph[par][stage], nullptr, nullptr, 0));
+        }
+    }
+    return RTMODT_OK;
+}
+
 static int capture_graph(rtmodt_detector *d) {
+    if (d->pipe) return capture_pipe(d);
     const int C = d->n_chains;
     for (auto g : d->graph_execs) if (g) hipGraphExecDestroy(g);
     for (auto g : d->graphs) if (g) hipGraphDestroy(g);
@@ -1084,7 +1155,7 @@ static int capture_graph(rtmodt_detector *d) {
 
 // stem output -> dense per-anchor candidates of a single-chain detector, on the main stream
 static int forward_graphs(rtmodt_detector *d) {
-    const int inst = getenv("RTMODT_ONE_EXEC") ? 0 : (d->cur_dense & 1);   // ring slot parity
+    const int inst = getenv("RTMODT_ONE_EXEC") ? 0 : (int)(d->batch_no & 1);   // alternate batches, alternate instances
     RT_HIP(hipGraphLaunch(d->graph_execs[inst], d->stream));
     return run_decode(d);
 }
@@ -1097,7 +1168,7 @@ static int forward_graphs(rtmodt_detector *d) {
 // (needed when the next batch's whole-batch letterbox would overwrite an image tensor a lagging chain still reads).
 static int forward_chains(rtmodt_detector *d, rtmodt_detector::Slot &sl, bool host_frames, bool join_main) {
     const int C = d->n_chains, nb = d->B / C;
-    const int inst = getenv("RTMODT_ONE_EXEC") ? 0 : (d->cur_dense & 1);
+    const int inst = getenv("RTMODT_ONE_EXEC") ? 0 : (int)(d->batch_no & 1);
     for (int c = 0; c < C; ++c) {
         hipStream_t st = d->chain_streams[c];
         if (c > 0) {
@@ -1194,7 +1265,13 @@ void rtmodt_detector_destroy(rtmodt_detector *d) {
     hipDeviceSynchronize();
     for (auto g : d->graph_execs) if (g) hipGraphExecDestroy(g);
     for (auto g : d->graphs) if (g) hipGraphDestroy(g);
-    for (int k = 0; k < 2; ++k) { hipFree(d->dense[k].box); hipFree(d->dense[k].score); hipFree(d->dense[k].cls); }
+    for (int par = 0; par < 2; ++par)
+        for (int st = 0; st < 2; ++st) {
+            for (int k = 0; k < 2; ++k) if (d->pipe_exec[par][st][k]) hipGraphExecDestroy(d->pipe_exec[par][st][k]);
+            if (d->pipe_graph[par][st]) hipGraphDestroy(d->pipe_graph[par][st]);
+        }
+    if (d->back_stream) hipStreamDestroy(d->back_stream);
+    for (auto &dn : d->dense) { hipFree(dn.box); hipFree(dn.score); hipFree(dn.cls); }
     for (size_t c = 1; c < d->chain_streams.size(); ++c) hipStreamDestroy(d->chain_streams[c]);
     for (auto e : d->chain_fork) hipEventDestroy(e);
     for (auto e : d->chain_join) hipEventDestroy(e);
@@ -1212,6 +1289,7 @@ void rtmodt_detector_destroy(rtmodt_detector *d) {
         hipHostFree(sl.h_xyxy); hipHostFree(sl.h_conf); hipHostFree(sl.h_cls); hipHostFree(sl.h_n);
         for (hipEvent_t e : {sl.ev0, sl.evp, sl.ev1, sl.ev2, sl.done, sl.decoded, sl.copied}) if (e) hipEventDestroy(e);
         for (hipEvent_t e : sl.chain_done) if (e) hipEventDestroy(e);
+        if (sl.front_done) hipEventDestroy(sl.front_done);
     }
     if (d->stream) hipStreamDestroy(d->stream);
     delete d;
@@ -1282,6 +1360,7 @@ static int detector_create_impl(const rtmodt_det_cfg *cfg, rtmodt_detector *d) {
         RT_HIP(hipEventCreateWithFlags(&sl.copied, hipEventDisableTiming));
         sl.chain_done.assign(d->n_chains, nullptr);
         for (int c = 1; c < d->n_chains; ++c) RT_HIP(hipEventCreate(&sl.chain_done[c]));
+        RT_HIP(hipEventCreateWithFlags(&sl.front_done, hipEventDisableTiming));
     }
 
     {   // c / 255 in fp16 exactly as the letterbox kernel computes it (IEEE float division, then round to half)
@@ -1362,10 +1441,10 @@ int rtmodt_detector_enqueue_batch(rtmodt_detector *d, const uint8_t *const *fram
     }
     LetterboxGeom lg{h, w, g.new_w, g.new_h, g.top, g.left, g.resize};
     TensorView img; img.base = d->tensors[d->img_t].ptr; img.H = d->in_h; img.W = d->in_w; img.C = 4; img.pad = 1; img.c = 4;
-    d->cur_dense = d->head;                            // ring slot == dense set == graph
+    d->cur_dense = d->head;                            // ring slot == dense set
     d->last_lg = lg; d->last_pitch = stride_bytes;
     d->last_fused = d->stem_fuse && !g.resize;
-    const bool graphs = !d->graph_execs.empty() && !d->want_pred;
+    const bool graphs = (!d->graph_execs.empty() || (d->pipe && d->pipe_exec[0][0][0])) && !d->want_pred;
     const bool chained = graphs && d->n_chains > 1;
     // a lagging chain of the previous batch may still be reading what the main stream is about to overwrite or time
     if (!chained || !d->last_fused || !d->chain_free_run)
@@ -1374,13 +1453,34 @@ int rtmodt_detector_enqueue_batch(rtmodt_detector *d, const uint8_t *const *fram
                 for (int c = 1; c < d->n_chains; ++c) RT_HIP(hipStreamWaitEvent(d->stream, d->slots[k].chain_done[c], 0));
                 d->slots[k].joined = true;
             }
+    if (graphs && d->pipe && d->batch_no >= 2) {           // this arena copy was last read by the back stage of batch t - 2
+        const rtmodt_detector::Slot &old = d->slots[(d->head + rtmodt_detector::RING_SLOTS - 2) % rtmodt_detector::RING_SLOTS];
+        RT_HIP(hipStreamWaitEvent(d->stream, old.ev1, 0));
+    }
     RT_HIP(hipEventRecord(sl.ev0, d->stream));
     if (!d->last_fused) {
+        if (graphs && d->pipe) img.base = (f16 *)((char *)img.base + (size_t)(d->batch_no & 1) * d->arena_stride);
         RT_TRY(launch_letterbox(d->fptrs, stride_bytes, lg, d->tabs, img, d->B, d->stream));
         if (chained) RT_HIP(hipEventRecord(sl.evp, d->stream));
     }
     sl.chained = chained; sl.joined = false;
-    if (chained) {
+    d->run_par = 0;
+    if (graphs && d->pipe) {
+        const int par = (int)(d->batch_no & 1), inst = (int)((d->batch_no >> 1) & 1);
+        d->run_par = par;
+        const Op &stem = d->par_ops[par][0];
+        if (d->last_fused) RT_TRY(launch_stem_fused(d->fptrs, 0, d->last_pitch, d->last_lg, d->in_h, d->in_w, d->lut255, stem.v[1], stem.stem_w, stem.stem_b,
+                                                    d->B, stem.v[1].c, d->stream));
+        else RT_TRY(run_op_on(stem, d->stream));
+        RT_HIP(hipEventRecord(sl.evp, d->stream));
+        RT_HIP(hipGraphLaunch(d->pipe_exec[par][0][inst], d->stream));
+        RT_HIP(hipEventRecord(sl.front_done, d->stream));
+        RT_HIP(hipStreamWaitEvent(d->back_stream, sl.front_done, 0));
+        RT_HIP(hipGraphLaunch(d->pipe_exec[par][1][inst], d->back_stream));
+        RT_TRY(run_decode_sub(d, 0, d->B, d->back_stream));
+        RT_HIP(hipEventRecord(sl.ev1, d->back_stream));
+        RT_HIP(hipEventRecord(sl.decoded, d->back_stream));
+    } else if (chained) {
         sl.joined = !d->last_fused || !d->chain_free_run;
         RT_TRY(forward_chains(d, sl, mem_kind == RTMODT_MEM_HOST, sl.joined));
     } else {
@@ -1389,8 +1489,11 @@ int rtmodt_detector_enqueue_batch(rtmodt_detector *d, const uint8_t *const *fram
         if (graphs) RT_TRY(forward_graphs(d));
         else RT_TRY(forward_eager(d));
     }
-    RT_HIP(hipEventRecord(sl.ev1, d->stream));
-    RT_HIP(hipEventRecord(sl.decoded, d->stream));
+    if (!(graphs && d->pipe)) {
+        RT_HIP(hipEventRecord(sl.ev1, d->stream));
+        RT_HIP(hipEventRecord(sl.decoded, d->stream));
+    }
+    d->last_par = d->run_par;
     // post-processing on its own stream: one small workgroup per image, latency-bound -- it runs
     // underneath the next batch's forward pass instead of in front of it
     RT_HIP(hipStreamWaitEvent(d->post_stream, sl.decoded, 0));
@@ -1407,6 +1510,7 @@ int rtmodt_detector_enqueue_batch(rtmodt_detector *d, const uint8_t *const *fram
     sl.n = n;
     d->newest = d->head;
     d->head = (d->head + 1) % rtmodt_detector::RING_SLOTS;
+    d->batch_no += 1;
     d->n_pending += 1;
     d->last_h = h; d->last_w = w;
     return RTMODT_OK;
@@ -1459,16 +1563,23 @@ int rtmodt_detector_info(rtmodt_detector *d, int32_t *scale_id, int32_t *nc, int
 }
 
 // dense copy of a channel-slice view of image `img`
+int rtmodt_detector_stages(rtmodt_detector *d, int32_t *n_stages) {
+    RT_CHECK(d && n_stages, RTMODT_E_INVALID, "null argument");
+    *n_stages = d->pipe ? 2 : 1;
+    return RTMODT_OK;
+}
+
 int rtmodt_detector_chains(rtmodt_detector *d, int32_t *n_chains) {
     RT_CHECK(d && n_chains, RTMODT_E_INVALID, "null argument");
     *n_chains = d->n_chains;
     return RTMODT_OK;
 }
 
-static int fetch_view(rtmodt_detector *d, const TensorView &v, int img, uint16_t *out) {
+static int fetch_view(rtmodt_detector *d, const TensorView &v, int img, uint16_t *out, int par = -1) {
     size_t per = (size_t)(v.H + 2 * v.pad) * (v.W + 2 * v.pad) * v.C;
     std::vector<uint16_t> tmp(per);
-    RT_HIP(hipMemcpy(tmp.data(), v.base + per * img, per * 2, hipMemcpyDeviceToHost));
+    if (par < 0) par = d->last_par;                        // the arena copy the newest batch ran in
+    RT_HIP(hipMemcpy(tmp.data(), (const char *)(v.base + per * img) + (size_t)par * d->arena_stride, per * 2, hipMemcpyDeviceToHost));
     for (int y = 0; y < v.H; ++y)
         for (int x = 0; x < v.W; ++x)
             memcpy(out + ((size_t)y * v.W + x) * v.c, &tmp[((size_t)(y + v.pad) * (v.W + 2 * v.pad) + x + v.pad) * v.C + v.coff], (size_t)v.c * 2);
@@ -1482,7 +1593,8 @@ static int materialize_heads(rtmodt_detector *d) {
     h.conf = d->cfg.conf; h.class_mask[0] = d->class_mask[0]; h.class_mask[1] = d->class_mask[1];
     const rtmodt_detector::Dense &dn = d->dense[d->cur_dense];
     h.box = dn.box; h.score = dn.score; h.cls = dn.cls;
-    for (int l = 0; l < 3; ++l) h.lvl[l].heads = d->tensors[d->head_t[l]].ptr;
+    const size_t par = (size_t)d->last_par * d->arena_stride / sizeof(f16);      // the arena copy the newest batch ran in
+    for (int l = 0; l < 3; ++l) { h.lvl[l].xb += par; h.lvl[l].xc += par; h.lvl[l].heads = d->tensors[d->head_t[l]].ptr + par; }
     RT_TRY(launch_head_final(h, d->stream));
     RT_HIP(hipStreamSynchronize(d->stream));
     return RTMODT_OK;
@@ -1501,7 +1613,7 @@ int rtmodt_detector_debug_fetch(rtmodt_detector *d, int img, uint16_t *input_f16
         }
         TensorView v; const Tensor &t = d->tensors[d->img_t];
         v.base = t.ptr; v.H = t.H; v.W = t.W; v.C = 4; v.pad = 1; v.coff = 0; v.c = 3;
-        RT_TRY(fetch_view(d, v, img, input_f16));
+        RT_TRY(fetch_view(d, v, img, input_f16, d->last_fused ? 0 : -1));      // (the re-run above wrote the first arena copy)
     }
     if (d->head_final && (heads_f16 || pred)) RT_TRY(materialize_heads(d));
     if (heads_f16) {
@@ -1516,8 +1628,10 @@ int rtmodt_detector_debug_fetch(rtmodt_detector *d, int img, uint16_t *input_f16
     if (pred) {
         // re-run decode with the pred dump enabled (inputs are still resident)
         d->want_pred = true;
+        d->run_par = d->last_par;
         int rc = run_decode(d);
         d->want_pred = false;
+        d->run_par = 0;
         RT_TRY(rc);
         RT_HIP(hipStreamSynchronize(d->stream));
         size_t per = (size_t)(4 + d->nc) * d->n_anchors;
@@ -1560,6 +1674,7 @@ int rtmodt_detector_profile(rtmodt_detector *d, int iters, int max_entries, cons
     RT_HIP(hipSetDevice(d->device));
     // with sub-batch chains the launches that run are those of one chain (its sub-batch), timed here alone on the device
     const std::vector<Op> &ops = d->n_chains > 1 ? d->chain_ops[0] : d->ops;
+    d->run_par = 0;                                        // eager launches work in the first arena copy
     const int PB = d->B / d->n_chains;
     const int n = (int)ops.size() + 1;
     std::vector<hipEvent_t> ev((size_t)n + 1);

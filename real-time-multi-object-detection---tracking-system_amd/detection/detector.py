@@ -161,6 +161,8 @@ class Detector:
             nch = C.c_int32()
             _ffi.check(L.rtmodt_detector_chains(h, C.byref(nch)))
             m.chains = nch.value             # sub-batch chains the batch runs as (own streams, joined by the post-processing stream)
+            _ffi.check(L.rtmodt_detector_stages(h, C.byref(nch)))
+            m.stages = nch.value             # 2: staged mode (chains=-1), front and back half of the net on two streams
             self._models[(in_h, in_w)] = m
         return m
 
@@ -214,7 +216,7 @@ class Detector:
         self._in_flight.append(n)
 
     def fetch(self) -> list:
-        """Results of the OLDEST batch in flight (up to two may be: enqueue t+1, fetch t)."""
+        """Results of the OLDEST batch in flight (up to three may be: enqueue t+1 [, t+2], fetch t)."""
         if not self._in_flight:
             raise RuntimeError("fetch() without a pending enqueue()")
         n = self._in_flight.pop(0)

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Where a step's time goes, from a rocprofv3 --kernel-trace CSV of `bench.py`.  The forward pass runs as one chain of
-dependent launches per sub-batch, each chain on its own queue (the queues that carry a stem launch); over the last
+dependent launches per sub-batch (or per stage of the net), each on its own queue (the queues that carry a stem or a
+head_final launch); over the last
 `steps` steps this prints, per chain, the sum of its kernels' durations and the idle gaps between consecutive
 kernels, and for the device the time during which at least one / at least two forward-pass kernels were running.
     python tools/trace_gaps.py gpurun_out/trace/*/*_kernel_trace.csv [steps]
@@ -16,7 +17,7 @@ for r in csv.DictReader(open(path)):
     rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r.get("Queue_Id", "")))
 rows.sort()
 is_stem = lambda name: "letterbox" in name or "stem_fused" in name      # first launch of a chain's step
-queues = sorted({r[3] for r in rows if is_stem(r[2])})
+queues = sorted({r[3] for r in rows if is_stem(r[2])}) + sorted({r[3] for r in rows if "head_final" in r[2]} - {r[3] for r in rows if is_stem(r[2])})      # (+ the back stage's queue in the staged mode)
 first = [r for r in rows if is_stem(r[2]) and r[3] == queues[0]]
 assert len(first) > steps, "trace shorter than the requested number of steps"
 t0, t1 = first[-steps - 1][0], first[-1][0]
