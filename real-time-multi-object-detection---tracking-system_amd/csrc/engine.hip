@@ -635,7 +635,7 @@ static int build_graph(rtmodt_detector *d, WeightFile &wf) {
     if (const char *e = getenv("RTMODT_PIPE")) d->pipe = atoi(e) != 0;
     d->pipe = d->pipe && d->cfg.use_graph;
     for (size_t i = 0; d->pipe && i < d->ops.size(); ++i)
-        if (d->ops[i].name.rfind("12.", 0) == 0) { d->split_op = (int)i; break; }      // the neck starts at layer 12 (10 / 11 are folded away)
+        if (d->ops[i].name.rfind(getenv("RTMODT_SPLIT") ? getenv("RTMODT_SPLIT") : "12.", 0) == 0) { d->split_op = (int)i; break; }   // the neck starts at layer 12 (10 / 11 are folded away); RTMODT_SPLIT: experiment hook
     d->pipe = d->pipe && d->split_op > 1;
     d->arena_stride = align_up(d->arena_bytes, 4096);
     RT_HIP(hipMalloc((void **)&d->arena, d->arena_stride * (d->pipe ? 2 : 1)));

@@ -3,7 +3,7 @@
 #   gpurun --timeout 1100 -- 'bash tools/collect_profiles.sh r01'   then   python tools/summarize_profiles.py gpurun_out/r01 profiles/r01
 # PMC counters are collected in their own passes (never together with a trace domain other than kernel-trace); counter
 # collection serialises every kernel, so the engine's stream-overlap probe is switched off there (RTMODT_CHAIN_PROBE=0) to
-# keep the two-chain configuration the bench runs.
+# keep the two-stream configuration the bench runs.
 set -o pipefail
 R=${1:-r01}
 O=gpurun_out/$R
@@ -18,9 +18,9 @@ B="python3 bench.py --no-cpu-baseline --no-latency --no-compare"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- $B --steps 100 --warmup 10 > $O/stats_bench.json 2> $O/stats.log || exit 1
 python tools/trace_gaps.py $O/stats/*/*_kernel_trace.csv 50 > $O/step_gaps.txt 2>&1
 rm -f $O/stats/*/*_kernel_trace.csv
-# the same bench as ONE chain: every forward-pass kernel alone on the device, so the per-kernel averages of the trace can be
-# set against the HIP-event times of tools/profile_layers.py and bench.py (with two chains, kernels of both overlap and each
-# one's duration in the trace includes the time it shared the CUs)
+# the same bench on the PLAIN engine (one stream, one graph): every forward-pass kernel alone on the device, so the per-kernel
+# averages of the trace can be set against the HIP-event times of tools/profile_layers.py and bench.py (in the staged default
+# the kernels of the two stages overlap and each one's duration in the trace includes the time it shared the CUs)
 RTMODT_CHAINS=1 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_chains1 -- $B --steps 100 --warmup 10 > $O/stats_chains1_bench.json 2> $O/stats_chains1.log || exit 1
 python tools/trace_gaps.py $O/stats_chains1/*/*_kernel_trace.csv 50 > $O/step_gaps_chains1.txt 2>&1
 rm -f $O/stats_chains1/*/*_kernel_trace.csv
@@ -33,6 +33,7 @@ echo "[collect] pmc done"
 python tools/profile_layers.py > $O/layers.txt 2> /dev/null
 RTMODT_CHAINS=1 python tools/profile_layers.py > $O/layers_chains1.txt 2> /dev/null
 RTMODT_CHAINS=1 $B --steps 300 --warmup 30 > $O/bench_chains1.json 2> /dev/null
+RTMODT_CHAINS=2 $B --steps 300 --warmup 30 > $O/bench_chains2.json 2> /dev/null
 $B --steps 300 --warmup 30 --frames-per-stream 1 > $O/bench_frames1.json 2> /dev/null
 $B --steps 200 --warmup 20 --frames-per-stream 4 > $O/bench_frames4.json 2> /dev/null
 $B --steps 300 --warmup 30 --streams 16 --frames-per-stream 1 > $O/bench_streams16.json 2> /dev/null
