@@ -47,7 +47,8 @@ def parse():
     ap.add_argument("--max-det", type=int, default=100)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true")
-    ap.add_argument("--depth", type=int, default=0, help="batches in flight after a submit (0: 2, or 3 in the staged mode)")
+    ap.add_argument("--stages", type=int, default=0, help="stages of the staged engine (0: 3 for HBM-resident frames, 2 for host frames; 1: plain engine)")
+    ap.add_argument("--depth", type=int, default=0, help="batches in flight after a submit (0: 2, or stages + 1 in the staged mode)")
     ap.add_argument("--no-compare", action="store_true", help="skip the extra one-frame-per-stream run (profiler passes: one workload per process)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend: nccl (= RCCL, default) or gloo (rehearsal on a 1-GPU box)")
@@ -141,8 +142,11 @@ def main():
 
     def measure(F, steps, warmup, collective=True):
         """K timed steps; a step = one launch set over S streams x F consecutive frames (image f * S + s)."""
+        # engine: the staged one; three stages when the frames are already in HBM (the headline configuration), two when
+        # they come from the host, because the copy stream then needs the hardware queue the third stage would take
+        stages = args.stages if args.stages > 0 else (2 if args.host_frames else 3)
         det = pkg.Detector(wpath, input_size=(size, size), max_det=args.max_det, device=f"cuda:{dev}", batch=S * F,
-                           use_graph=not args.no_graph, warmup=False)
+                           use_graph=not args.no_graph, warmup=False, chains=1 - stages if stages > 1 else 1)
         trk = core_cls(device=dev, n_streams=S, max_dets=max(128, args.max_det), max_tracks=2048)
 
         def submit(t):
@@ -166,7 +170,7 @@ def main():
         gc.disable()
         # prime the pipeline: one batch always in flight (two in the staged mode, whose front stage of batch t + 2 would
         # otherwise wait for the host to see the results of batch t)
-        depth = args.depth if args.depth > 0 else (3 if getattr(det.model, "stages", 1) > 1 else 2)
+        depth = args.depth if args.depth > 0 else (getattr(det.model, "stages", 1) + 1 if getattr(det.model, "stages", 1) > 1 else 2)
         for t in range(depth - 1):
             submit(t)
         for t in range(depth - 1, warmup + depth - 1):
@@ -232,7 +236,7 @@ def main():
                      "frac": round(achieved / MFMA_F16_DENSE_PEAK_TFLOPS, 4), "traffic": None,
                      "kernel": "forward pass = conv_mfma<*> launches (+ stem, SPPF pool, decode); " +
                                (f"{chains} sub-batch chains of {S * F // chains} frames on their own streams, one hipGraph each" if chains > 1 else
-                                "two stages (backbone | neck + Detect) on two streams, consecutive batches overlapped, one hipGraph per stage" if stages > 1 else "one hipGraph"),
+                                f"{stages} stages of the net on {stages} streams, consecutive batches overlapped, one hipGraph per stage" if stages > 1 else "one hipGraph"),
                      "chains": chains, "stages": stages,
                      "flops_per_step": int(flops_step), "forward_ms_per_step": round(fwd_ms_step, 4),
                      "device_ms_per_step": round(tot_ms / args.steps, 4)},

@@ -74,10 +74,12 @@ typedef struct rtmodt_det_cfg {
     int32_t use_graph;         /* 1: replay the forward pass as one captured hipGraph                      */
     int32_t autotune;          /* 1: time every conv tile configuration at create and keep the fastest      */
     int32_t chains;            /* sub-batches that run as independent chains (stem -> graph -> decode) on their own streams;
-                                * -1 = STAGED: the whole batch per launch, net cut after SPPF into two stages on two
-                                * streams, stage 1 of batch t + 1 overlapping stage 2 of batch t (two arena copies;
-                                * keep three batches in flight: enqueue t + 2 before fetching t);
-                                * 0 = automatic: staged for batch >= 2, the plain single-stream engine for batch 1;
+                                * -1 / -2 = STAGED with S = 2 / 3 stages: the whole batch per launch, the net cut into S
+                                * stages on S streams, stage 1 of batch t + 1 overlapping stage 2 of batch t (S arena
+                                * copies; keep S + 1 batches in flight: enqueue t + S before fetching t).  Three stages
+                                * take every hardware queue of the process: use them when the frames are already in
+                                * device memory, two when they come from the host through the engine's copy stream;
+                                * 0 = automatic: two stages for batch >= 2, the plain single-stream engine for batch 1;
                                 * 1 = plain engine; n > 1 = n sub-batch chains */
     int32_t rect;              /* 1: minimal-rectangle letterbox of `predict` on a .pt model (LetterBox auto=True): the scale is
                                 * min(S/h, S/w) with S = max(in_w, in_h) and in_w x in_h is the rectangle (1080p: 640 x 384) */
@@ -113,7 +115,7 @@ int rtmodt_detector_info(rtmodt_detector *det, int32_t *scale_id, int32_t *nc, i
                          int32_t *n_convs, int64_t *conv_flops_per_frame, int64_t *arena_bytes);
 /* Number of sub-batch chains this detector runs its batch as (see rtmodt_det_cfg.chains). */
 int rtmodt_detector_chains(rtmodt_detector *det, int32_t *n_chains);
-/* 2 when the detector runs in the staged mode (rtmodt_det_cfg.chains = -1) and found a hardware queue for it, else 1. */
+/* Stages the detector runs as (rtmodt_det_cfg.chains = -1 / -2 and a hardware queue found for each): 2 or 3, else 1. */
 int rtmodt_detector_stages(rtmodt_detector *det, int32_t *n_stages);
 /* Copies out, for frame `img` of the last batch: the letterboxed network input as fp16 NHWC(3)
  * [in_h*in_w*3] (may be NULL), the three Detect maps as fp16 [A_i*(64+nc)] concatenated

@@ -192,12 +192,14 @@ struct rtmodt_detector {
     // stages of consecutive batches work in alternate copies of the activation arena (ring slot parity).
     bool pipe = false;
     size_t arena_stride = 0;                          // bytes between the two arena copies
-    int split_op = -1;                                // first op of the back stage
+    static constexpr int MAX_STAGES = 3;
+    int n_stages = 1;                                 // 2: backbone | neck + Detect; 3: layers 0-6.cv1 | 6.m-15 | 16-22
+    int stage_lo[MAX_STAGES + 1] = {0, 0, 0, 0};      // stage s runs ops [stage_lo[s], stage_lo[s + 1])
     int run_par = 0, last_par = 0;                    // arena copy the launches being issued use / the newest batch used
-    std::vector<Op> par_ops[2];                       // d->ops shifted into each arena copy
-    hipGraph_t pipe_graph[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};       // [parity][stage]
-    hipGraphExec_t pipe_exec[2][2][2] = {};           // [parity][stage][instance]: a copy's successive uses alternate instances
-    hipStream_t back_stream = nullptr;
+    std::vector<Op> par_ops[MAX_STAGES];              // d->ops shifted into each arena copy (one copy per stage)
+    hipGraph_t pipe_graph[MAX_STAGES][MAX_STAGES] = {};       // [arena copy][stage]
+    hipGraphExec_t pipe_exec[MAX_STAGES][MAX_STAGES][2] = {};   // [arena copy][stage][instance]: a copy's successive uses alternate instances
+    hipStream_t stage_stream[MAX_STAGES] = {nullptr, nullptr, nullptr};      // [0] = the main stream
     bool chain_free_run = true;                       // chains never wait for each other (RTMODT_CHAIN_JOIN=1: join on the main stream per batch)
     std::vector<std::vector<Op>> chain_ops;
     std::vector<hipStream_t> aux_streams;             // fork targets during capture
@@ -231,7 +233,7 @@ struct rtmodt_detector {
     // decode's dense per-anchor outputs, one set per ring slot: NMS of batch t (post stream) reads
     // set t%2 while the forward pass of batch t+1 (main stream) fills the other one
     struct Dense { float4 *box = nullptr; float *score = nullptr; int32_t *cls = nullptr; };
-    Dense dense[3];                                   // [RING_SLOTS]
+    Dense dense[4];                                   // [RING_SLOTS]
     int cur_dense = 0;
     uint64_t batch_no = 0;                            // batches enqueued so far (graph instance / arena copy = parity)
     float *d_pred = nullptr;
@@ -244,12 +246,12 @@ struct rtmodt_detector {
         hipEvent_t ev0 = nullptr, evp = nullptr, ev1 = nullptr, ev2 = nullptr, done = nullptr, decoded = nullptr;   // evp: letterbox done
         hipEvent_t copied = nullptr;       // this slot's frames have arrived in its staging area
         std::vector<hipEvent_t> chain_done; // [n_chains] (entry 0 unused): chain c has finished this slot's sub-batch
-        hipEvent_t front_done = nullptr;   // staged mode: the front stage of this slot's batch is done
+        hipEvent_t stage_done[2] = {nullptr, nullptr};   // staged mode: stage s of this slot's batch is done (s < last)
         bool staged = false;               // the staging area has been read by a letterbox launch (evp is meaningful)
         bool chained = false, joined = false;   // this slot's batch ran as sub-batch chains; the main stream has waited for all of them
         int n = 0;
     };
-    static constexpr int RING_SLOTS = 3;
+    static constexpr int RING_SLOTS = 4;               // staged engine with S stages: S + 1 batches in flight
     Slot slots[RING_SLOTS];
     int head = 0, n_pending = 0;          // next slot to fill; batches enqueued but not fetched
     int newest = -1, last_fetched = -1;
@@ -630,16 +632,29 @@ static int build_graph(rtmodt_detector *d, WeightFile &wf) {
     // automatic (chains = 0): staged for every multi-frame batch -- measured against the best chain count at 1 / 2 / 4 / 8 /
     // 16 / 32 frames per launch set: +48 / +43 / +30 / +31 / +10 / +3 % throughput with three batches in flight; a single
     // frame run synchronously (detect(), batch 1) keeps the plain engine, whose latency is 7 % lower
-    d->pipe = d->cfg.chains == -1 || (d->cfg.chains == 0 && d->B >= 2);
-    if (getenv("RTMODT_CHAINS")) d->pipe = false;
-    if (const char *e = getenv("RTMODT_PIPE")) d->pipe = atoi(e) != 0;
-    d->pipe = d->pipe && d->cfg.use_graph;
-    for (size_t i = 0; d->pipe && i < d->ops.size(); ++i)
-        if (d->ops[i].name.rfind(getenv("RTMODT_SPLIT") ? getenv("RTMODT_SPLIT") : "12.", 0) == 0) { d->split_op = (int)i; break; }   // the neck starts at layer 12 (10 / 11 are folded away); RTMODT_SPLIT: experiment hook
-    d->pipe = d->pipe && d->split_op > 1;
+    int stages = d->cfg.chains < 0 ? 1 - d->cfg.chains : (d->cfg.chains == 0 && d->B >= 2 ? 2 : 1);      // -1 -> 2 stages, -2 -> 3
+    if (getenv("RTMODT_CHAINS")) stages = 1;
+    if (const char *e = getenv("RTMODT_PIPE")) stages = atoi(e) != 0 ? 2 : 1;
+    if (const char *e = getenv("RTMODT_STAGES")) stages = atoi(e);
+    stages = d->cfg.use_graph ? std::max(1, std::min(stages, (int)rtmodt_detector::MAX_STAGES)) : 1;
+    {   // stage boundaries by layer name: 2 stages cut after SPPF (52 % / 48 % of the kernel time), 3 stages at 32 % / 66 %
+        const char *cut2[] = {"12."}, *cut3[] = {"6.m", "16"};
+        const char **cuts = stages == 3 ? cut3 : cut2;
+        if (const char *e = getenv("RTMODT_SPLIT")) { static std::string keep; keep = e; cut2[0] = keep.c_str(); }   // experiment hook (2 stages)
+        d->stage_lo[0] = 0;
+        for (int k = 1; k < stages; ++k) {
+            d->stage_lo[k] = -1;
+            for (size_t i = 0; i < d->ops.size(); ++i)
+                if (d->ops[i].name.rfind(cuts[k - 1], 0) == 0) { d->stage_lo[k] = (int)i; break; }
+            if (d->stage_lo[k] <= d->stage_lo[k - 1] + 1) { stages = 1; break; }
+        }
+        d->stage_lo[stages] = (int)d->ops.size();
+    }
+    d->n_stages = stages;
+    d->pipe = stages > 1;
     d->arena_stride = align_up(d->arena_bytes, 4096);
-    RT_HIP(hipMalloc((void **)&d->arena, d->arena_stride * (d->pipe ? 2 : 1)));
-    RT_HIP(hipMemset(d->arena, 0, d->arena_stride * (d->pipe ? 2 : 1)));
+    RT_HIP(hipMalloc((void **)&d->arena, d->arena_stride * d->n_stages));
+    RT_HIP(hipMemset(d->arena, 0, d->arena_stride * d->n_stages));
     auto rebase = [&](TensorView &v) { if (v.base || v.c) v.base = (f16 *)(d->arena + (uintptr_t)v.base); };
     for (auto &t : d->tensors) t.ptr = (f16 *)(d->arena + (uintptr_t)t.ptr);
     for (auto &op : d->ops) {
@@ -1051,8 +1066,8 @@ static int streams_overlap(hipStream_t a, hipStream_t b, hipEvent_t e0, hipEvent
     return RTMODT_OK;
 }
 static int ensure_chain_streams(rtmodt_detector *d) {
-    const int want = d->pipe ? 2 : d->n_chains;            // staged mode: the back stage's stream is found like a chain's
-    if ((int)d->chain_streams.size() >= want || d->back_stream) return RTMODT_OK;
+    const int want = d->pipe ? d->n_stages : d->n_chains;  // staged mode: the later stages' streams are found like a chain's
+    if ((int)d->chain_streams.size() >= want || d->stage_stream[0]) return RTMODT_OK;
     hipEvent_t e0, e1, ej;
     RT_HIP(hipEventCreate(&e0)); RT_HIP(hipEventCreate(&e1)); RT_HIP(hipEventCreateWithFlags(&ej, hipEventDisableTiming));
     if (const char *e = getenv("RTMODT_PAD_STREAMS"))      // test hook: streams created ahead of ours shift the queue mapping
@@ -1071,7 +1086,9 @@ static int ensure_chain_streams(rtmodt_detector *d) {
                 if (pe && atoi(pe) == 0) { st = cand; break; }
                 std::vector<hipStream_t> others = d->chain_streams;
                 others.push_back(d->post_stream);
-                others.push_back(d->copy_stream);            // its event waits would hold up a chain that shared its queue
+                // the copy stream's event waits would hold up a chain that shared its queue; only the third stage of the staged
+                // engine may (main, two more stages and post-processing are all four queues this runtime gives a process)
+                if (!(d->pipe && d->chain_streams.size() == 2)) others.push_back(d->copy_stream);
                 for (hipStream_t o : others) {
                     bool ov = false; float ms = 0;
                     rc = streams_overlap(o, cand, e0, e1, ej, ov, ms);
@@ -1091,9 +1108,14 @@ static int ensure_chain_streams(rtmodt_detector *d) {
     for (hipStream_t st : rejected) hipStreamDestroy(st);
     hipEventDestroy(e0); hipEventDestroy(e1); hipEventDestroy(ej);
     RT_TRY(rc);
-    if (d->pipe) {
-        if (d->chain_streams.size() == 2) { d->back_stream = d->chain_streams[1]; hipEventDestroy(d->chain_fork[1]); hipEventDestroy(d->chain_join[1]); }
-        else d->pipe = false;                              // no queue to spare: plain single-chain engine (the second arena copy stays unused)
+    if (d->pipe) {                                         // fewer stages when fewer queues: 3 -> 2 needs new boundaries, so -> plain
+        if ((int)d->chain_streams.size() == d->n_stages) {
+            for (int k = 0; k < d->n_stages; ++k) d->stage_stream[k] = d->chain_streams[k];
+        } else {
+            for (size_t k = 1; k < d->chain_streams.size(); ++k) hipStreamDestroy(d->chain_streams[k]);
+            d->pipe = false; d->n_stages = 1;              // (the extra arena copies stay unused)
+        }
+        for (size_t k = 1; k < d->chain_fork.size(); ++k) { hipEventDestroy(d->chain_fork[k]); hipEventDestroy(d->chain_join[k]); }
         d->chain_streams.resize(1); d->chain_fork.resize(1); d->chain_join.resize(1);
         return RTMODT_OK;
     }
@@ -1109,17 +1131,16 @@ static int ensure_chain_streams(rtmodt_detector *d) {
 
 // staged mode: per arena copy, one graph for the front stage (captured on the main stream) and one for the back stage
 static int capture_pipe(rtmodt_detector *d) {
-    for (int par = 0; par < 2; ++par) {
+    for (int par = 0; par < d->n_stages; ++par) {
         d->par_ops[par].clear();
         for (auto &op : d->chain_ops[0]) d->par_ops[par].push_back(shift_arena(op, par * d->arena_stride));
-        for (int stage = 0; stage < 2; ++stage) {
+        for (int stage = 0; stage < d->n_stages; ++stage) {
             for (int k = 0; k < 2; ++k) if (d->pipe_exec[par][stage][k]) { hipGraphExecDestroy(d->pipe_exec[par][stage][k]); d->pipe_exec[par][stage][k] = nullptr; }
             if (d->pipe_graph[par][stage]) hipGraphDestroy(d->pipe_graph[par][stage]);
-            hipStream_t st = stage == 0 ? d->stream : d->back_stream;
-            const size_t lo = stage == 0 ? 0 : (size_t)d->split_op, hi = stage == 0 ? (size_t)d->split_op : d->par_ops[par].size();
+            hipStream_t st = d->stage_stream[stage];
             RT_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed));
             int rc = RTMODT_OK;
-            for (size_t i = lo; i < hi && rc == RTMODT_OK; ++i)
+            for (int i = d->stage_lo[stage]; i < d->stage_lo[stage + 1] && rc == RTMODT_OK; ++i)
                 if (d->par_ops[par][i].kind != OP_STEM) rc = run_op_on(d->par_ops[par][i], st);      // the stem is launched by enqueue_batch (fresh frame pointers)
             hipError_t e = hipStreamEndCapture(st, &d->pipe_graph[par][stage]);
             RT_TRY(rc);
@@ -1265,12 +1286,12 @@ void rtmodt_detector_destroy(rtmodt_detector *d) {
     hipDeviceSynchronize();
     for (auto g : d->graph_execs) if (g) hipGraphExecDestroy(g);
     for (auto g : d->graphs) if (g) hipGraphDestroy(g);
-    for (int par = 0; par < 2; ++par)
-        for (int st = 0; st < 2; ++st) {
+    for (int par = 0; par < rtmodt_detector::MAX_STAGES; ++par)
+        for (int st = 0; st < rtmodt_detector::MAX_STAGES; ++st) {
             for (int k = 0; k < 2; ++k) if (d->pipe_exec[par][st][k]) hipGraphExecDestroy(d->pipe_exec[par][st][k]);
             if (d->pipe_graph[par][st]) hipGraphDestroy(d->pipe_graph[par][st]);
         }
-    if (d->back_stream) hipStreamDestroy(d->back_stream);
+    for (int k = 1; k < rtmodt_detector::MAX_STAGES; ++k) if (d->stage_stream[k]) hipStreamDestroy(d->stage_stream[k]);
     for (auto &dn : d->dense) { hipFree(dn.box); hipFree(dn.score); hipFree(dn.cls); }
     for (size_t c = 1; c < d->chain_streams.size(); ++c) hipStreamDestroy(d->chain_streams[c]);
     for (auto e : d->chain_fork) hipEventDestroy(e);
@@ -1289,7 +1310,7 @@ void rtmodt_detector_destroy(rtmodt_detector *d) {
         hipHostFree(sl.h_xyxy); hipHostFree(sl.h_conf); hipHostFree(sl.h_cls); hipHostFree(sl.h_n);
         for (hipEvent_t e : {sl.ev0, sl.evp, sl.ev1, sl.ev2, sl.done, sl.decoded, sl.copied}) if (e) hipEventDestroy(e);
         for (hipEvent_t e : sl.chain_done) if (e) hipEventDestroy(e);
-        if (sl.front_done) hipEventDestroy(sl.front_done);
+        for (hipEvent_t e : sl.stage_done) if (e) hipEventDestroy(e);
     }
     if (d->stream) hipStreamDestroy(d->stream);
     delete d;
@@ -1360,7 +1381,7 @@ static int detector_create_impl(const rtmodt_det_cfg *cfg, rtmodt_detector *d) {
         RT_HIP(hipEventCreateWithFlags(&sl.copied, hipEventDisableTiming));
         sl.chain_done.assign(d->n_chains, nullptr);
         for (int c = 1; c < d->n_chains; ++c) RT_HIP(hipEventCreate(&sl.chain_done[c]));
-        RT_HIP(hipEventCreateWithFlags(&sl.front_done, hipEventDisableTiming));
+        for (auto &e : sl.stage_done) RT_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     }
 
     {   // c / 255 in fp16 exactly as the letterbox kernel computes it (IEEE float division, then round to half)
@@ -1453,33 +1474,36 @@ int rtmodt_detector_enqueue_batch(rtmodt_detector *d, const uint8_t *const *fram
                 for (int c = 1; c < d->n_chains; ++c) RT_HIP(hipStreamWaitEvent(d->stream, d->slots[k].chain_done[c], 0));
                 d->slots[k].joined = true;
             }
-    if (graphs && d->pipe && d->batch_no >= 2) {           // this arena copy was last read by the back stage of batch t - 2
-        const rtmodt_detector::Slot &old = d->slots[(d->head + rtmodt_detector::RING_SLOTS - 2) % rtmodt_detector::RING_SLOTS];
+    if (graphs && d->pipe && d->batch_no >= (uint64_t)d->n_stages) {   // this arena copy was last read by the last stage of batch t - S
+        const rtmodt_detector::Slot &old = d->slots[(d->head + rtmodt_detector::RING_SLOTS - d->n_stages) % rtmodt_detector::RING_SLOTS];
         RT_HIP(hipStreamWaitEvent(d->stream, old.ev1, 0));
     }
     RT_HIP(hipEventRecord(sl.ev0, d->stream));
     if (!d->last_fused) {
-        if (graphs && d->pipe) img.base = (f16 *)((char *)img.base + (size_t)(d->batch_no & 1) * d->arena_stride);
+        if (graphs && d->pipe) img.base = (f16 *)((char *)img.base + (size_t)(d->batch_no % d->n_stages) * d->arena_stride);
         RT_TRY(launch_letterbox(d->fptrs, stride_bytes, lg, d->tabs, img, d->B, d->stream));
         if (chained) RT_HIP(hipEventRecord(sl.evp, d->stream));
     }
     sl.chained = chained; sl.joined = false;
     d->run_par = 0;
     if (graphs && d->pipe) {
-        const int par = (int)(d->batch_no & 1), inst = (int)((d->batch_no >> 1) & 1);
+        const int S = d->n_stages, par = (int)(d->batch_no % S), inst = (int)((d->batch_no / S) & 1);
         d->run_par = par;
         const Op &stem = d->par_ops[par][0];
         if (d->last_fused) RT_TRY(launch_stem_fused(d->fptrs, 0, d->last_pitch, d->last_lg, d->in_h, d->in_w, d->lut255, stem.v[1], stem.stem_w, stem.stem_b,
                                                     d->B, stem.v[1].c, d->stream));
         else RT_TRY(run_op_on(stem, d->stream));
         RT_HIP(hipEventRecord(sl.evp, d->stream));
-        RT_HIP(hipGraphLaunch(d->pipe_exec[par][0][inst], d->stream));
-        RT_HIP(hipEventRecord(sl.front_done, d->stream));
-        RT_HIP(hipStreamWaitEvent(d->back_stream, sl.front_done, 0));
-        RT_HIP(hipGraphLaunch(d->pipe_exec[par][1][inst], d->back_stream));
-        RT_TRY(run_decode_sub(d, 0, d->B, d->back_stream));
-        RT_HIP(hipEventRecord(sl.ev1, d->back_stream));
-        RT_HIP(hipEventRecord(sl.decoded, d->back_stream));
+        for (int k = 0; k < S; ++k) {
+            hipStream_t st = d->stage_stream[k];
+            if (k > 0) RT_HIP(hipStreamWaitEvent(st, sl.stage_done[k - 1], 0));
+            RT_HIP(hipGraphLaunch(d->pipe_exec[par][k][inst], st));
+            if (k + 1 < S) RT_HIP(hipEventRecord(sl.stage_done[k], st));
+        }
+        hipStream_t last = d->stage_stream[S - 1];
+        RT_TRY(run_decode_sub(d, 0, d->B, last));
+        RT_HIP(hipEventRecord(sl.ev1, last));
+        RT_HIP(hipEventRecord(sl.decoded, last));
     } else if (chained) {
         sl.joined = !d->last_fused || !d->chain_free_run;
         RT_TRY(forward_chains(d, sl, mem_kind == RTMODT_MEM_HOST, sl.joined));
@@ -1565,7 +1589,7 @@ int rtmodt_detector_info(rtmodt_detector *d, int32_t *scale_id, int32_t *nc, int
 // dense copy of a channel-slice view of image `img`
 int rtmodt_detector_stages(rtmodt_detector *d, int32_t *n_stages) {
     RT_CHECK(d && n_stages, RTMODT_E_INVALID, "null argument");
-    *n_stages = d->pipe ? 2 : 1;
+    *n_stages = d->pipe ? d->n_stages : 1;
     return RTMODT_OK;
 }
 

@@ -762,9 +762,10 @@ def test_staged_pipeline_matches_single_stream_engine(pkg, wdir, monkeypatch, sr
 
     def run(chains):
         det, wts = make_detector(pkg, wdir, "s", 320, batch=B, autotune=False, confidence=0.02, chains=chains)
-        assert det.model.stages == (2 if chains == -1 else 1) and det.model.chains == 1
+        want = 1 - chains if chains < 0 else 1
+        assert det.model.chains == 1 and (det.model.stages == want or (want == 3 and det.model.stages == 1)), det.model.stages   # 3 stages need every queue of the process
         outs = []
-        depth = 3 if chains == -1 else 2                                 # batches in flight: the staged engine is run three deep
+        depth = det.model.stages + 1 if det.model.stages > 1 else 2      # batches in flight: S stages are run S + 1 deep
         for t in range(steps):
             if host:
                 det.enqueue(list(frames[t]))
@@ -774,7 +775,7 @@ def test_staged_pipeline_matches_single_stream_engine(pkg, wdir, monkeypatch, sr
                 outs.append(det.fetch())
         for _ in range(depth - 1):
             outs.append(det.fetch())
-        if chains == -1 and src_hw == (320, 320):                       # 5 batches: the newest ran in arena copy 0; one more -> copy 1
+        if chains < 0 and src_hw == (320, 320):                         # 5 batches so far; the sixth runs in arena copy 5 % S (1 or 2)
             if host:
                 det.enqueue(list(frames[0]))
             else:
@@ -790,12 +791,14 @@ def test_staged_pipeline_matches_single_stream_engine(pkg, wdir, monkeypatch, sr
         det.close()
         return outs
 
-    ref, got = run(1), run(-1)
+    ref = run(1)
     assert sum(len(d) for batch in ref for d in batch) > 0
-    for t in range(steps):
-        for i in range(B):
-            a, b = got[t][i], ref[t][i]
-            assert np.array_equal(a.xyxy.view(np.int32), b.xyxy.view(np.int32)) and np.array_equal(a.class_id, b.class_id) and \
-                np.array_equal(a.confidence.view(np.int32), b.confidence.view(np.int32)), (t, i)
+    for chains in (-1, -2):
+        got = run(chains)
+        for t in range(steps):
+            for i in range(B):
+                a, b = got[t][i], ref[t][i]
+                assert np.array_equal(a.xyxy.view(np.int32), b.xyxy.view(np.int32)) and np.array_equal(a.class_id, b.class_id) and \
+                    np.array_equal(a.confidence.view(np.int32), b.confidence.view(np.int32)), (chains, t, i)
     if buf is not None:
         buf.free()

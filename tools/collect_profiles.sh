@@ -34,6 +34,7 @@ python tools/profile_layers.py > $O/layers.txt 2> /dev/null
 RTMODT_CHAINS=1 python tools/profile_layers.py > $O/layers_chains1.txt 2> /dev/null
 RTMODT_CHAINS=1 $B --steps 300 --warmup 30 > $O/bench_chains1.json 2> /dev/null
 RTMODT_CHAINS=2 $B --steps 300 --warmup 30 > $O/bench_chains2.json 2> /dev/null
+$B --steps 300 --warmup 30 --stages 2 > $O/bench_stages2.json 2> /dev/null
 $B --steps 300 --warmup 30 --frames-per-stream 1 > $O/bench_frames1.json 2> /dev/null
 $B --steps 200 --warmup 20 --frames-per-stream 4 > $O/bench_frames4.json 2> /dev/null
 $B --steps 300 --warmup 30 --streams 16 --frames-per-stream 1 > $O/bench_streams16.json 2> /dev/null
