@@ -193,7 +193,7 @@ struct rtmodt_detector {
     bool pipe = false;
     size_t arena_stride = 0;                          // bytes between the two arena copies
     static constexpr int MAX_STAGES = 3;
-    int n_stages = 1;                                 // 2: backbone | neck + Detect; 3: layers 0-6.cv1 | 6.m-15 | 16-22
+    int n_stages = 1;                                 // 2: backbone | neck + Detect; 3: layers 0-6.m.0 | 6.m.1-15 | 16-22
     int stage_lo[MAX_STAGES + 1] = {0, 0, 0, 0};      // stage s runs ops [stage_lo[s], stage_lo[s + 1])
     int run_par = 0, last_par = 0;                    // arena copy the launches being issued use / the newest batch used
     std::vector<Op> par_ops[MAX_STAGES];              // d->ops shifted into each arena copy (one copy per stage)
@@ -637,10 +637,15 @@ static int build_graph(rtmodt_detector *d, WeightFile &wf) {
     if (const char *e = getenv("RTMODT_PIPE")) stages = atoi(e) != 0 ? 2 : 1;
     if (const char *e = getenv("RTMODT_STAGES")) stages = atoi(e);
     stages = d->cfg.use_graph ? std::max(1, std::min(stages, (int)rtmodt_detector::MAX_STAGES)) : 1;
-    {   // stage boundaries by layer name: 2 stages cut after SPPF (52 % / 48 % of the kernel time), 3 stages at 32 % / 66 %
-        const char *cut2[] = {"12."}, *cut3[] = {"6.m", "16"};
+    {   // stage boundaries by layer name: 2 stages cut after SPPF (52 % / 48 % of the kernel time), 3 stages at 35 % / 66 %
+        const char *cut2[] = {"12."}, *cut3[] = {"6.m.1", "16"};      // (sweeps of both sets of cuts on s @ 640: these, within 1 %)
         const char **cuts = stages == 3 ? cut3 : cut2;
-        if (const char *e = getenv("RTMODT_SPLIT")) { static std::string keep; keep = e; cut2[0] = keep.c_str(); }   // experiment hook (2 stages)
+        static std::string keep[2];                        // experiment hooks: RTMODT_SPLIT=<layer> (2 stages), RTMODT_SPLIT3=<layer>,<layer>
+        if (const char *e = getenv("RTMODT_SPLIT")) { keep[0] = e; cut2[0] = keep[0].c_str(); }
+        if (const char *e = getenv("RTMODT_SPLIT3")) {
+            const std::string v = e; const size_t c = v.find(',');
+            if (c != std::string::npos) { keep[0] = v.substr(0, c); keep[1] = v.substr(c + 1); cut3[0] = keep[0].c_str(); cut3[1] = keep[1].c_str(); }
+        }
         d->stage_lo[0] = 0;
         for (int k = 1; k < stages; ++k) {
             d->stage_lo[k] = -1;
