@@ -71,7 +71,13 @@ class _NativeModel:
 
 
 class Detector:
-    """YOLOv8 detector on the native gfx950 engine (reference: detector.py:54-135)."""
+    """YOLOv8 detector on the native gfx950 engine (reference: detector.py:54-135).
+
+    Keyword-only extensions (no reference counterpart): ``batch`` frames per launch set (streams batched per GPU);
+    ``chains`` picks the engine (``rtmodt_det_cfg.chains``): 0 automatic (two stages for ``batch >= 2``, the plain
+    engine for ``batch == 1``), 1 plain, n > 1 sub-batch chains, -1 / -2 the staged engine with two / three stages
+    (keep stages + 1 batches in flight through :meth:`enqueue` / :meth:`fetch`; three stages only when the frames are
+    already in device memory); ``rect`` the minimal-rectangle letterbox of ``predict`` on a ``.pt`` model."""
 
     _WARMUP_ITERATIONS = 10
 
@@ -162,7 +168,7 @@ class Detector:
             _ffi.check(L.rtmodt_detector_chains(h, C.byref(nch)))
             m.chains = nch.value             # sub-batch chains the batch runs as (own streams, joined by the post-processing stream)
             _ffi.check(L.rtmodt_detector_stages(h, C.byref(nch)))
-            m.stages = nch.value             # 2: staged mode (chains=-1), front and back half of the net on two streams
+            m.stages = nch.value             # 2 / 3: staged engine (chains=-1 / -2), the stages of the net on their own streams
             self._models[(in_h, in_w)] = m
         return m
 

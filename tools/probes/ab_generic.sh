@@ -4,5 +4,4 @@ run() { label=$1; shift
   python -c "import json; d=json.loads(open('gpurun_out/ab_$label.json').read().strip().splitlines()[-1]); print('$label', d['value'], d['ms_per_step'], d['roofline']['achieved'], d['roofline']['chains'], d['roofline'].get('stages'))"
 }
 EXTRA=""
-export RTMODT_TUNE_CACHE=/tmp/tc.txt
-run base A=1 && run p1 RTMODT_STAGE_PRIO=1 && run p2 RTMODT_STAGE_PRIO=2 && run base2 A=1 && run p1b RTMODT_STAGE_PRIO=1 || exit 1
+run base A=1 && run bneck0 RTMODT_BNECK=0 && run nobt RTMODT_NO_BNECK_TAIL=1 && run tail0 RTMODT_TAIL=0 && run nohf RTMODT_NO_HEAD_FINAL=1 && run stem0 RTMODT_STEM_FUSE=0 && run base2 A=1 || exit 1
