@@ -5,9 +5,8 @@ run() { label=$1; shift
 }
 EXTRA=""
 export RTMODT_TUNE_CACHE=/tmp/tc.txt
-run base RTMODT_POST_PRIO=0 && run prio RTMODT_POST_PRIO=1 RTMODT_TUNE_LOG=1 && run base2 RTMODT_POST_PRIO=0 && run prio2 RTMODT_POST_PRIO=1 || exit 1
-grep streams gpurun_out/ab_prio.err | tail -8
+run base A=1 && run lop RTMODT_LAST_ON_POST=1 && run base2 A=1 && run lop2 RTMODT_LAST_ON_POST=1 || exit 1
 EXTRA="--host-frames --stages 3"
-run hbase RTMODT_POST_PRIO=0 && run hprio RTMODT_POST_PRIO=1 || exit 1
+run hlop RTMODT_LAST_ON_POST=1 || exit 1
 EXTRA="--host-frames --stages 2"
-run h2base RTMODT_POST_PRIO=0 && run h2prio RTMODT_POST_PRIO=1 || exit 1
+run h2 A=1 || exit 1
