@@ -800,12 +800,13 @@ static int forward_eager_all(rtmodt_detector *d) {
 // best of a few launches) and keeps the fastest: the GEMM shapes of this net are small and
 // skinny, so the best tile depends on how M x N fills 256 CUs, not on a rule.
 // best-of-3 time (ms per launch) of `launch` issued 4 times back to back on the detector's stream
-// best-of-3 time (ms per launch) of `launch` issued 4 times back to back on the detector's stream
+// best-of-5 time (ms per launch) of `launch` issued 4 times back to back on the detector's stream (with 3 repetitions
+// near-ties between tiles flipped from run to run and the bench moved by +-1 %)
 template <typename F>
 static int time_launch(rtmodt_detector *d, hipEvent_t e0, hipEvent_t e1, F &&launch, float &ms_out) {
     for (int w = 0; w < 2; ++w) RT_TRY(launch());
     float ms_min = 1e30f;
-    for (int rep = 0; rep < 3; ++rep) {
+    for (int rep = 0; rep < 5; ++rep) {
         RT_HIP(hipEventRecord(e0, d->stream));
         for (int k = 0; k < 4; ++k) RT_TRY(launch());
         RT_HIP(hipEventRecord(e1, d->stream));
