@@ -52,6 +52,8 @@ struct ConvArgs {
     f16 *out2;                           // optional second destination: nearest-2x upsampled copy (neck concat slice)
     int out2_Hp, out2_Wp, out2_cs, out2_pad;
     int cin, cout, ks, stride, act, kp, K;
+    const f16 *in2;                      // optional half-resolution source of channels [0, split) (nearest-2x on the fly), 1x1 only
+    int in2_Hp, in2_Wp, in2_cs, in2_pad, split;
     // optional fused TAIL: a 1x1 conv (+bias +SiLU) applied to this conv's output tile while it sits in LDS; only the
     // tail's output is stored (the tile kernels with BN == cout, TAIL instantiations)
     const f16 *t_wt; const float *t_bias; f16 *t_out;
@@ -168,6 +170,15 @@ __device__ __forceinline__ bool pixel_offsets(const ConvArgs &p, int m, long &op
     rpix = p.res ? ((long)(b * p.res_Hp + oy + p.res_pad) * p.res_Wp + ox + p.res_pad) * p.res_cs : 0;
     opix2 = upsampled_offset(p, b, oy, ox);
     return true;
+}
+
+// the same pixel in the half-resolution source (1x1 stride-1 convs only)
+__device__ __forceinline__ int input_offset_lo(const ConvArgs &p, int m) {
+    m = m < p.M ? m : p.M - 1;
+    const int HoWo = p.Ho * p.Wo;
+    int b = m / HoWo, rem = m - b * HoWo;
+    int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+    return ((b * p.in2_Hp + (oy >> 1) + p.in2_pad) * p.in2_Wp + (ox >> 1) + p.in2_pad) * p.in2_cs;
 }
 
 __device__ __forceinline__ int input_offset(const ConvArgs &p, int m) {
@@ -487,11 +498,12 @@ __device__ __forceinline__ void conv_mfma64_body(const ConvArgs &p, const int bx
     const int rd_off0 = rd_base + (((0 + q) ^ ((r >> 1) & 7)) << 4);
     const int rd_off1 = rd_base + (((4 + q) ^ ((r >> 1) & 7)) << 4);
 
-    int a_off[LA], b_off[LBp];
+    int a_off[LA], a_lo[LA], b_off[LBp];
 #pragma unroll
     for (int i = 0; i < LA; ++i) {
         int row = (wave + NW * i) * 8 + ld_row8;             // row inside the BM tile
         a_off[i] = input_offset(p, m0 + row) + ((ld_slot ^ ((row >> 1) & 7)) << 3);
+        a_lo[i] = p.in2 ? input_offset_lo(p, m0 + row) + ((ld_slot ^ ((row >> 1) & 7)) << 3) : 0;
     }
 #pragma unroll
     for (int i = 0; i < LBp; ++i) {
@@ -510,8 +522,13 @@ __device__ __forceinline__ void conv_mfma64_body(const ConvArgs &p, const int bx
     auto issue = [&](int kt, int stage) {
         unsigned char *sbase = lds + stage * STAGE;
         const int tap_off = (kh * p.in_Wp + kw) * p.in_cs + c0;
+        if (p.in2 && c0 < p.split) {                       // the upsampled half of a neck concat, read where it was produced
 #pragma unroll
-        for (int i = 0; i < LA; ++i) glds16(p.in + (a_off[i] + tap_off), sbase + (wave + NW * i) * 1024);
+            for (int i = 0; i < LA; ++i) glds16(p.in2 + (a_lo[i] + c0), sbase + (wave + NW * i) * 1024);
+        } else {
+#pragma unroll
+            for (int i = 0; i < LA; ++i) glds16(p.in + (a_off[i] + tap_off), sbase + (wave + NW * i) * 1024);
+        }
 #pragma unroll
         for (int i = 0; i < LBp; ++i) glds16(p.wt + (b_off[i] + kt * 64), sbase + (NA + wave + NW * i) * 1024);
         c0 += 64;
@@ -912,6 +929,8 @@ bool tile_needs_cin64(int tile) {
            tile == TILE_ROWS_K64_128x128_W8 || tile == TILE_ROWS_K64_256x64_W8;
 }
 bool tile_is_tail(int tile) { return tile >= TILE_TAIL_128x64 && tile <= TILE_TAIL_K64_64x128; }
+// the 64-deep tile kernels (conv_mfma64_body) know how to read channels [0, lo_c) from a half-resolution tensor
+bool tile_reads_lo(int tile) { return (tile >= TILE_K64_128x128_S2 && tile <= TILE_K64_128x128_S2W) || (tile >= TILE_K64_128x128_S2_W8 && tile <= TILE_K64_256x64_S2_W8); }
 bool tile_is_rows(int tile) { return (tile >= TILE_ROWS_128x64 && tile <= TILE_ROWS_K64_256x64) || (tile >= TILE_ROWS_128x64_W8 && tile <= TILE_ROWS_K64_256x64_W8); }
 
 TileShape tile_shape(int tile) {
@@ -1045,7 +1064,7 @@ static void launch_wsk(const LaunchPlan &l, hipStream_t s) {
 static int make_args(const ConvLaunch &c, ConvArgs &a) {
     RT_CHECK(c.in.base && c.out.base && c.wt && c.bias, RTMODT_E_INVALID, "launch_conv: null operand");
     // a view that still holds an arena OFFSET instead of a device address (engine.hip rebases them once) must never reach a kernel
-    for (const TensorView *v : {&c.in, &c.out, &c.res, &c.out2, &c.tail_out})
+    for (const TensorView *v : {&c.in, &c.out, &c.res, &c.out2, &c.tail_out, &c.in_lo})
         RT_CHECK(!v->base || (uintptr_t)v->base >= (1ull << 32), RTMODT_E_INVALID, "launch_conv: view base %p is not a device address", (void *)v->base);
     RT_CHECK(c.ks == 1 || c.ks == 3, RTMODT_E_INVALID, "launch_conv: kernel size %d", c.ks);
     RT_CHECK(c.cin % 8 == 0 && c.cout % 4 == 0, RTMODT_E_INVALID, "launch_conv: cin %d / cout %d granularity", c.cin, c.cout);
@@ -1075,6 +1094,16 @@ static int make_args(const ConvLaunch &c, ConvArgs &a) {
         a.out2 = c.out2.base + c.out2.coff;
         a.out2_Hp = c.out2.H + 2 * c.out2.pad; a.out2_Wp = c.out2.W + 2 * c.out2.pad; a.out2_cs = c.out2.C; a.out2_pad = c.out2.pad;
     }
+    a.in2 = nullptr; a.in2_Hp = a.in2_Wp = a.in2_cs = a.in2_pad = a.split = 0;
+    if (c.in_lo.base) {
+        RT_CHECK(c.ks == 1 && c.stride == 1 && c.in_lo.H * 2 == c.in.H && c.in_lo.W * 2 == c.in.W && c.in_lo.c == c.lo_c && c.lo_c % 64 == 0 && c.lo_c > 0 &&
+                     c.lo_c < c.cin && c.cin % 64 == 0 && c.in_lo.coff % 8 == 0 && c.in_lo.C % 8 == 0,
+                 RTMODT_E_INVALID, "launch_conv: half-resolution source shape");
+        RT_CHECK((long)c.B * (c.in_lo.H + 2 * c.in_lo.pad) * (c.in_lo.W + 2 * c.in_lo.pad) * c.in_lo.C < (1L << 31), RTMODT_E_INVALID, "launch_conv: tensor exceeds 2^31 elements");
+        a.in2 = c.in_lo.base + c.in_lo.coff;
+        a.in2_Hp = c.in_lo.H + 2 * c.in_lo.pad; a.in2_Wp = c.in_lo.W + 2 * c.in_lo.pad; a.in2_cs = c.in_lo.C; a.in2_pad = c.in_lo.pad;
+        a.split = c.lo_c;
+    }
     a.M = c.B * a.Ho * a.Wo;
     a.cin = c.cin; a.cout = c.cout; a.ks = c.ks; a.stride = c.stride; a.act = c.act;
     a.K = c.ks * c.ks * c.cin;
@@ -1102,6 +1131,8 @@ int launch_conv_group(const ConvLaunch *c, int n, int tile, hipStream_t s) {
         if (tile_needs_cin64(tile))
             RT_CHECK(c[i].cin % 64 == 0 && a[i].kp % 64 == 0, RTMODT_E_INVALID, "launch_conv: tile %s needs cin %% 64 == 0 (cin %d)", tile_name(tile), c[i].cin);
     }
+    for (int i = 0; i < n; ++i)
+        RT_CHECK(!c[i].in_lo.base || tile_reads_lo(tile), RTMODT_E_INVALID, "launch_conv: tile %s cannot read a half-resolution source", tile_name(tile));
     if (tile_is_rows(tile)) {
         const int bk = tile_needs_cin64(tile) ? 64 : 32;
         for (int i = 0; i < n; ++i) {

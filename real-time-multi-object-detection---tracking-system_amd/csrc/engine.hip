@@ -307,7 +307,7 @@ static Op sub_batch(const Op &op, int b0, int nb) {
         if (v.c) v.base += (size_t)b0 * (v.H + 2 * v.pad) * (v.W + 2 * v.pad) * v.C;
     };
     o.B = nb;
-    if (o.kind == OP_CONV) { shift(o.conv.in); shift(o.conv.out); shift(o.conv.res); shift(o.conv.out2); shift(o.conv.tail_out); o.conv.B = nb; }
+    if (o.kind == OP_CONV) { shift(o.conv.in); shift(o.conv.out); shift(o.conv.res); shift(o.conv.out2); shift(o.conv.tail_out); shift(o.conv.in_lo); o.conv.B = nb; }
     else if (o.kind == OP_GROUP || o.kind == OP_BNECK) {
         for (auto &c : o.group) { shift(c.in); shift(c.out); shift(c.res); c.B = nb; }
         if (o.kind == OP_BNECK) { shift(o.bneck.in); shift(o.bneck.out); shift(o.bneck.res); shift(o.bneck.tail_in); shift(o.bneck.tail_out); o.bneck.B = nb; }
@@ -320,7 +320,7 @@ static Op sub_batch(const Op &op, int b0, int nb) {
 static Op shift_arena(const Op &op, size_t bytes) {
     Op o = op;
     auto shift = [&](TensorView &v) { if (v.c) v.base = (f16 *)((char *)v.base + bytes); };
-    if (o.kind == OP_CONV) { shift(o.conv.in); shift(o.conv.out); shift(o.conv.res); shift(o.conv.out2); shift(o.conv.tail_out); }
+    if (o.kind == OP_CONV) { shift(o.conv.in); shift(o.conv.out); shift(o.conv.res); shift(o.conv.out2); shift(o.conv.tail_out); shift(o.conv.in_lo); }
     else if (o.kind == OP_GROUP || o.kind == OP_BNECK) {
         for (auto &c : o.group) { shift(c.in); shift(c.out); shift(c.res); }
         if (o.kind == OP_BNECK) { shift(o.bneck.in); shift(o.bneck.out); shift(o.bneck.res); shift(o.bneck.tail_in); shift(o.bneck.tail_out); }
@@ -540,14 +540,32 @@ static int build_graph(rtmodt_detector *d, WeightFile &wf) {
         d->ops.back().skip = false;
         if (d->ops.size() >= 2) { Op &bn = d->ops[d->ops.size() - 2]; if (bn.kind == OP_BNECK) { bn.bneck.tail_wt = nullptr; bn.tail_on = false; } }
     };
-    if (fold_up) fold_into_last(V(cat11, 0, c5));             // layer 10 (Upsample) + 11 (Concat) folded into 9.cv2's epilogue
+    // Upsample + Concat of the neck (layers 10/11 and 13/14), cheapest first: (a) the consumer C2f.cv1 -- a 1x1 -- reads the
+    // upsampled channels straight from the half-resolution tensor (no copy exists at all), (b) the producer's epilogue also
+    // writes the nearest-2x copy into the concat slice, (c) separate upsample launches (RTMODT_NO_UPFOLD)
+    const bool read_lo = fold_up && !(getenv("RTMODT_UP_READ") && atoi(getenv("RTMODT_UP_READ")) == 0);
+    auto read_from_lo = [&](const std::string &cv1, const TensorView &lo, int lo_c) -> bool {
+        for (auto &op : d->ops)
+            if (op.kind == OP_CONV && op.name == cv1 && lo_c % 64 == 0 && op.conv.cin % 64 == 0 && op.conv.kp % 64 == 0 && op.conv.ks == 1) {
+                op.conv.in_lo = lo; op.conv.lo_c = lo_c;
+                if (!tile_reads_lo(op.conv.tile)) op.conv.tile = TILE_K64_128x64_S3;
+                return true;
+            }
+        return false;
+    };
+    const bool lo11 = read_lo && c5 % 64 == 0 && (c5 + c4) % 64 == 0, lo14 = read_lo && c4 % 64 == 0 && (c4 + c3) % 64 == 0;
+    if (lo11) {}                                             // 12.cv1 is pointed at out9 once it exists (below)
+    else if (fold_up) fold_into_last(V(cat11, 0, c5));        // layer 10 (Upsample) + 11 (Concat) folded into 9.cv2's epilogue
     else { Op op; op.kind = OP_UP; op.name = "10.up"; op.v[0] = out9; op.v[1] = V(cat11, 0, c5); d->ops.push_back(op); }
     TensorView out12 = V(cat17, c3, c4);
     c2f("12", V(cat11), c4, rep(3), false, out12);
-    if (fold_up) fold_into_last(V(cat14, 0, c4));             // layer 13 (Upsample) + 14 (Concat) folded into 12.cv2's epilogue
+    if (lo11) RT_CHECK(read_from_lo("12.cv1", out9, c5), RTMODT_E_INVALID, "12.cv1 cannot read the half-resolution source");
+    if (lo14) {}
+    else if (fold_up) fold_into_last(V(cat14, 0, c4));        // layer 13 (Upsample) + 14 (Concat) folded into 12.cv2's epilogue
     else { Op op; op.kind = OP_UP; op.name = "13.up"; op.v[0] = out12; op.v[1] = V(cat14, 0, c4); d->ops.push_back(op); }
     int t15 = T(H / 8, W / 8, c3, 1);
     c2f("15", V(cat14), c3, rep(3), false, V(t15));
+    if (lo14) RT_CHECK(read_from_lo("15.cv1", out12, c4), RTMODT_E_INVALID, "15.cv1 cannot read the half-resolution source");
     conv("16", V(t15), V(cat17, 0, c3));
     int t18 = T(H / 16, W / 16, c4, 1);
     c2f("18", V(cat17), c4, rep(3), false, V(t18));
@@ -668,6 +686,7 @@ static int build_graph(rtmodt_detector *d, WeightFile &wf) {
             if (op.conv.res.c) rebase(op.conv.res);
             if (op.conv.out2.c) rebase(op.conv.out2);
             if (op.conv.tail_out.c) rebase(op.conv.tail_out);
+            if (op.conv.in_lo.c) rebase(op.conv.in_lo);
         } else if (op.kind == OP_GROUP || op.kind == OP_BNECK) {
             for (auto &c : op.group) { rebase(c.in); rebase(c.out); if (c.res.c) rebase(c.res); }
             if (op.kind == OP_BNECK) {
@@ -833,6 +852,7 @@ static int tune_conv(rtmodt_detector *d, hipEvent_t e0, hipEvent_t e1, const std
         if (tile_needs_cin64(t) && !cin64) continue;
         if (tile_is_rows(t) && !rows_ok) continue;
         if (tile_is_tail(t)) continue;                     // only through tune_tails()
+        if (c[0].in_lo.base && !tile_reads_lo(t)) continue;
         if (t >= TILE_K64_128x128_S2_W8 && t <= TILE_K64_256x64_S2_W8 && n != 1) continue;   // the 8-wave tiles have no group entry point
         float ms;
         RT_TRY(time_launch(d, e0, e1, [&]() { return launch_conv_group(c, n, t, d->stream); }, ms));
@@ -877,6 +897,7 @@ static int autotune_ops(rtmodt_detector *d, std::vector<Op> &ops) {
         if (op.kind != OP_CONV && op.kind != OP_GROUP && op.kind != OP_BNECK) continue;
         const std::string key = tune_key(d, op);
         auto hit = cache.find(key);
+        if (hit != cache.end() && op.kind == OP_CONV && op.conv.in_lo.base && !tile_reads_lo(hit->second.t0)) hit = cache.end();   // (a cache from before this conv read a half-resolution source)
         if (hit != cache.end()) {
             const TuneRec &r = hit->second;
             if (op.kind == OP_CONV) { op.conv.tile = r.t0; if (op.conv.tail_wt) { op.tail_tile = r.t1; op.tail_on = r.fused != 0; } }

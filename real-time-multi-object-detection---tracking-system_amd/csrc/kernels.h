@@ -38,12 +38,16 @@ const char *tile_name(int tile);
 bool tile_needs_cin64(int tile);
 bool tile_is_rows(int tile);      // 3x3 stride-1 only, bordered input
 bool tile_is_tail(int tile);      // runs ConvLaunch::tail_* as well; needs cout == the tile's BN
+bool tile_reads_lo(int tile);     // can serve ConvLaunch::in_lo
 struct TileShape { int bm, bn; };
 TileShape tile_shape(int tile);
 
 struct ConvLaunch {
     TensorView in, out, res;      // res.base == nullptr -> no residual
     TensorView out2;              // optional: the output is ALSO written nearest-2x upsampled into this slice
+    // optional (1x1 stride-1 only, 64-deep tiles): channels [0, lo_c) of the input are read from this HALF-resolution tensor,
+    // nearest-2x upsampled on the fly (Upsample + Concat of the neck without the upsampled copy); `in` covers [lo_c, cin)
+    TensorView in_lo; int lo_c = 0;
     const f16 *wt = nullptr;      // [cout_pad][kp] fp16, K order (kh, kw, cin), zero padded
     const float *bias = nullptr;  // [cout_pad]
     int B = 1;
