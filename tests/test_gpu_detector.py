@@ -802,3 +802,34 @@ def test_staged_pipeline_matches_single_stream_engine(pkg, wdir, monkeypatch, sr
                     np.array_equal(a.confidence.view(np.int32), b.confidence.view(np.int32)), (chains, t, i)
     if buf is not None:
         buf.free()
+
+
+@pytest.mark.parametrize("size,batch", [(320, 2), (288, 1)])
+def test_neck_concat_read_from_half_resolution(pkg, wdir, monkeypatch, size, batch):
+    """Neck Upsample + Concat (layers 10/11, 13/14): by default C2f.cv1 of layers 12 and 15 reads the upsampled channels
+    straight from the half-resolution producer (ConvLaunch::in_lo) and no upsampled copy is written; with
+    RTMODT_UP_READ=0 the producer's epilogue writes the copy into the concat slice.  On a common 64-deep tile the two
+    give bit-identical layers, and both match the oracle (odd map sizes at 288: 9 -> 18 -> 36)."""
+    monkeypatch.setenv("RTMODT_TILE", "2")
+    monkeypatch.setenv("RTMODT_TILE_K64", "15")
+    monkeypatch.setenv("RTMODT_BNECK", "0")
+    frames = list(pkg.synth.frames(batch, size, size, seed=57))
+    names = [c.name for c in pkg.weights.spec("s")]
+    outs = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("RTMODT_UP_READ", mode)
+        det, w = make_detector(pkg, wdir, "s", size, autotune=False, batch=batch)
+        det.detect_batch(frames)
+        outs[mode] = []
+        for img in range(batch):
+            inp, _, _ = det.debug_fetch(img, want_heads=False, want_pred=False)
+            gpu = fetch_layers(pkg, det, names, img)
+            outs[mode].append(gpu)
+            taps = {}
+            Y.forward(inp.astype(np.float32), w, "s", taps=taps, force=gpu)
+            for n in ("12.cv1", "15.cv1", "12.cv2", "9.cv2"):
+                assert float(np.abs(taps[n] - gpu[n]).max()) <= 2e-3 * np.abs(taps[n]).max() + 2e-3, (mode, img, n)
+        det.close()
+    for img in range(batch):
+        for n in outs["1"][img]:
+            assert np.array_equal(outs["0"][img][n], outs["1"][img][n]), (img, n)
