@@ -220,6 +220,7 @@ struct rtmodt_detector {
     // t+1 runs under the forward pass of batch t when the caller's frames are in pinned memory
     uint8_t *stage = nullptr; size_t stage_per = 0;      // [RING_SLOTS][B][stage_per]
     hipStream_t copy_stream = nullptr;
+    int h2d_mode = 0;                                 // RTMODT_H2D: 0 = stream-ordered upload (events), 1 = host-synchronised upload (no events)
     FramePtrs fptrs{};
     // letterbox folded into the stem conv whenever the frames need no resize (conv.hip: stem_fused); the stem is
     // launched by enqueue_batch itself, never from the captured graph (its frame pointers change every batch)
@@ -1371,6 +1372,7 @@ static int detector_create_impl(const rtmodt_det_cfg *cfg, rtmodt_detector *d) {
     RT_HIP(hipStreamCreateWithFlags(&d->copy_stream, hipStreamNonBlocking));
     RT_HIP(hipMalloc((void **)&d->d_zeros, 256));
     RT_HIP(hipMemset(d->d_zeros, 0, 256));
+    if (const char *e = getenv("RTMODT_H2D")) d->h2d_mode = atoi(e);
     RT_TRY(build_graph(d, wf));
     RT_TRY(ensure_chain_streams(d));                       // may fall back to one chain: before anything is sized by n_chains
 
@@ -1454,21 +1456,37 @@ int rtmodt_detector_enqueue_batch(rtmodt_detector *d, const uint8_t *const *fram
         RT_CHECK((size_t)h * stride_bytes <= d->stage_per, RTMODT_E_CAPACITY, "frame %dx%d exceeds max_src %dx%d", w, h, d->cfg.max_src_w,
                  d->cfg.max_src_h);
         uint8_t *area = d->stage + d->stage_per * d->B * d->head;
-        // three stages leave the copy stream no hardware queue of its own (it shares the third stage's, and its event waits
-        // then hold that stage up: 12.8 k frames/s): the uploads go through the main stream instead, in front of stage 1
-        const bool on_main = d->pipe && d->n_stages == 3 && !(getenv("RTMODT_COPY_ON_MAIN") && atoi(getenv("RTMODT_COPY_ON_MAIN")) == 0);
-        hipStream_t cs = on_main ? d->stream : d->copy_stream;
-        if (sl.staged && !on_main) {                       // the launches that last read this area are done
-            RT_HIP(hipStreamWaitEvent(d->copy_stream, sl.evp, 0));
-            if (sl.chained) for (int c = 1; c < d->n_chains; ++c) RT_HIP(hipStreamWaitEvent(d->copy_stream, sl.chain_done[c], 0));
-        }
-        for (int i = 0; i < n; ++i) {
-            RT_HIP(hipMemcpyAsync(area + d->stage_per * i, frames[i], (size_t)h * stride_bytes, hipMemcpyHostToDevice, cs));
-            d->fptrs.p[i] = area + d->stage_per * i;
-        }
-        if (!on_main) {
-            RT_HIP(hipEventRecord(sl.copied, d->copy_stream));
-            RT_HIP(hipStreamWaitEvent(d->stream, sl.copied, 0));
+        // frames that sit back to back in the caller's (page-locked) ring slot travel as ONE copy
+        const size_t fbytes = (size_t)h * stride_bytes;
+        bool contig = n > 1;
+        for (int i = 1; i < n && contig; ++i) contig = frames[i] == frames[0] + fbytes * i;
+        const size_t dst_step = contig ? fbytes : d->stage_per;
+        for (int i = 0; i < n; ++i) d->fptrs.p[i] = area + dst_step * i;
+        auto upload_on = [&](hipStream_t cs) -> int {
+            if (contig) RT_HIP(hipMemcpyAsync(area, frames[0], fbytes * n, hipMemcpyHostToDevice, cs));
+            else for (int i = 0; i < n; ++i) RT_HIP(hipMemcpyAsync(area + dst_step * i, frames[i], fbytes, hipMemcpyHostToDevice, cs));
+            return RTMODT_OK;
+        };
+        if (d->h2d_mode == 1) {
+            // host-synchronised upload: the DMA runs on the copy stream with NO event recorded on it and no stream waiting for
+            // it, so no barrier packet of the copy ever sits in a hardware queue that a stage of the net shares; the host waits
+            // for the DMA itself (the S + 1 batches in flight keep the device busy meanwhile).  The staging area of this ring
+            // slot was last read by the stem of a batch that has been fetched.
+            RT_TRY(upload_on(d->copy_stream));
+            RT_HIP(hipStreamSynchronize(d->copy_stream));
+        } else {
+            // three stages leave the copy stream no hardware queue of its own (it shares the third stage's, and its event waits
+            // then hold that stage up: 12.8 k frames/s): the uploads go through the main stream instead, in front of stage 1
+            const bool on_main = d->pipe && d->n_stages == 3 && !(getenv("RTMODT_COPY_ON_MAIN") && atoi(getenv("RTMODT_COPY_ON_MAIN")) == 0);
+            if (sl.staged && !on_main) {                       // the launches that last read this area are done
+                RT_HIP(hipStreamWaitEvent(d->copy_stream, sl.evp, 0));
+                if (sl.chained) for (int c = 1; c < d->n_chains; ++c) RT_HIP(hipStreamWaitEvent(d->copy_stream, sl.chain_done[c], 0));
+            }
+            RT_TRY(upload_on(on_main ? d->stream : d->copy_stream));
+            if (!on_main) {
+                RT_HIP(hipEventRecord(sl.copied, d->copy_stream));
+                RT_HIP(hipStreamWaitEvent(d->stream, sl.copied, 0));
+            }
         }
         sl.staged = true;
     } else {

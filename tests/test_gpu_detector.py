@@ -833,3 +833,82 @@ def test_neck_concat_read_from_half_resolution(pkg, wdir, monkeypatch, size, bat
     for img in range(batch):
         for n in outs["1"][img]:
             assert np.array_equal(outs["0"][img][n], outs["1"][img][n]), (img, n)
+
+
+def test_benchmarked_shape_parity(pkg, wdir):
+    """BASELINE config 4's per-GPU shard exactly as bench.py builds it: YOLOv8s @ 640, batch 16 (8 streams x 2 consecutive
+    frames), autotuned tiles, three-stage engine, S + 1 batches in flight, tracker fed on the device.
+      * every stored layer of images 0 and 15 of the last batch within fp16 tolerance of the fp32 oracle (teacher-forced);
+      * NMS survivors, boxes, scores, classes of all 16 images bit-equal to oracle NMS on the engine's own pre-NMS tensor;
+      * pipelined enqueue/fetch results bit-equal to a synchronous detect_batch of the same frames on the same engine;
+      * the 8 streams' tracker state bit-equal to TrackerOracle fed the fetched detections frame by frame."""
+    from oracle import tracker_oracle as T
+    from importlib import import_module
+    core_cls = import_module(pkg.__name__ + ".tracking.tracker")._ByteTrackCore
+    S, F, steps, size = 8, 2, 6, 640
+    B = S * F
+    det, w = make_detector(pkg, wdir, "s", size, batch=B, autotune=True, chains=-2, max_det=100)
+    assert det.model.stages == 3, "the bench configuration needs all four hardware queues of the process"
+    frames = np.stack([pkg.synth.frames(F * steps, size, size, seed=1234 + s) for s in range(S)], 1).reshape(steps, F, S, size, size, 3)
+    buf = pkg._ffi.DeviceBuffer(frames.nbytes)
+    buf.upload(frames)
+    per = size * size * 3
+    core = core_cls(n_streams=S, max_dets=128, max_tracks=2048)
+    oracles = [T.TrackerOracle() for _ in range(S)]
+    depth = det.model.stages + 1
+    outs = []
+
+    def submit(t):
+        det.enqueue([buf.ptr + ((t * F + f) * S + s) * per for f in range(F) for s in range(S)], height=size, width=size)
+        for f in range(F):
+            core.update_from_detector(det, f * S, S)
+
+    for t in range(steps):
+        submit(t)
+        if t >= depth - 1:
+            outs.append(det.fetch())
+    for _ in range(depth - 1):
+        outs.append(det.fetch())
+    assert len(outs) == steps
+    # tracker: device hand-off == oracle on the fetched detections
+    for t in range(steps):
+        for f in range(F):
+            for s in range(S):
+                d = outs[t][f * S + s]
+                oracles[s].update(d.xyxy, d.confidence, d.class_id)
+    for s in range(S):
+        assert np.array_equal(T.state_digest(core.snapshot(s)), T.state_digest(oracles[s].snapshot())), s
+    assert sum(len(core.snapshot(s)["ids"]) for s in range(S)) > 0
+    # the newest batch is still resident: pre-NMS tensor -> oracle NMS, all 16 images
+    last = outs[-1]
+    for i in range(B):
+        _, _, pred = det.debug_fetch(i, want_input=False, want_heads=False)
+        dets, _ = Y.non_max_suppression(pred, 0.35, 0.45, None, False, 100)
+        ref = Y.scale_boxes(dets[:, :4], size, size, size, size) if len(dets) else np.empty((0, 4), np.float32)
+        assert len(last[i]) == len(dets), i
+        assert np.array_equal(last[i].xyxy.view(np.int32), ref.view(np.int32)), i
+        assert np.array_equal(last[i].confidence.view(np.int32), dets[:, 4].astype(np.float32).view(np.int32)), i
+        assert last[i].class_id.tolist() == dets[:, 5].astype(np.int32).tolist(), i
+    assert sum(len(d) for d in last) > 16
+    # layers of images 0 and 15 against the fp32 oracle
+    names = [c.name for c in pkg.weights.spec("s")]
+    loose = {"2.cv1", "4.cv1", "6.cv1", "8.cv1", "2.cv2", "15.cv2"}       # consumers of an LDS-resident fp16 intermediate when the tuner fused the pair
+    for img in (0, B - 1):
+        inp, _, _ = det.debug_fetch(img, want_heads=False, want_pred=False)
+        f, s = divmod(img, S)
+        assert np.array_equal(inp.astype(np.float32), Y.preprocess(frames[steps - 1][f][s], size, size).astype(np.float16).astype(np.float32))
+        gpu = fetch_layers(pkg, det, names, img)
+        assert len(gpu) >= 50
+        taps = {}
+        Y.forward(inp.astype(np.float32), w, "s", taps=taps, force=gpu)
+        for n in gpu:
+            k = 4e-3 if (n in loose or (".m." in n and n.endswith(".cv2"))) else 2e-3
+            tol = k * np.abs(taps[n]).max() + 2e-3
+            err = float(np.abs(taps[n] - gpu[n]).max())
+            assert err <= tol, f"img {img} layer {n}: max err {err:.4g} > tol {tol:.4g}"
+    # the same frames synchronously through the same engine
+    sync = det.detect_batch([frames[steps - 1][f][s] for f in range(F) for s in range(S)])
+    for i in range(B):
+        assert np.array_equal(sync[i].xyxy.view(np.int32), last[i].xyxy.view(np.int32)) and sync[i].class_id.tolist() == last[i].class_id.tolist(), i
+    buf.free()
+    det.close()
