@@ -163,10 +163,10 @@ def main():
 
     # the same frames in a page-locked host ring: slot (r, s) = frame r of stream s, slots of one r -- and of
     # consecutive r -- back to back, so the S x F frames of a step are ONE contiguous block (one DMA)
-    host_ring = host_ptrs = None
+    host_ring = host_ptrs = pinned = None
 
     def make_host_ring():
-        nonlocal host_ring, host_ptrs
+        nonlocal host_ring, host_ptrs, pinned            # `pinned` owns the page-locked memory: it must outlive every view
         if host_ring is not None:
             return
         if args.pageable:

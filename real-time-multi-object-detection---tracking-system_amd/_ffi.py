@@ -226,6 +226,7 @@ class PinnedArray:
         check(lib().rtmodt_host_alloc(device, max(self.nbytes, 1), C.byref(p)))
         self.ptr = p.value
         buf = (C.c_uint8 * self.nbytes).from_address(self.ptr)
+        buf._owner = self                                 # every NumPy view of the memory keeps its owner (and so the allocation) alive
         self.array = np.frombuffer(buf, dtype=dtype).reshape(shape)
 
     def free(self):

@@ -220,6 +220,9 @@ struct rtmodt_detector {
     // t+1 runs under the forward pass of batch t when the caller's frames are in pinned memory
     uint8_t *stage = nullptr; size_t stage_per = 0;      // [RING_SLOTS][B][stage_per]
     hipStream_t copy_stream = nullptr;
+    // RTMODT_ZERO_COPY=1: page-locked frames are read in place by the stem (opt-in: the stem then waits on PCIe with every CU's
+    // wave slots taken, 11.8 k frames/s against 17.4 k for one DMA per step in front of stage 1 -- profiles/r02/README.md)
+    bool zero_copy = false, last_in_place = false;
     int h2d_mode = 0;                                 // RTMODT_H2D: 0 = stream-ordered upload (events), 1 = host-synchronised upload (no events)
     FramePtrs fptrs{};
     // letterbox folded into the stem conv whenever the frames need no resize (conv.hip: stem_fused); the stem is
@@ -1373,6 +1376,7 @@ static int detector_create_impl(const rtmodt_det_cfg *cfg, rtmodt_detector *d) {
     RT_HIP(hipMalloc((void **)&d->d_zeros, 256));
     RT_HIP(hipMemset(d->d_zeros, 0, 256));
     if (const char *e = getenv("RTMODT_H2D")) d->h2d_mode = atoi(e);
+    if (const char *e = getenv("RTMODT_ZERO_COPY")) d->zero_copy = atoi(e) != 0;
     RT_TRY(build_graph(d, wf));
     RT_TRY(ensure_chain_streams(d));                       // may fall back to one chain: before anything is sized by n_chains
 
@@ -1452,7 +1456,24 @@ int rtmodt_detector_enqueue_batch(rtmodt_detector *d, const uint8_t *const *fram
              d->n_pending);
     RT_HIP(hipSetDevice(d->device));
     rtmodt_detector::Slot &sl = d->slots[d->head];
-    if (mem_kind == RTMODT_MEM_HOST) {
+    LbHost g = letterbox_geometry(h, w, d->in_h, d->in_w, d->rect);
+    RT_CHECK(g.new_w <= d->in_w && g.new_h <= d->in_h, RTMODT_E_INVALID, "a %dx%d frame does not fit the %dx%d rectangle this detector was built for", w, h, d->in_w, d->in_h);
+    // Opt-in (RTMODT_ZERO_COPY=1): page-locked frames the device can address (rtmodt_host_alloc / hipHostMalloc) that need no
+    // resize are not copied -- the stem conv reads their bytes in place, over PCIe, once.  The caller keeps such frames
+    // unchanged until the batch is fetched.
+    bool in_place = false;
+    if (mem_kind == RTMODT_MEM_HOST && d->zero_copy && d->stem_fuse && !g.resize) {
+        in_place = true;
+        for (int i = 0; i < n && in_place; ++i) {
+            hipPointerAttribute_t at{};
+            if (hipPointerGetAttributes(&at, frames[i]) != hipSuccess) { (void)hipGetLastError(); in_place = false; break; }
+            in_place = at.type == hipMemoryTypeHost && at.devicePointer != nullptr;
+            if (in_place) d->fptrs.p[i] = (const uint8_t *)at.devicePointer;
+        }
+    }
+    d->last_in_place = in_place;
+    if (in_place) {
+    } else if (mem_kind == RTMODT_MEM_HOST) {
         RT_CHECK((size_t)h * stride_bytes <= d->stage_per, RTMODT_E_CAPACITY, "frame %dx%d exceeds max_src %dx%d", w, h, d->cfg.max_src_w,
                  d->cfg.max_src_h);
         uint8_t *area = d->stage + d->stage_per * d->B * d->head;
@@ -1493,8 +1514,6 @@ int rtmodt_detector_enqueue_batch(rtmodt_detector *d, const uint8_t *const *fram
         for (int i = 0; i < n; ++i) d->fptrs.p[i] = frames[i];
     }
     for (int i = n; i < d->B; ++i) d->fptrs.p[i] = d->fptrs.p[0];
-    LbHost g = letterbox_geometry(h, w, d->in_h, d->in_w, d->rect);
-    RT_CHECK(g.new_w <= d->in_w && g.new_h <= d->in_h, RTMODT_E_INVALID, "a %dx%d frame does not fit the %dx%d rectangle this detector was built for", w, h, d->in_w, d->in_h);
     if (g.resize && (h != d->tab_h || w != d->tab_w)) {
         std::vector<int32_t> xo, x0, x1, yo, y0, y1;
         build_resize_tables(g.new_w, w, xo, x0, x1);

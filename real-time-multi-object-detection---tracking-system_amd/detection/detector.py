@@ -144,6 +144,7 @@ class Detector:
         self._cls = np.empty((self.batch, max_det), np.int32)
         self._n = np.zeros(self.batch, np.int32)
         self._in_flight = []                              # frame counts of batches enqueued, not yet fetched
+        self._keepalive = []                              # per batch in flight: the host arrays its upload / in-place read uses
         if warmup:
             self._warmup()
 
@@ -193,11 +194,16 @@ class Detector:
 
     def enqueue(self, frames: Sequence, height: int = 0, width: int = 0, pitch: int = 0) -> None:
         """Asynchronous half of :meth:`detect_batch`.  ``frames``: NumPy BGR images, or raw
-        device addresses (ints) of BGR images with ``height/width/pitch`` given."""
+        device addresses (ints) of BGR images with ``height/width/pitch`` given.
+
+        Host frames in page-locked memory (``_ffi.PinnedArray`` / ``pipeline.PinnedFrameRing``) that need no resize are
+        read by the stem kernel in place, other host frames are copied asynchronously: either way the caller must not
+        rewrite a frame before the batch it belongs to has been fetched (the arrays themselves are kept alive here)."""
         n = len(frames)
         if n < 1 or n > self.batch:
             raise ValueError(f"{n} frames for a detector built with batch={self.batch}")
         arr = (C.c_void_p * n)()
+        keep = None
         if isinstance(frames[0], (int, np.integer)):
             kind, h, w, p = _ffi.MEM_DEVICE, height, width, pitch or width * 3
             for i, a in enumerate(frames):
@@ -211,7 +217,6 @@ class Detector:
                 if a.shape[:2] != (h, w) or a.ndim != 3 or a.shape[2] != 3:
                     raise ValueError("frames of one batch must share one H x W x 3 shape")
                 arr[i] = a.ctypes.data
-            self._frames_keepalive = keep
         if self.rect:
             want = self.rect_shape(int(h), int(w), self._side)
             if want != self.model.input_hw:
@@ -220,14 +225,17 @@ class Detector:
                 self.model = self._model_for(*want)
         _ffi.check(_ffi.lib().rtmodt_detector_enqueue_batch(self.model.handle, arr, n, int(h), int(w), int(p), kind))
         self._in_flight.append(n)
+        self._keepalive.append(keep)
 
     def fetch(self) -> list:
         """Results of the OLDEST batch in flight (up to three may be: enqueue t+1 [, t+2], fetch t)."""
         if not self._in_flight:
             raise RuntimeError("fetch() without a pending enqueue()")
-        n = self._in_flight.pop(0)
+        n = self._in_flight[0]
         _ffi.check(_ffi.lib().rtmodt_detector_fetch(self.model.handle, _ffi.ptr(self._xyxy), _ffi.ptr(self._conf),
                                                     _ffi.ptr(self._cls), _ffi.ptr(self._n)))
+        self._in_flight.pop(0)
+        self._keepalive.pop(0)                            # the batch's frames have been consumed
         return [self._parse(i) for i in range(n)]
 
     def synchronize(self) -> None:

@@ -912,3 +912,44 @@ def test_benchmarked_shape_parity(pkg, wdir):
         assert np.array_equal(sync[i].xyxy.view(np.int32), last[i].xyxy.view(np.int32)) and sync[i].class_id.tolist() == last[i].class_id.tolist(), i
     buf.free()
     det.close()
+
+
+@pytest.mark.parametrize("h,w", [(640, 640), (480, 640)])
+def test_page_locked_frames_read_in_place(pkg, wdir, monkeypatch, h, w):
+    """RTMODT_ZERO_COPY=1: host frames in page-locked memory that need no resize are not copied, the stem kernel reads them
+    over PCIe in place (engine.hip: in_place).  Stem output, input image and detections must equal, bit for bit, the staged-copy path
+    (RTMODT_ZERO_COPY=0: one DMA for the contiguous ring slots) and the pageable path (16 separate copies); pipelined,
+    with the ring slots of later batches in flight while earlier ones are read."""
+    B, steps = 4, 5
+    src = pkg.synth.structured_frames(B * steps, h, w, seed=h * 3 + w)
+    ring = pkg.pipeline.PinnedFrameRing(B * steps, h, w)
+    for i in range(B * steps):
+        ring.write(i, src[i])
+    outs = {}
+    for mode in ("inplace", "copy", "pageable"):
+        monkeypatch.setenv("RTMODT_ZERO_COPY", "0" if mode == "copy" else "1")
+        det, _ = make_detector(pkg, wdir, "s", 640, autotune=False, batch=B, chains=-1, confidence=0.05)
+        res = []
+        for t in range(steps):
+            det.enqueue([(src[t * B + i] if mode == "pageable" else ring.frame(t * B + i)) for i in range(B)])
+            if t >= 2:
+                res.append(det.fetch())
+        while len(res) < steps:
+            res.append(det.fetch())
+        stem = [det.debug_layer("0", i) for i in range(B)]
+        inp = [det.debug_fetch(i, want_heads=False, want_pred=False)[0] for i in range(B)]
+        outs[mode] = (res, stem, inp)
+        det.close()
+    want = Y.preprocess(src[(steps - 1) * B + 1], 640, 640).astype(np.float16)
+    assert np.array_equal(outs["inplace"][2][1].view(np.uint16), want.view(np.uint16))
+    assert sum(len(d) for batch in outs["inplace"][0] for d in batch) > 0
+    for mode in ("copy", "pageable"):
+        for t in range(steps):
+            for i in range(B):
+                a, b = outs["inplace"][0][t][i], outs[mode][0][t][i]
+                assert np.array_equal(a.xyxy.view(np.int32), b.xyxy.view(np.int32)) and np.array_equal(a.confidence.view(np.int32), b.confidence.view(np.int32)) and \
+                    a.class_id.tolist() == b.class_id.tolist(), (mode, t, i)
+        for i in range(B):
+            assert np.array_equal(outs["inplace"][1][i].view(np.uint16), outs[mode][1][i].view(np.uint16)), (mode, i)
+            assert np.array_equal(outs["inplace"][2][i].view(np.uint16), outs[mode][2][i].view(np.uint16)), (mode, i)
+    ring.close()
