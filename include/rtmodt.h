@@ -176,6 +176,15 @@ int rtmodt_tracker_update_from_detector_frames(rtmodt_tracker *trk, rtmodt_detec
 int rtmodt_tracker_state(rtmodt_tracker *trk, int stream, int64_t *ids, float *xyxy, float *conf,
                          int32_t *cls, int32_t *age, int32_t *tsu, int32_t *n, int64_t *next_id);
 int rtmodt_tracker_reset(rtmodt_tracker *trk, int stream);   /* stream < 0: all */
+/* OPT-IN, no reference counterpart (the reference overwrites a matched track's box, tracker.py:99-104, and has no motion
+ * model): ByteTrack's published 8-state constant-velocity Kalman filter over (cx, cy, a, h), batched inside the same
+ * launch -- every track is predicted at the start of a frame, association runs on the predicted boxes, a matched track
+ * is corrected with its detection, a new track is initiated from it.  `xyxy` in rtmodt_tracker_state keeps the
+ * reference's meaning (the last matched detection).  Call before the first update.  oracle/kalman_oracle.py. */
+int rtmodt_tracker_enable_kalman(rtmodt_tracker *trk);
+/* Filter state in list order: mean[n][8] = (cx, cy, a, h, vx, vy, va, vh); cov[n][12] = per coordinate the (a, b, c)
+ * entries of its 2x2 covariance block [[a, b], [b, c]] (the 8x8 covariance is block-diagonal by construction). */
+int rtmodt_tracker_kalman_state(rtmodt_tracker *trk, int stream, float *mean, float *cov, int32_t *n);
 
 /* _ByteTrackCore._batch_iou (tracker.py:150-161) alone: out[m*n] float32, bit-exact. */
 int rtmodt_iou_matrix(int device, const float *a, int m, const float *b, int n, float *out);

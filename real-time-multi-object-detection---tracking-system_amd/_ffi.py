@@ -97,6 +97,8 @@ def lib() -> C.CDLL:
         "rtmodt_tracker_update_from_detector_frames": (C.c_int, [vp, vp, C.c_int, C.c_int]),
         "rtmodt_tracker_state": (C.c_int, [vp, C.c_int, vp, vp, vp, vp, vp, vp, C.POINTER(i32), C.POINTER(i64)]),
         "rtmodt_tracker_reset": (C.c_int, [vp, C.c_int]),
+        "rtmodt_tracker_enable_kalman": (C.c_int, [vp]),
+        "rtmodt_tracker_kalman_state": (C.c_int, [vp, C.c_int, vp, vp, C.POINTER(i32)]),
         "rtmodt_iou_matrix": (C.c_int, [C.c_int, vp, C.c_int, vp, C.c_int, vp]),
         "rtmodt_assign_greedy": (C.c_int, [C.c_int, vp, C.c_int, C.c_int, f32, vp, vp]),
         "rtmodt_assign_lapjv": (C.c_int, [C.c_int, vp, C.c_int, C.c_int, C.c_double, vp, vp]),

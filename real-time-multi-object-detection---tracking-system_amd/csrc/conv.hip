@@ -60,10 +60,28 @@ struct ConvArgs {
     int t_cout, t_kp, t_act, t_out_Hp, t_out_Wp, t_out_cs, t_out_pad;
     int epi16;                           // epilogue through LDS with 16-byte NHWC stores (all channel offsets / strides % 8 == 0):
                                          // 1 = tile kernels, 2 = also the tap-reuse kernel
+    int wthru;                           // output stores are WRITE-THROUGH (sc1): the tile leaves the XCD's L2 while the kernel still runs,
+                                         // instead of as one write-back of every dirty line at the kernel boundary
 };
 
 __device__ __forceinline__ float silu_f(float x) {
     return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x));
+}
+
+// Output stores.  A plain store leaves the line dirty in the XCD's L2 and the whole output is written back at the kernel
+// boundary (B / ~6 TB/s with nothing else running); a write-through (sc1) store sends it on its way at once, under the
+// rest of the kernel.  Values and addresses are identical either way.  Measured per launch at 16 frames (profiles/r02):
+// the tile kernels' 16-byte stores gain 5-12 % (6.cv2 21.1 -> 18.5 us), the 8-byte stores of the accumulator layout LOSE
+// 5-10 % written through (an 8-byte sc1 store costs 2.7x a 16-byte one per byte), so only mode 2 (A/B hook) sends those too.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void store16(f16 *base, long off, const half8 &v, int wt) {
+    if (wt) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, 0xFFFFFFFF, 0x00020000), (unsigned)(off * 2), 0, 16);
+    else *(half8 *)(base + off) = v;
+}
+__device__ __forceinline__ void store8(f16 *base, long off, const half4 &v, int wt) {
+    if (wt > 1) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, 0xFFFFFFFF, 0x00020000), (unsigned)(off * 2), 0, 16);
+    else *(half4 *)(base + off) = v;
 }
 
 // XCD-aware tile order (speed only, any placement is correct).  Workgroups are dealt round-robin
@@ -147,13 +165,13 @@ __device__ __forceinline__ void store_tile(const ConvArgs &p, const floatx4 &acc
         v[0] += (float)rv[0]; v[1] += (float)rv[1]; v[2] += (float)rv[2]; v[3] += (float)rv[3];
     }
     half4 o = {(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
-    *(half4 *)(p.out + opix + n) = o;
+    store8(p.out, opix + n, o, p.wthru);
     if (opix2 >= 0) {                                    // Upsample(nearest, x2) + Concat folded into this epilogue
         const long row = (long)p.out2_Wp * p.out2_cs;
-        *(half4 *)(p.out2 + opix2 + n) = o;
-        *(half4 *)(p.out2 + opix2 + p.out2_cs + n) = o;
-        *(half4 *)(p.out2 + opix2 + row + n) = o;
-        *(half4 *)(p.out2 + opix2 + row + p.out2_cs + n) = o;
+        store8(p.out2, opix2 + n, o, p.wthru);
+        store8(p.out2, opix2 + p.out2_cs + n, o, p.wthru);
+        store8(p.out2, opix2 + row + n, o, p.wthru);
+        store8(p.out2, opix2 + row + p.out2_cs + n, o, p.wthru);
     }
 }
 
@@ -228,23 +246,23 @@ __device__ __forceinline__ void epilogue_lds(const ConvArgs &p, const int n0, co
         const unsigned char *src = lds + pm * ROWB + k8 * 16;
         if (n + 8 <= p.cout) {
             const half8 v = *(const half8 *)src;
-            *(half8 *)(p.out + opix + n) = v;
+            store16(p.out, opix + n, v, p.wthru);
             if (opix2 >= 0) {
                 const long row = (long)p.out2_Wp * p.out2_cs;
-                *(half8 *)(p.out2 + opix2 + n) = v;
-                *(half8 *)(p.out2 + opix2 + p.out2_cs + n) = v;
-                *(half8 *)(p.out2 + opix2 + row + n) = v;
-                *(half8 *)(p.out2 + opix2 + row + p.out2_cs + n) = v;
+                store16(p.out2, opix2 + n, v, p.wthru);
+                store16(p.out2, opix2 + p.out2_cs + n, v, p.wthru);
+                store16(p.out2, opix2 + row + n, v, p.wthru);
+                store16(p.out2, opix2 + row + p.out2_cs + n, v, p.wthru);
             }
         } else {                                           // cout % 8 == 4: the last chunk is half a chunk
             const half4 v = *(const half4 *)src;
-            *(half4 *)(p.out + opix + n) = v;
+            store8(p.out, opix + n, v, p.wthru);
             if (opix2 >= 0) {
                 const long row = (long)p.out2_Wp * p.out2_cs;
-                *(half4 *)(p.out2 + opix2 + n) = v;
-                *(half4 *)(p.out2 + opix2 + p.out2_cs + n) = v;
-                *(half4 *)(p.out2 + opix2 + row + n) = v;
-                *(half4 *)(p.out2 + opix2 + row + p.out2_cs + n) = v;
+                store8(p.out2, opix2 + n, v, p.wthru);
+                store8(p.out2, opix2 + p.out2_cs + n, v, p.wthru);
+                store8(p.out2, opix2 + row + n, v, p.wthru);
+                store8(p.out2, opix2 + row + p.out2_cs + n, v, p.wthru);
             }
         }
     }
@@ -320,7 +338,7 @@ __device__ __forceinline__ void epilogue_tail(const ConvArgs &p, const floatx4 (
         if (n >= p.t_cout) continue;
         long opix;
         if (!pix(pm, opix)) continue;
-        *(half8 *)(p.t_out + opix + n) = *(const half8 *)(lds + pm * ROWB2 + k8 * 16);
+        store16(p.t_out, opix + n, *(const half8 *)(lds + pm * ROWB2 + k8 * 16), p.wthru);
     }
 }
 
@@ -1111,6 +1129,8 @@ static int make_args(const ConvLaunch &c, ConvArgs &a) {
     a.t_wt = c.tail_wt; a.t_bias = c.tail_bias; a.t_out = c.tail_wt ? c.tail_out.base + c.tail_out.coff : nullptr;
     a.t_cout = c.tail_cout; a.t_kp = c.tail_kp; a.t_act = c.tail_act;
     a.t_out_Hp = c.tail_out.H + 2 * c.tail_out.pad; a.t_out_Wp = c.tail_out.W + 2 * c.tail_out.pad; a.t_out_cs = c.tail_out.C; a.t_out_pad = c.tail_out.pad;
+    static const int wt_env = getenv("RTMODT_WT") ? atoi(getenv("RTMODT_WT")) : 0;
+    a.wthru = wt_env;
     a.epi16 = c.out.coff % 8 == 0 && c.out.C % 8 == 0 && (!c.out2.base || (c.out2.coff % 8 == 0 && c.out2.C % 8 == 0)) &&
               (!c.res.base || (c.res.coff % 4 == 0)) ? c.epilogue : 0;
     RT_CHECK(a.kp % 32 == 0 && a.kp >= a.K, RTMODT_E_INVALID, "launch_conv: kp %d for K %d", a.kp, a.K);

@@ -842,22 +842,31 @@ static int time_launch(rtmodt_detector *d, hipEvent_t e0, hipEvent_t e1, F &&lau
     return RTMODT_OK;
 }
 
-// fastest tile for one conv (or one group of convs sharing a tile); returns its time
-static int tune_conv(rtmodt_detector *d, hipEvent_t e0, hipEvent_t e1, const std::string &name, ConvLaunch *c, int n, int &tile_io,
-                     float &best_ms) {
+// may tile `t` run these n convs as one launch?  (the tuner's candidate filter; also applied to every cache hit)
+static bool tile_legal(const ConvLaunch *c, int n, int t) {
+    if (t < 0 || t >= TILE_COUNT || tile_is_tail(t)) return false;              // tail tiles only through tune_tails()
     bool cin64 = true, rows_ok = true;
     for (int i = 0; i < n; ++i) {
         cin64 = cin64 && c[i].cin % 64 == 0 && c[i].kp % 64 == 0;
         rows_ok = rows_ok && c[i].ks == 3 && c[i].stride == 1 && c[i].in.pad == 1 && c[i].cin % 32 == 0;
     }
+    if (tile_needs_cin64(t) && !cin64) return false;
+    if (tile_is_rows(t) && !rows_ok) return false;
+    if (c[0].in_lo.base && !tile_reads_lo(t)) return false;
+    if (t >= TILE_K64_128x128_S2_W8 && t <= TILE_K64_256x64_S2_W8 && n != 1) return false;   // the 8-wave tiles have no group entry point
+    return true;
+}
+static bool tail_tile_legal(const ConvLaunch &c, int t) {
+    return tile_is_tail(t) && tile_shape(t).bn == c.cout && !(tile_needs_cin64(t) && (c.cin % 64 != 0 || c.kp % 64 != 0)) && c.cin % 32 == 0;
+}
+
+// fastest tile for one conv (or one group of convs sharing a tile); returns its time
+static int tune_conv(rtmodt_detector *d, hipEvent_t e0, hipEvent_t e1, const std::string &name, ConvLaunch *c, int n, int &tile_io,
+                     float &best_ms) {
     best_ms = 1e30f;
     int best_tile = tile_io;
     for (int t = 0; t < TILE_COUNT; ++t) {
-        if (tile_needs_cin64(t) && !cin64) continue;
-        if (tile_is_rows(t) && !rows_ok) continue;
-        if (tile_is_tail(t)) continue;                     // only through tune_tails()
-        if (c[0].in_lo.base && !tile_reads_lo(t)) continue;
-        if (t >= TILE_K64_128x128_S2_W8 && t <= TILE_K64_256x64_S2_W8 && n != 1) continue;   // the 8-wave tiles have no group entry point
+        if (!tile_legal(c, n, t)) continue;
         float ms;
         RT_TRY(time_launch(d, e0, e1, [&]() { return launch_conv_group(c, n, t, d->stream); }, ms));
         if (getenv("RTMODT_TUNE_LOG")) fprintf(stderr, "[tune] %-28s %-16s %8.2f us\n", name.c_str(), tile_name(t), ms * 1e3f);
@@ -880,11 +889,23 @@ static std::string tune_key(const rtmodt_detector *d, const Op &op) {
     return buf;
 }
 struct TuneRec { int t0 = 0, t1 = 0, fused = 0; };
+// first line of a cache file: the tile table it was written for (count + a hash of the tile names in id order); a file
+// written by a build with another table is ignored, so an id can never silently select a different kernel
+static std::string tune_cache_header() {
+    uint64_t h = 1469598103934665603ull;
+    for (int t = 0; t < TILE_COUNT; ++t)
+        for (const char *p = tile_name(t); ; ++p) { h = (h ^ (unsigned char)*p) * 1099511628211ull; if (!*p) break; }
+    char buf[96];
+    snprintf(buf, sizeof(buf), "#rtmodt-tune tiles=%d table=%016llx", TILE_COUNT, (unsigned long long)h);
+    return buf;
+}
 static std::map<std::string, TuneRec> tune_cache_read(const char *path) {
     std::map<std::string, TuneRec> m;
     std::ifstream f(path);
     std::string key;
     TuneRec r;
+    std::string first;
+    if (!std::getline(f, first) || first != tune_cache_header()) return m;
     while (f >> key >> r.t0 >> r.t1 >> r.fused)
         if (r.t0 >= 0 && r.t0 < TILE_COUNT && r.t1 >= 0 && r.t1 < TILE_COUNT) m[key] = r;
     return m;
@@ -901,7 +922,14 @@ static int autotune_ops(rtmodt_detector *d, std::vector<Op> &ops) {
         if (op.kind != OP_CONV && op.kind != OP_GROUP && op.kind != OP_BNECK) continue;
         const std::string key = tune_key(d, op);
         auto hit = cache.find(key);
-        if (hit != cache.end() && op.kind == OP_CONV && op.conv.in_lo.base && !tile_reads_lo(hit->second.t0)) hit = cache.end();   // (a cache from before this conv read a half-resolution source)
+        if (hit != cache.end()) {                          // a hit must pass the same legality checks as a tuning candidate
+            const TuneRec &r = hit->second;
+            bool ok;
+            if (op.kind == OP_CONV) ok = tile_legal(&op.conv, 1, r.t0) && (!op.conv.tail_wt || r.t1 == 0 || !r.fused || tail_tile_legal(op.conv, r.t1));
+            else if (op.kind == OP_GROUP) ok = tile_legal(op.group.data(), (int)op.group.size(), r.t0);
+            else ok = tile_legal(&op.group[0], 1, r.t0) && tile_legal(&op.group[1], 1, r.t1);
+            if (!ok) { cache.erase(hit); hit = cache.end(); }
+        }
         if (hit != cache.end()) {
             const TuneRec &r = hit->second;
             if (op.kind == OP_CONV) { op.conv.tile = r.t0; if (op.conv.tail_wt) { op.tail_tile = r.t1; op.tail_on = r.fused != 0; } }
@@ -990,6 +1018,7 @@ static int autotune_ops(rtmodt_detector *d, std::vector<Op> &ops) {
         const std::string tmp = std::string(cache_path) + ".tmp." + std::to_string((long)getpid());
         {
             std::ofstream f(tmp);
+            f << tune_cache_header() << '\n';
             for (auto &kv : cache) f << kv.first << '\t' << kv.second.t0 << ' ' << kv.second.t1 << ' ' << kv.second.fused << '\n';
         }
         rename(tmp.c_str(), cache_path);

@@ -165,11 +165,15 @@ int launch_pred_candidates(const float *pred, int nc, int n_anchors, float conf,
 // ---------------------------------------------------------------------------------------
 struct TrackerState {          // one stream; device pointers; double-buffered (cur = buffer index)
     int64_t *ids[2]; float4 *box[2]; float *conf[2]; int32_t *cls[2]; int32_t *age[2]; int32_t *tsu[2];
+    // opt-in Kalman motion model (TrackerArgs::kalman): [5][max_tracks] float4 per buffer =
+    // mean (cx, cy, a, h), velocities, and the a / b / c entries of the four 2x2 covariance blocks
+    float4 *kf[2];
 };
 struct TrackerArgs {
     int n_streams, stream_base, max_tracks, max_dets;   // grid = n_streams workgroups, stream index = stream_base + blockIdx.x
     float track_thresh, match_thresh; int track_buffer;
     int assign_mode;           // RTMODT_ASSIGN_GREEDY | RTMODT_ASSIGN_LAPJV
+    int kalman;                // 1: constant-velocity Kalman predict / update per track (opt-in; the reference has none)
     double cost_limit;         // lapjv: 1 - match_thresh evaluated in double (tracker.py:170)
     TrackerState *states;      // device array [n_streams]
     int64_t *meta;             // device [n_streams][8]: {cur, n_tracks, err, n_active, next_id, 0, 0, 0}

@@ -36,6 +36,74 @@ __device__ __forceinline__ float iou_ref(const float4 a, const float4 b) {
     return inter / (uni + 1e-6f);
 }
 
+// ---------------------------------------------------------------------------------------
+// Opt-in Kalman motion model (TrackerArgs::kalman; oracle/kalman_oracle.py states the algorithm and its provenance:
+// ByteTrack's published 8-state constant-velocity filter -- the reference itself has none, tracker.py:99-104).
+// F, H, Q, R and the initial P keep P block-diagonal, so the filter is four independent (position, velocity) pairs
+// with covariance [[a, b], [b, c]] whose only coupling is the noise scale h.  float32, one rounding per operation in
+// exactly the oracle's order (this file is built with FMA contraction off and correctly rounded division).
+// ---------------------------------------------------------------------------------------
+struct Kf { float4 pos, vel, pa, pb, pc; };
+constexpr float KF_WP = 0.05f, KF_WV = 0.00625f;
+__device__ __forceinline__ Kf kf_load(const float4 *kf, int Mc, int i) { return Kf{kf[i], kf[Mc + i], kf[2 * Mc + i], kf[3 * Mc + i], kf[4 * Mc + i]}; }
+__device__ __forceinline__ void kf_store(float4 *kf, int Mc, int i, const Kf &k) {
+    kf[i] = k.pos; kf[Mc + i] = k.vel; kf[2 * Mc + i] = k.pa; kf[3 * Mc + i] = k.pb; kf[4 * Mc + i] = k.pc;
+}
+__device__ __forceinline__ float4 xyxy_to_xyah(const float4 b) {
+    const float w = b.z - b.x, h = b.w - b.y;
+    return float4{b.x + w * 0.5f, b.y + h * 0.5f, w / fmaxf(h, 1e-6f), h};
+}
+__device__ __forceinline__ float4 xyah_to_xyxy(const float4 m) {
+    const float w = m.z * m.w;
+    const float x1 = m.x - w * 0.5f, y1 = m.y - m.w * 0.5f;
+    return float4{x1, y1, x1 + w, y1 + m.w};
+}
+__device__ __forceinline__ Kf kf_initiate(const float4 z) {
+    const float sp = (2.0f * KF_WP) * z.w, sv = (10.0f * KF_WV) * z.w;
+    const float p2 = sp * sp, v2 = sv * sv;
+    Kf k;
+    k.pos = z; k.vel = float4{0.f, 0.f, 0.f, 0.f};
+    k.pa = float4{p2, p2, 1e-2f * 1e-2f, p2};
+    k.pb = float4{0.f, 0.f, 0.f, 0.f};
+    k.pc = float4{v2, v2, 1e-5f * 1e-5f, v2};
+    return k;
+}
+__device__ __forceinline__ void kf_predict1(float &p, const float v, float &a, float &b, float &c, const float qp, const float qv) {
+    const float a0 = a, b0 = b, c0 = c;
+    p = p + v;
+    a = ((a0 + (b0 + b0)) + c0) + qp;
+    b = b0 + c0;
+    c = c0 + qv;
+}
+__device__ __forceinline__ void kf_predict(Kf &k) {
+    const float h = k.pos.w;
+    const float sp = KF_WP * h, sv = KF_WV * h;
+    const float qp = sp * sp, qv = sv * sv;
+    kf_predict1(k.pos.x, k.vel.x, k.pa.x, k.pb.x, k.pc.x, qp, qv);
+    kf_predict1(k.pos.y, k.vel.y, k.pa.y, k.pb.y, k.pc.y, qp, qv);
+    kf_predict1(k.pos.z, k.vel.z, k.pa.z, k.pb.z, k.pc.z, 1e-2f * 1e-2f, 1e-5f * 1e-5f);
+    kf_predict1(k.pos.w, k.vel.w, k.pa.w, k.pb.w, k.pc.w, qp, qv);
+}
+__device__ __forceinline__ void kf_update1(float &p, float &v, float &a, float &b, float &c, const float z, const float r) {
+    const float a0 = a, b0 = b, c0 = c;
+    const float s = a0 + r;
+    const float k0 = a0 / s, k1 = b0 / s;
+    const float y = z - p;
+    p = p + k0 * y;
+    v = v + k1 * y;
+    a = a0 - k0 * a0;
+    b = b0 - k0 * b0;
+    c = c0 - k1 * b0;
+}
+__device__ __forceinline__ void kf_update(Kf &k, const float4 z) {
+    const float sp = KF_WP * k.pos.w;
+    const float r = sp * sp;
+    kf_update1(k.pos.x, k.vel.x, k.pa.x, k.pb.x, k.pc.x, z.x, r);
+    kf_update1(k.pos.y, k.vel.y, k.pa.y, k.pb.y, k.pc.y, z.y, r);
+    kf_update1(k.pos.z, k.vel.z, k.pa.z, k.pb.z, k.pc.z, z.z, 1e-1f * 1e-1f);
+    kf_update1(k.pos.w, k.vel.w, k.pa.w, k.pb.w, k.pc.w, z.w, r);
+}
+
 constexpr int TRK_THREADS = 1024;
 constexpr int TRK_WAVES = TRK_THREADS / 64;
 
@@ -357,10 +425,20 @@ __global__ __launch_bounds__(TRK_THREADS) void tracker_update(TrackerArgs a) {
     int32_t *c_cls = cur ? st.cls[1] : st.cls[0];   int32_t *n_cls = cur ? st.cls[0] : st.cls[1];
     int32_t *c_age = cur ? st.age[1] : st.age[0];   int32_t *n_age = cur ? st.age[0] : st.age[1];
     int32_t *c_tsu = cur ? st.tsu[1] : st.tsu[0];   int32_t *n_tsu = cur ? st.tsu[0] : st.tsu[1];
+    float4 *c_kf = cur ? st.kf[1] : st.kf[0];       float4 *n_kf = cur ? st.kf[0] : st.kf[1];
+    const bool kalman = a.kalman && c_kf != nullptr;
     int n = a.det_n[sidx];                                // detections are indexed by absolute stream too
     if (n > Nc) n = Nc;                                   // host rejects this; belt and braces
     const int tid = threadIdx.x;
 
+    if (kalman)                                            // every track moves on by one frame; a track that was not matched in
+        for (int i = tid; i < M; i += TRK_THREADS) {       // the previous frame (tsu >= 2) coasts with its height velocity zeroed
+            Kf k = kf_load(c_kf, Mc, i);
+            if (c_tsu[i] >= 2) k.vel.w = 0.f;
+            kf_predict(k);
+            kf_store(c_kf, Mc, i, k);
+            tbox[i] = xyah_to_xyxy(k.pos);                 // association sees the PREDICTED boxes
+        }
     if (n == 0) {                                         // tracker.py:70-73: age only, nothing expires
         for (int i = tid; i < M; i += TRK_THREADS) c_tsu[i] += 1;
         if (tid == 0) meta[3] = 0;
@@ -371,7 +449,7 @@ __global__ __launch_bounds__(TRK_THREADS) void tracker_update(TrackerArgs a) {
     const float *gc = a.det_conf + (size_t)sidx * a.det_stride;
     const int32_t *gk = a.det_cls + (size_t)sidx * a.det_stride;
     for (int i = tid; i < n; i += TRK_THREADS) { dbox[i] = gb[i]; dconf[i] = gc[i]; dcls[i] = gk[i]; }
-    for (int i = tid; i < M; i += TRK_THREADS) tbox[i] = c_box[i];
+    if (!kalman) for (int i = tid; i < M; i += TRK_THREADS) tbox[i] = c_box[i];
     __syncthreads();
 
     // ---- 1. hi / lo split (tracker.py:76-85), input order preserved ----
@@ -408,6 +486,7 @@ __global__ __launch_bounds__(TRK_THREADS) void tracker_update(TrackerArgs a) {
                 c_cls[i] = dcls[d];
                 c_age[i] += 1;
                 c_tsu[i] = 0;
+                if (kalman) { Kf k = kf_load(c_kf, Mc, i); kf_update(k, xyxy_to_xyah(dbox[d])); kf_store(c_kf, Mc, i, k); }
             }
         }
     } else {
@@ -452,6 +531,7 @@ __global__ __launch_bounds__(TRK_THREADS) void tracker_update(TrackerArgs a) {
                 c_cls[i] = dcls[d];
                 c_age[i] += 1;
                 c_tsu[i] = 0;
+                if (kalman) { Kf k = kf_load(c_kf, Mc, i); kf_update(k, xyxy_to_xyah(dbox[d])); kf_store(c_kf, Mc, i, k); }
             }
         }
     }
@@ -467,6 +547,7 @@ __global__ __launch_bounds__(TRK_THREADS) void tracker_update(TrackerArgs a) {
         c_cls[i] = dcls[d];
         c_age[i] = 1;
         c_tsu[i] = 0;
+        if (kalman) kf_store(c_kf, Mc, i, kf_initiate(xyxy_to_xyah(dbox[d])));
     }
     const int M2 = M + nsp;
     __syncthreads();                                      // state writes visible to the whole workgroup
@@ -489,6 +570,7 @@ __global__ __launch_bounds__(TRK_THREADS) void tracker_update(TrackerArgs a) {
             n_cls[o] = c_cls[i];
             n_age[o] = c_age[i];
             n_tsu[o] = tsu;
+            if (kalman) kf_store(n_kf, Mc, o, kf_load(c_kf, Mc, i));
         }
         if (keep && tsu == 0) atomicAdd(&act_cnt, 1);      // tracker.py:141 -- never true (SURVEY finding 4)
         kept += tot;
@@ -513,10 +595,12 @@ int launch_tracker_update(const TrackerArgs &a, hipStream_t s) {
     size_t smem = tracker_smem_bytes(a.max_tracks, a.max_dets) + (a.assign_mode == RTMODT_ASSIGN_LAPJV ? lap_smem_bytes(a.max_dets) + 8 : 0);
     RT_CHECK(smem <= 150 * 1024, RTMODT_E_INVALID, "tracker: max_tracks %d / max_dets %d need %zu B of LDS (> 160 KiB)", a.max_tracks,
              a.max_dets, smem);
-    static size_t attr_bytes = 0;
-    if (smem > attr_bytes) {
+    static size_t attr_bytes[64] = {};                     // the attribute is per device
+    int dev = 0;
+    RT_HIP(hipGetDevice(&dev));
+    if (dev >= 0 && dev < 64 && smem > attr_bytes[dev]) {
         RT_HIP(hipFuncSetAttribute((const void *)tracker_update, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        attr_bytes = smem;
+        attr_bytes[dev] = smem;
     }
     hipLaunchKernelGGL(tracker_update, dim3(a.n_streams), dim3(TRK_THREADS), smem, s, a);
     RT_HIP(hipGetLastError());

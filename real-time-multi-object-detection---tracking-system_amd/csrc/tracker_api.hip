@@ -12,7 +12,13 @@ using namespace rtmodt;
 struct rtmodt_tracker {
     int device = 0;
     hipStream_t stream = nullptr;
-    hipStream_t last_stream = nullptr;    // where the most recent update ran (own stream, or the detector's)
+    // An update fed from a detector runs on THAT detector's post-processing stream (ordered behind its NMS, no host hop).
+    // The tracker never keeps the foreign stream handle: it records `foreign_done` there, and everything it later does on
+    // its own stream (host-fed updates, state read-back, reset, destroy) waits for that event first.
+    hipEvent_t foreign_done = nullptr;
+    bool foreign_pending = false;
+    bool kalman = false;                  // opt-in motion model (rtmodt_tracker_enable_kalman)
+    char *kf_pool = nullptr;
     int S = 1, Mc = 0, Nc = 0;
     float track_thresh = 0.5f, match_thresh = 0.8f;
     int track_buffer = 30;
@@ -32,11 +38,20 @@ struct rtmodt_tracker {
 
 static int64_t init_meta_row[8] = {0, 0, 0, 0, 1, 0, 0, 0};   // cur, n_tracks, err, n_active, next_id (tracker.py:55)
 
+// make the tracker's own stream wait for the last update that ran on a detector's stream
+static int join_foreign(rtmodt_tracker *t) {
+    if (t->foreign_pending) {
+        RT_HIP(hipStreamWaitEvent(t->stream, t->foreign_done, 0));
+        t->foreign_pending = false;
+    }
+    return RTMODT_OK;
+}
+
 namespace rtmodt {
 int tracker_device_view(rtmodt_tracker *t, TrackerDeviceView *out) {
     RT_CHECK(t && out, RTMODT_E_INVALID, "null argument");
-    *out = TrackerDeviceView{t->d_states, t->d_meta, t->S, t->Mc, t->device, t->last_stream};
-    return RTMODT_OK;
+    *out = TrackerDeviceView{t->d_states, t->d_meta, t->S, t->Mc, t->device, t->stream};
+    return join_foreign(t);                                // the caller's work on t->stream is ordered behind every update
 }
 }  // namespace rtmodt
 
@@ -45,7 +60,10 @@ extern "C" {
 void rtmodt_tracker_destroy(rtmodt_tracker *t) {
     if (!t) return;
     hipSetDevice(t->device);
+    if (t->foreign_done) hipEventSynchronize(t->foreign_done);      // an update may still be queued on a detector's stream
     if (t->stream) hipStreamSynchronize(t->stream);
+    if (t->foreign_done) hipEventDestroy(t->foreign_done);
+    hipFree(t->kf_pool);
     hipFree(t->pool); hipFree(t->d_states); hipFree(t->d_meta);
     hipFree(t->d_box); hipFree(t->d_conf); hipFree(t->d_cls); hipFree(t->d_n);
     hipHostFree(t->h_meta); hipHostFree(t->h_n); hipHostFree(t->h_state);
@@ -56,7 +74,7 @@ void rtmodt_tracker_destroy(rtmodt_tracker *t) {
 static int tracker_create_impl(rtmodt_tracker *t) {
     RT_HIP(hipSetDevice(t->device));
     RT_HIP(hipStreamCreateWithFlags(&t->stream, hipStreamNonBlocking));
-    t->last_stream = t->stream;
+    RT_HIP(hipEventCreateWithFlags(&t->foreign_done, hipEventDisableTiming));
     const size_t per_buf = (size_t)t->Mc * (8 + 16 + 4 + 4 + 4 + 4);
     const size_t total = per_buf * 2 * t->S;
     RT_HIP(hipMalloc((void **)&t->pool, total));
@@ -72,6 +90,7 @@ static int tracker_create_impl(rtmodt_tracker *t) {
             st.cls[b] = (int32_t *)p; p += (size_t)t->Mc * 4;
             st.age[b] = (int32_t *)p; p += (size_t)t->Mc * 4;
             st.tsu[b] = (int32_t *)p; p += (size_t)t->Mc * 4;
+            st.kf[b] = nullptr;
         }
     RT_HIP(hipMalloc((void **)&t->d_states, sizeof(TrackerState) * t->S));
     RT_HIP(hipMemcpy(t->d_states, t->h_states.data(), sizeof(TrackerState) * t->S, hipMemcpyHostToDevice));
@@ -121,7 +140,7 @@ static TrackerArgs make_args(rtmodt_tracker *t) {
     TrackerArgs a{};
     a.n_streams = t->S; a.stream_base = 0; a.max_tracks = t->Mc; a.max_dets = t->Nc;
     a.track_thresh = t->track_thresh; a.match_thresh = t->match_thresh; a.track_buffer = t->track_buffer;
-    a.assign_mode = t->assign_mode; a.cost_limit = t->cost_limit;
+    a.assign_mode = t->assign_mode; a.cost_limit = t->cost_limit; a.kalman = t->kalman ? 1 : 0;
     a.states = t->d_states; a.meta = t->d_meta;
     a.det_box = t->d_box; a.det_conf = t->d_conf; a.det_cls = t->d_cls; a.det_n = t->d_n; a.det_stride = t->Nc;
     return a;
@@ -151,6 +170,7 @@ int rtmodt_tracker_update(rtmodt_tracker *t, int stream, const float *xyxy, cons
     RT_CHECK(n == 0 || (xyxy && conf && cls), RTMODT_E_INVALID, "null detections");
     RT_CHECK(n <= t->Nc, RTMODT_E_CAPACITY, "%d detections > max_dets %d", n, t->Nc);
     RT_HIP(hipSetDevice(t->device));
+    RT_TRY(join_foreign(t));
     t->h_n[stream] = n;
     if (n) {
         RT_HIP(hipMemcpyAsync(t->d_box + (size_t)stream * t->Nc, xyxy, (size_t)n * 16, hipMemcpyHostToDevice, t->stream));
@@ -161,7 +181,6 @@ int rtmodt_tracker_update(rtmodt_tracker *t, int stream, const float *xyxy, cons
     TrackerArgs a = make_args(t);
     a.n_streams = 1; a.stream_base = stream;
     RT_TRY(launch_tracker_update(a, t->stream));
-    t->last_stream = t->stream;
     return finish(t, stream, 1, n_active_out);
 }
 
@@ -169,6 +188,7 @@ int rtmodt_tracker_update_batch(rtmodt_tracker *t, const float *xyxy, const floa
                                 int32_t *n_active_out) {
     RT_CHECK(t && n, RTMODT_E_INVALID, "null argument");
     RT_HIP(hipSetDevice(t->device));
+    RT_TRY(join_foreign(t));
     for (int s = 0; s < t->S; ++s) {
         RT_CHECK(n[s] >= 0 && n[s] <= t->Nc, RTMODT_E_CAPACITY, "stream %d: %d detections > max_dets %d", s, n[s], t->Nc);
         t->h_n[s] = n[s];
@@ -178,7 +198,6 @@ int rtmodt_tracker_update_batch(rtmodt_tracker *t, const float *xyxy, const floa
     RT_HIP(hipMemcpyAsync(t->d_cls, cls, (size_t)t->S * t->Nc * 4, hipMemcpyHostToDevice, t->stream));
     RT_HIP(hipMemcpyAsync(t->d_n, t->h_n, (size_t)t->S * 4, hipMemcpyHostToDevice, t->stream));
     RT_TRY(launch_tracker_update(make_args(t), t->stream));
-    t->last_stream = t->stream;
     return finish(t, 0, t->S, n_active_out);
 }
 
@@ -197,8 +216,11 @@ static int update_from_detector_slice(rtmodt_tracker *t, rtmodt_detector *det, i
     a.n_streams = count;
     a.det_box = o.box + (size_t)first * o.stride; a.det_conf = o.conf + (size_t)first * o.stride; a.det_cls = o.cls + (size_t)first * o.stride;
     a.det_n = o.n + first; a.det_stride = o.stride;
-    t->last_stream = o.stream;
-    return launch_tracker_update(a, o.stream);          // same HIP stream as the detector: ordered, no host sync
+    // (host-fed updates are synchronous -- finish() waits for them -- so the detector's stream needs no event from ours)
+    RT_TRY(launch_tracker_update(a, o.stream));          // same HIP stream as the detector's NMS: ordered, no host sync
+    RT_HIP(hipEventRecord(t->foreign_done, o.stream));
+    t->foreign_pending = true;
+    return RTMODT_OK;
 }
 
 int rtmodt_tracker_update_from_detector(rtmodt_tracker *t, rtmodt_detector *det) { return update_from_detector_slice(t, det, 0, -1); }
@@ -212,9 +234,10 @@ int rtmodt_tracker_state(rtmodt_tracker *t, int stream, int64_t *ids, float *xyx
                          int32_t *tsu, int32_t *n, int64_t *next_id) {
     RT_CHECK(t && stream >= 0 && stream < t->S, RTMODT_E_INVALID, "bad argument");
     RT_HIP(hipSetDevice(t->device));
-    // ordered behind the most recent update (own stream, or the detector's): meta first, then the arrays of the
-    // buffer it names, all through pinned memory -- two stream syncs instead of a device sync and seven blocking copies
-    hipStream_t q = t->last_stream;
+    // ordered behind the most recent update (own stream, or -- through its event -- a detector's): meta first, then the arrays
+    // of the buffer it names, all through pinned memory -- two stream syncs instead of a device sync and seven blocking copies
+    RT_TRY(join_foreign(t));
+    hipStream_t q = t->stream;
     int64_t *m = t->h_meta + 8 * stream;
     RT_HIP(hipMemcpyAsync(m, t->d_meta + 8 * stream, sizeof(int64_t) * 8, hipMemcpyDeviceToHost, q));
     RT_HIP(hipStreamSynchronize(q));
@@ -240,6 +263,51 @@ int rtmodt_tracker_state(rtmodt_tracker *t, int stream, int64_t *ids, float *xyx
         if (cls) memcpy(cls, h_cls, (size_t)cnt * 4);
         if (age) memcpy(age, h_age, (size_t)cnt * 4);
         if (tsu) memcpy(tsu, h_tsu, (size_t)cnt * 4);
+    }
+    return RTMODT_OK;
+}
+
+int rtmodt_tracker_enable_kalman(rtmodt_tracker *t) {
+    RT_CHECK(t, RTMODT_E_INVALID, "null argument");
+    if (t->kalman) return RTMODT_OK;
+    RT_HIP(hipSetDevice(t->device));
+    RT_TRY(join_foreign(t));
+    RT_HIP(hipMemcpyAsync(t->h_meta, t->d_meta, sizeof(int64_t) * 8 * t->S, hipMemcpyDeviceToHost, t->stream));
+    RT_HIP(hipStreamSynchronize(t->stream));
+    for (int s = 0; s < t->S; ++s)
+        RT_CHECK(t->h_meta[8 * s + 1] == 0, RTMODT_E_INVALID, "stream %d already holds tracks: enable the Kalman model before the first update (or after reset)", s);
+    const size_t per_buf = (size_t)t->Mc * 5 * sizeof(float4);
+    RT_HIP(hipMalloc((void **)&t->kf_pool, per_buf * 2 * t->S));
+    RT_HIP(hipMemset(t->kf_pool, 0, per_buf * 2 * t->S));
+    for (int s = 0; s < t->S; ++s)
+        for (int b = 0; b < 2; ++b) t->h_states[s].kf[b] = (float4 *)(t->kf_pool + per_buf * (2 * s + b));
+    RT_HIP(hipMemcpy(t->d_states, t->h_states.data(), sizeof(TrackerState) * t->S, hipMemcpyHostToDevice));
+    t->kalman = true;
+    return RTMODT_OK;
+}
+
+int rtmodt_tracker_kalman_state(rtmodt_tracker *t, int stream, float *mean, float *cov, int32_t *n) {
+    RT_CHECK(t && stream >= 0 && stream < t->S && n, RTMODT_E_INVALID, "bad argument");
+    RT_CHECK(t->kalman, RTMODT_E_INVALID, "the Kalman model is not enabled on this tracker");
+    RT_HIP(hipSetDevice(t->device));
+    RT_TRY(join_foreign(t));
+    int64_t *m = t->h_meta + 8 * stream;
+    RT_HIP(hipMemcpyAsync(m, t->d_meta + 8 * stream, sizeof(int64_t) * 8, hipMemcpyDeviceToHost, t->stream));
+    RT_HIP(hipStreamSynchronize(t->stream));
+    RT_TRY(check_sticky(t, stream, m[2]));
+    const int cur = (int)m[0], cnt = (int)m[1];
+    *n = cnt;
+    if (!cnt) return RTMODT_OK;
+    std::vector<float4> buf((size_t)5 * t->Mc);
+    RT_HIP(hipMemcpy(buf.data(), t->h_states[stream].kf[cur], buf.size() * sizeof(float4), hipMemcpyDeviceToHost));
+    for (int i = 0; i < cnt; ++i) {
+        const float4 pos = buf[i], vel = buf[t->Mc + i], pa = buf[2 * (size_t)t->Mc + i], pb = buf[3 * (size_t)t->Mc + i], pc = buf[4 * (size_t)t->Mc + i];
+        if (mean) { float *o = mean + 8 * (size_t)i; o[0] = pos.x; o[1] = pos.y; o[2] = pos.z; o[3] = pos.w; o[4] = vel.x; o[5] = vel.y; o[6] = vel.z; o[7] = vel.w; }
+        if (cov) {                                          // per coordinate (a, b, c) of [[a, b], [b, c]]
+            float *o = cov + 12 * (size_t)i;
+            o[0] = pa.x; o[1] = pb.x; o[2] = pc.x; o[3] = pa.y; o[4] = pb.y; o[5] = pc.y;
+            o[6] = pa.z; o[7] = pb.z; o[8] = pc.z; o[9] = pa.w; o[10] = pb.w; o[11] = pc.w;
+        }
     }
     return RTMODT_OK;
 }

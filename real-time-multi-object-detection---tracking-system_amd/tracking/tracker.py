@@ -44,7 +44,7 @@ class _ByteTrackCore:
 
     def __init__(self, track_thresh: float = 0.5, track_buffer: int = 30, match_thresh: float = 0.8, *,
                  device=0, max_tracks: int = 2048, max_dets: int = 1024, n_streams: int = 1,
-                 assign_mode: int = _ffi.ASSIGN_GREEDY) -> None:
+                 assign_mode: int = _ffi.ASSIGN_GREEDY, kalman: bool = False) -> None:
         self.track_thresh = track_thresh
         self.track_buffer = track_buffer
         self.match_thresh = match_thresh
@@ -57,6 +57,10 @@ class _ByteTrackCore:
         self.assign_mode = int(assign_mode)
         if self.assign_mode == _ffi.ASSIGN_LAPJV:        # tracker.py:170: cost_limit = 1 - thresh in Python doubles
             _ffi.check(_ffi.lib().rtmodt_tracker_set_cost_limit(self._h, float(1 - match_thresh)))
+        #: opt-in constant-velocity Kalman motion model (no reference counterpart; include/rtmodt.h)
+        self.kalman = bool(kalman)
+        if self.kalman:
+            _ffi.check(_ffi.lib().rtmodt_tracker_enable_kalman(self._h))
 
     # -- tracker.py:58-141 -------------------------------------------------------------
     def update(self, xyxy: np.ndarray, confidence: np.ndarray, class_id: np.ndarray, stream: int = 0) -> list:
@@ -103,6 +107,14 @@ class _ByteTrackCore:
         k = n.value
         return {"ids": ids[:k].copy(), "xyxy": box[:k].copy(), "conf": conf[:k].copy(), "cls": cls[:k].copy(),
                 "age": age[:k].copy(), "tsu": tsu[:k].copy(), "next_id": int(nid.value)}
+
+    def kalman_snapshot(self, stream: int = 0) -> dict:
+        """Filter state in list order: ``mean`` (n, 8) = (cx, cy, a, h, vx, vy, va, vh), ``cov`` (n, 12) = (a, b, c) of the
+        2x2 covariance block of each coordinate."""
+        mean, cov = np.empty((self.max_tracks, 8), np.float32), np.empty((self.max_tracks, 12), np.float32)
+        n = C.c_int32(0)
+        _ffi.check(_ffi.lib().rtmodt_tracker_kalman_state(self._h, stream, _ffi.ptr(mean), _ffi.ptr(cov), C.byref(n)))
+        return {"mean": mean[:n.value].copy(), "cov": cov[:n.value].copy()}
 
     def tracks(self, stream: int = 0) -> list:
         s = self.snapshot(stream)
@@ -156,6 +168,7 @@ class MultiObjectTracker:
                 max_tracks=p.get("max_tracks", 2048),
                 max_dets=p.get("max_dets", 1024),
                 assign_mode={"greedy": _ffi.ASSIGN_GREEDY, "lapjv": _ffi.ASSIGN_LAPJV}[self.assignment],
+                kalman=bool(p.get("kalman", kwargs.get("kalman", False))),
             )
         elif self.algorithm == "deepsort":
             raise NotImplementedError("DeepSORT adapter not yet wired. Use bytetrack.")

@@ -216,34 +216,71 @@ def iou_1to1(a, b):
     return inter / ((a[:, 2] - a[:, 0]) * (a[:, 3] - a[:, 1]) + (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1]) - inter + 1e-9)
 
 
-def test_end_to_end_vs_fp32_oracle(pkg, wdir):
-    """Whole pipeline, fp16 engine vs all-fp32 oracle, 1080p source (real letterbox):
-    every oracle detection whose score clears the thresholds by a margin is found by the
-    engine with IoU >= 0.99 and the same class (north_star tolerance)."""
-    det, w = make_detector(pkg, wdir, "s", 640, classes=[0, 1, 2, 3, 5, 7, 17, 18], max_det=300)
-    frame = np.ascontiguousarray(pkg.synth.frames(1, 1080, 1920, seed=5)[0])
+def match_report(rx, rc, rk, d, thr):
+    """For every oracle detection with score > thr: best-IoU engine detection of the same class."""
+    rows = []
+    for i in np.nonzero(rc > thr)[0]:
+        same = np.nonzero(d.class_id == rk[i])[0]
+        if len(same) == 0:
+            rows.append((int(i), float(rc[i]), 0.0, -1))
+            continue
+        ious = iou_1to1(np.repeat(rx[i:i + 1], len(same), 0), d.xyxy[same])
+        j = int(np.argmax(ious))
+        rows.append((int(i), float(rc[i]), float(ious[j]), int(same[j])))
+    return rows
+
+
+@pytest.mark.parametrize("src_hw,seed", [((1080, 1920), 5), ((640, 640), 1234), ((720, 1280), 77)])
+def test_end_to_end_vs_fp32_oracle(pkg, wdir, src_hw, seed):
+    """Whole pipeline, FREE-RUNNING fp16 engine vs all-fp32 oracle (no teacher forcing: the drift of 63 fp16 convs is in).
+    north_star: IoU >= 0.99 per box, identical NMS survivors.  What is asserted, and printed with -s:
+      (1) head logits: max and p99 |engine - oracle| over the three Detect maps (box and class logits separately);
+      (2) pre-NMS tensor: boxes within 1 % of their extent + 0.5 px, scores within 0.03;
+      (3) NMS on the engine's own pre-NMS tensor: bit-exact (identical survivors given identical inputs);
+      (4) every oracle detection whose score clears the confidence threshold by more than the measured score drift is
+          reproduced with IoU >= 0.99 and the same class.  Oracle detections closer to the threshold than that may flip
+          (their score crosses 0.35 in one net and not the other) -- the only allowed kind of miss; they are counted."""
+    h, w = src_hw
+    classes = [0, 1, 2, 3, 5, 7, 17, 18]
+    det, wts = make_detector(pkg, wdir, "s", 640, classes=classes, max_det=300)
+    frame = np.ascontiguousarray(pkg.synth.frames(1, h, w, seed=seed)[0])
     d = det.detect(frame)
-    (rx, rc, rk), im = Y.detect(frame, w, "s", (640, 640), 0.35, 0.45, [0, 1, 2, 3, 5, 7, 17, 18], 300, return_intermediate=True)
-    _, _, pred = det.debug_fetch(0, want_input=False, want_heads=False)
-    # (1) pre-NMS tensors agree to fp16 tolerance
+    (rx, rc, rk), im = Y.detect(frame, wts, "s", (640, 640), 0.35, 0.45, classes, 300, return_intermediate=True)
+    _, heads, pred = det.debug_fetch(0, want_input=False)
+    # (1) free-running head logits
+    off, box_err, cls_err = 0, [], []
+    for lvl, s_ in enumerate((80, 40, 20)):
+        g = heads[off:off + s_ * s_ * 144].reshape(s_, s_, 144).astype(np.float32); off += s_ * s_ * 144
+        e = np.abs(g - im["heads"][lvl])
+        box_err.append(e[..., :64].ravel()); cls_err.append(e[..., 64:].ravel())
+    box_err, cls_err = np.concatenate(box_err), np.concatenate(cls_err)
+    stats = dict(box_max=float(box_err.max()), box_p99=float(np.percentile(box_err, 99)), cls_max=float(cls_err.max()), cls_p99=float(np.percentile(cls_err, 99)))
+    print(f"free-running head logits {src_hw}: box max {stats['box_max']:.4f} p99 {stats['box_p99']:.4f}; cls max {stats['cls_max']:.4f} p99 {stats['cls_p99']:.4f}")
+    assert stats["box_p99"] < 0.05 and stats["cls_p99"] < 0.05 and stats["box_max"] < 0.5 and stats["cls_max"] < 0.5, stats
+    # (2) pre-NMS tensors agree to fp16 tolerance
     cand = im["pred"][4:].max(0) > 0.2
     extent = np.maximum(im["pred"][2, cand], im["pred"][3, cand])             # box size in pixels (P5 boxes are ~480 px wide)
     assert np.all(np.abs(pred[:4, cand] - im["pred"][:4, cand]) <= 0.01 * extent + 0.5)      # fp16 net vs fp32 net: 1 % of the box + half a pixel
-    assert np.abs(pred[4:] - im["pred"][4:]).max() < 0.03
-    # (2) NMS on the engine's tensor is exact
-    dets, _ = Y.non_max_suppression(pred, 0.35, 0.45, [0, 1, 2, 3, 5, 7, 17, 18], False, 300)
-    assert np.array_equal(d.xyxy.view(np.int32), Y.scale_boxes(dets[:, :4], 640, 640, 1080, 1920).view(np.int32))
-    # (3) confident oracle detections are reproduced
-    strong = rc > 0.45
-    assert strong.sum() >= 5
-    hit = 0
-    for i in np.nonzero(strong)[0]:
-        ious = iou_1to1(np.repeat(rx[i:i + 1], len(d), 0), d.xyxy) if len(d) else np.zeros(0)
-        j = int(np.argmax(ious)) if len(d) else -1
-        if j >= 0 and ious[j] >= 0.99 and d.class_id[j] == rk[i]:
-            hit += 1
-    assert hit >= 0.9 * strong.sum(), f"{hit}/{strong.sum()} confident oracle detections matched with IoU >= 0.99"
-    assert np.all(d.xyxy[:, [0, 2]] >= 0) and np.all(d.xyxy[:, [0, 2]] <= 1920) and np.all(d.xyxy[:, [1, 3]] <= 1080)
+    score_drift = float(np.abs(pred[4:] - im["pred"][4:]).max())
+    assert score_drift < 0.03
+    # (3) NMS on the engine's tensor is exact
+    dets, _ = Y.non_max_suppression(pred, 0.35, 0.45, classes, False, 300)
+    assert np.array_equal(d.xyxy.view(np.int32), Y.scale_boxes(dets[:, :4], 640, 640, h, w).view(np.int32))
+    # (4) per-box reproduction
+    margin = 0.35 + 2 * score_drift + 1e-3
+    rows = match_report(rx, rc, rk, d, 0.35)
+    clear = [r for r in rows if r[1] > margin]
+    near = [r for r in rows if r[1] <= margin]
+    bad = [r for r in clear if r[2] < 0.99]
+    frac_all = np.mean([r[2] >= 0.99 for r in rows]) if rows else 1.0
+    print(f"end to end {src_hw}: {len(rows)} oracle detections, {len(d)} engine detections, score drift {score_drift:.4f}; "
+          f"IoU >= 0.99 + same class: {sum(r[2] >= 0.99 for r in rows)}/{len(rows)} = {frac_all:.4f}; "
+          f"within {margin - 0.35:.4f} of the threshold: {len(near)} (missed {sum(r[2] < 0.99 for r in near)}); clear of it: {len(clear)} (missed {len(bad)}) {bad[:5]}")
+    assert len(clear) >= 5
+    # a clear detection may still be absent when a near-threshold box that suppresses it (or that it suppresses) flipped: count, bound
+    assert len(bad) <= 0.02 * len(clear), bad
+    assert frac_all >= 0.95, frac_all
+    assert np.all(d.xyxy[:, [0, 2]] >= 0) and np.all(d.xyxy[:, [0, 2]] <= w) and np.all(d.xyxy[:, [1, 3]] <= h)
     det.close()
 
 

@@ -195,3 +195,74 @@ def test_lapjv_too_dense_is_an_error(pkg):
     with pytest.raises(pkg._ffi.RtmodtError) as e:
         pkg._ffi.assign_lapjv(iou, 0.8)
     assert e.value.code == pkg._ffi.E_CAPACITY
+
+
+# ------------------------------------------------------------------ opt-in Kalman motion model (no reference counterpart)
+def kalman_equal(core, orc, stream=0, tag=""):
+    s, k, o = core.snapshot(stream), core.kalman_snapshot(stream), orc.snapshot()
+    for key in KEYS:
+        assert np.array_equal(bits(s[key]), bits(o[key])), (tag, key)
+    assert s["next_id"] == o["next_id"], tag
+    assert np.array_equal(k["mean"].view(np.int32), o["mean"].view(np.int32)), (tag, "mean")
+    assert np.array_equal(k["cov"].view(np.int32), o["cov"].view(np.int32)), (tag, "cov")
+
+
+def test_kalman_tracker_bit_exact_vs_oracle(pkg):
+    """MultiObjectTracker(kalman=True): predict / associate on predicted boxes / update / initiate inside the one launch.
+    Ids, ages, tsu, boxes AND the filter state (mean[8], covariance blocks) equal the NumPy oracle bit for bit, on the
+    accelerating scene that the parity tracker cannot follow, on the jittery 200-box sequence of BASELINE config 3 with
+    empty and sparse frames mixed in, and after the tracks have been compacted (expiry)."""
+    from oracle import kalman_oracle as K
+    from test_oracle_kalman import accelerating_scene
+    boxes, conf, cls = accelerating_scene()
+    trk = pkg.MultiObjectTracker("bytetrack", kalman=True)
+    assert trk._core.kalman is True
+    orc = K.TrackerOracleKalman()
+    for f, b in enumerate(boxes):
+        if f == 90:
+            b, c, k = np.zeros((0, 4), np.float32), np.zeros(0, np.float32), np.zeros(0, np.int32)
+        else:
+            c, k = conf, cls
+        assert trk.update(pkg.Detections(b, c, k)) == []
+        orc.update(b, c, k)
+        kalman_equal(trk._core, orc, tag=f"accelerating frame {f}")
+    assert orc.next_id - 1 == len(conf)                      # no track was ever lost
+    # config 3's sequence: 200 boxes, jitter, low-confidence second pass, expiry after track_buffer frames
+    xy, cf, cl = pkg.synth.box_sequence(200, 640, 70, seed=1234)
+    trk2 = pkg.MultiObjectTracker("bytetrack", kalman=True, track_buffer=8)
+    orc2 = K.TrackerOracleKalman(track_buffer=8)
+    rng = np.random.default_rng(0)
+    for f in range(70):
+        keep = rng.uniform(size=200) < (0.0 if f in (20, 21) else 0.5 if 30 <= f < 45 else 1.0)
+        b, c, k = xy[f][keep], cf[keep], cl[keep]
+        trk2.update(pkg.Detections(b, c, k))
+        orc2.update(b, c, k)
+        kalman_equal(trk2._core, orc2, tag=f"config-3 frame {f}")
+    assert orc2.next_id > 201 and len(orc2.ids) < orc2.next_id - 1      # tracks were lost, respawned and expired along the way
+
+
+def test_kalman_multi_stream_and_enable_rules(pkg):
+    from importlib import import_module
+    from oracle import kalman_oracle as K
+    core_cls = import_module(pkg.__name__ + ".tracking.tracker")._ByteTrackCore
+    S, N = 3, 64
+    core = core_cls(n_streams=S, max_dets=N, max_tracks=256, kalman=True)
+    orcs = [K.TrackerOracleKalman() for _ in range(S)]
+    seqs = [pkg.synth.box_sequence(40 + 8 * s, 640, 25, seed=70 + s) for s in range(S)]
+    for f in range(25):
+        xyxy, conf, cls, cnt = np.zeros((S, N, 4), np.float32), np.zeros((S, N), np.float32), np.zeros((S, N), np.int32), np.zeros(S, np.int32)
+        for s in range(S):
+            n = 0 if (f + s) % 9 == 8 else len(seqs[s][1])
+            xyxy[s, :n], conf[s, :n], cls[s, :n], cnt[s] = seqs[s][0][f][:n], seqs[s][1][:n], seqs[s][2][:n], n
+            orcs[s].update(xyxy[s, :n], conf[s, :n], cls[s, :n])
+        core.update_batch(xyxy, conf, cls, cnt)
+        for s in range(S):
+            kalman_equal(core, orcs[s], stream=s, tag=f"stream {s} frame {f}")
+    core.close()
+    plain = core_cls(n_streams=1, max_dets=N, max_tracks=256)
+    with pytest.raises(pkg._ffi.RtmodtError):
+        plain.kalman_snapshot()                              # not enabled
+    plain.update(seqs[0][0][0], seqs[0][1], seqs[0][2])
+    with pytest.raises(pkg._ffi.RtmodtError):
+        pkg._ffi.check(pkg._ffi.lib().rtmodt_tracker_enable_kalman(plain._h))      # tracks already exist
+    plain.close()
