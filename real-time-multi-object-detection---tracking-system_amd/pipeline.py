@@ -55,9 +55,14 @@ class PinnedFrameRing:
 
 
 def run(source, detector, tracker, profiler: Optional[LatencyProfiler] = None, max_frames: int = 200,
-        device_stages: bool = True, event_engine=None) -> dict:
+        device_stages: bool = True, event_engine=None, device_handoff: bool = True) -> dict:
     """Runs ``max_frames`` iterations of the reference loop; returns ``profiler.summary(p50=True)``
-    plus the last frame's detections and tracks."""
+    plus the last frame's detections and tracks.
+
+    ``device_handoff`` (default): the tracker consumes the detector's detections where they are, on the device, and the
+    zone engine the tracker's device-resident state (``tracker.update_from_detector`` / ``event_engine.process_tracker``);
+    the host receives the detections (as the reference's ``Detector._parse`` does) and the events, never the track arrays.
+    ``False``: the reference's literal data flow -- ``tracker.update(detections)`` on host arrays, ``process(tracks)``."""
     profiler = profiler or LatencyProfiler(gpu_sync=True, warmup_frames=50, log_interval=100)
     detections = tracks = None
     n_events = 0
@@ -77,17 +82,24 @@ def run(source, detector, tracker, profiler: Optional[LatencyProfiler] = None, m
             profiler.record("preprocess", pre)
             profiler.record("nms", nms)
             profiler.record("inference", max(total_inf - pre - nms, 0.0))
+        handoff = device_handoff and hasattr(tracker, "update_from_detector") and hasattr(detector, "model")
         profiler.tick("tracking")
-        tracks = tracker.update(detections)
+        tracks = tracker.update_from_detector(detector, materialize=event_engine is None) if handoff else tracker.update(detections)
         profiler.tock("tracking")
         if event_engine is not None:                       # tools/run_pipeline.py:141-146
             profiler.tick("events")
-            n_events += len(event_engine.process(tracks, fid))
+            if handoff and hasattr(event_engine, "process_tracker"):
+                n_events += len(event_engine.process_tracker(tracker, fid, class_names=getattr(detector.model, "names", None))[0])
+            else:
+                n_events += len(event_engine.process(tracks, fid))
             profiler.tock("events")
         profiler.end_frame()
     out = profiler.summary(p50=True)
     out["frames"] = max_frames
     out["last_detections"] = 0 if detections is None else len(detections)
-    out["last_tracks"] = 0 if tracks is None else len(tracks)
+    if device_handoff and hasattr(tracker, "_core") and getattr(tracker, "report", "") == "matched":
+        out["last_tracks"] = int((tracker._core.snapshot(0)["tsu"] == 1).sum())      # read back once, after the loop
+    else:
+        out["last_tracks"] = 0 if tracks is None else len(tracks)
     out["events"] = n_events
     return out

