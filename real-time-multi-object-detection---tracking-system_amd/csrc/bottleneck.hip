@@ -55,6 +55,24 @@ struct BneckArgs {
 
 constexpr int BN_THREADS = 512, BN_WAVES = 8;
 
+// Diagnostic build only (tools/probes/kernel_probe.hip, -DRTMODT_STAMP): lane 0 of every workgroup writes the shader clock at
+// phase boundaries into a buffer of its own; no product build contains a stamp.
+#ifdef RTMODT_STAMP
+__device__ unsigned long long *g_stamps;
+#define STAMP(k)                                                                                         \
+    do {                                                                                                 \
+        __builtin_amdgcn_sched_barrier(0);                                                               \
+        if (threadIdx.x == 0) {                                                                          \
+            unsigned long long t_;                                                                       \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                    \
+            g_stamps[(size_t)blockIdx.x * 16 + (k)] = t_;                                                \
+        }                                                                                                \
+        __builtin_amdgcn_sched_barrier(0);                                                               \
+    } while (0)
+#else
+#define STAMP(k)
+#endif
+
 template <int CH, int TH, int TW>
 struct BneckGeom {
     static constexpr int CW = CH < 64 ? CH : 64;          // channels per LDS plane
@@ -70,9 +88,12 @@ struct BneckGeom {
     static constexpr int M2 = TW * TH, M2T = M2 / 16;
     static constexpr int TM1 = (M1T + BN_WAVES - 1) / BN_WAVES, TM2 = (M2T + BN_WAVES - 1) / BN_WAVES;
     static constexpr int W_PIECES = CH / RPP;             // DMA pieces per (tap, plane) of weights
-    static constexpr int W_STEP = CH * CB;                // bytes of one weight stage
+    static constexpr int W_STEP = CH * CB;                // bytes of one weight unit: (tap, plane)
+    static constexpr bool ALLW = CH == 32;                // a conv's whole weight matrix (18 KiB) sits in ONE LDS buffer: no ring, no barrier in the k-loop
+    static constexpr int UPS = CH == 64 ? 3 : 1;          // units per ring stage: 24 KiB (one kernel row of c = 64), 16 KiB (c = 128: one (tap, plane))
+    static constexpr int W_STAGE = UPS * W_STEP;
     static constexpr int PATCH_BYTES = NCH * P_ROWS * CB, T_BYTES = NCH * T_ROWS * CB;
-    static constexpr int LDS_BYTES = PATCH_BYTES + T_BYTES + 2 * W_STEP;
+    static constexpr int LDS_BYTES = PATCH_BYTES + T_BYTES + (ALLW ? 9 * NCH * W_STEP : 2 * W_STAGE);
     static_assert(M2 % 16 == 0, "tile must hold whole 16-pixel MFMA tiles");
     // tail variant (C2f.cv2 fused): y tile + 2 CH channels of the concat for the tile's pixels + the 1x1's weights, or its output tile
     static constexpr int LDS_TAIL = 152 * 1024;
@@ -87,21 +108,26 @@ __device__ __forceinline__ int plane_off(int R, int c16) {
 
 // One conv of the pair as an implicit GEMM from an LDS image.  src: planes [NCH][rows][CB];
 // SW = row width of that image; my_pb[i] = LDS pixel index (tap 0,0) of this lane's row in the
-// wave's i-th m-tile.  Weights stream through wring (2 stages), one (tap, plane) per step.
+// wave's i-th m-tile.  Weights stream through wring (2 stages); a stage holds UPS "units" (a unit = one (tap, plane):
+// CH couts x CW channels), so there is one wait + barrier per UPS units -- with one unit per stage (the first version) a
+// c = 32 conv met a barrier every 6 MFMAs per wave and a c = 64 one every 24; three taps per stage (c = 64) is a
+// barrier per 72, all nine (c = 32) one per conv.
 template <typename G, int TM, int SW, int SRC_ROWS>
 __device__ __forceinline__ void gemm_from_lds(const unsigned char *src, unsigned char *wring, const f16 *w, int kp, const int (&my_pb)[TM],
                                               floatx4 (&acc)[TM][G::NT], int lane, int wave) {
-    constexpr int CB = G::CB, NCH = G::NCH, RPP = G::RPP, SUB = G::SUB, NT = G::NT;
-    constexpr int STEPS = 9 * NCH;
+    constexpr int CB = G::CB, NCH = G::NCH, RPP = G::RPP, SUB = G::SUB, NT = G::NT, UPS = G::UPS;
+    constexpr int UNITS = 9 * NCH, STEPS = UNITS / UPS;
+    static_assert(UNITS % UPS == 0, "units per stage must divide the 9 * planes units of a conv");
     const int r = lane & 15, q = lane >> 4;
     const int ld_row = CB == 128 ? lane >> 3 : lane >> 2, ld_slot = CB == 128 ? lane & 7 : lane & 3;
     auto issue = [&](int step) {
-        const int tap = step / NCH, plane = step - tap * NCH;
-        unsigned char *dst = wring + (step & 1) * G::W_STEP;
-        for (int pc = wave; pc < G::W_PIECES; pc += BN_WAVES) {
+        unsigned char *dst = wring + (step & 1) * G::W_STAGE;
+        for (int idx = wave; idx < UPS * G::W_PIECES; idx += BN_WAVES) {
+            const int un = idx / G::W_PIECES, pc = idx - un * G::W_PIECES;
+            const int unit = step * UPS + un, tap = unit / NCH, plane = unit - tap * NCH;
             int row = pc * RPP + ld_row;
             int c16 = CB == 128 ? (ld_slot ^ ((row >> 1) & 7)) : (ld_slot ^ (((row >> 3) & 1) * 3));
-            dma16(w + ((long)row * kp + tap * (NCH * G::CW) + plane * G::CW + c16 * 8), dst + pc * 1024);
+            dma16(w + ((long)row * kp + tap * (NCH * G::CW) + plane * G::CW + c16 * 8), dst + un * G::W_STEP + pc * 1024);
         }
     };
     issue(0);
@@ -110,11 +136,57 @@ __device__ __forceinline__ void gemm_from_lds(const unsigned char *src, unsigned
         __builtin_amdgcn_s_barrier();                       // weights of `step` landed; everyone left step-1
         asm volatile("" ::: "memory");
         if (step + 1 < STEPS) issue(step + 1);
-        const int tap = step / NCH, plane = step - tap * NCH;
+#pragma unroll
+        for (int un = 0; un < UPS; ++un) {
+            const int unit = step * UPS + un, tap = unit / NCH, plane = unit - tap * NCH;
+            const int kh = tap / 3, kw = tap - kh * 3;
+            const int toff = kh * SW + kw;
+            const unsigned char *splane = src + plane * (SRC_ROWS * CB);
+            const unsigned char *wst = wring + (step & 1) * G::W_STAGE + un * G::W_STEP;
+#pragma unroll
+            for (int kk = 0; kk < SUB; ++kk) {
+                half8 fa[TM], fb[NT];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) fa[i] = *(const half8 *)(splane + plane_off<CB>(my_pb[i] + toff, kk * 4 + q));
+#pragma unroll
+                for (int u = 0; u < NT; ++u) fb[u] = *(const half8 *)(wst + plane_off<CB>(u * 16 + r, kk * 4 + q));
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int u = 0; u < NT; ++u) acc[i][u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[u], fa[i], acc[i][u], 0, 0, 0);
+            }
+        }
+    }
+}
+
+// c = 32: a conv's whole weight matrix is 18 KiB -- ONE LDS buffer holds it, loaded by DMA in one go (w1 together with the
+// input patch, w2 underneath conv1's epilogue), and the k-loop over the nine taps meets no wait and no barrier.  (Measured
+// with the phase stamps of tools/probes/kernel_probe.hip: with one (tap, plane) unit per ring stage a c = 32 conv spent
+// 8000 clk in a k-loop of 860 clk of MFMA per wave -- a barrier every 6 MFMAs; weights in REGISTERS instead cost each of the
+// 8 waves its own copy of the matrix through the global load path, 8x the bytes, and gave the gain back.)
+template <typename G>
+__device__ __forceinline__ void allw_issue(unsigned char *wbuf, const f16 *w, int kp, int lane, int wave) {
+    constexpr int CB = G::CB, NCH = G::NCH, RPP = G::RPP;
+    const int ld_row = CB == 128 ? lane >> 3 : lane >> 2, ld_slot = CB == 128 ? lane & 7 : lane & 3;
+    for (int idx = wave; idx < 9 * NCH * G::W_PIECES; idx += BN_WAVES) {
+        const int unit = idx / G::W_PIECES, pc = idx - unit * G::W_PIECES;
+        const int tap = unit / NCH, plane = unit - tap * NCH;
+        int row = pc * RPP + ld_row;
+        int c16 = CB == 128 ? (ld_slot ^ ((row >> 1) & 7)) : (ld_slot ^ (((row >> 3) & 1) * 3));
+        dma16(w + ((long)row * kp + tap * (NCH * G::CW) + plane * G::CW + c16 * 8), wbuf + unit * G::W_STEP + pc * 1024);
+    }
+}
+template <typename G, int TM, int SW, int SRC_ROWS>
+__device__ __forceinline__ void gemm_allw(const unsigned char *src, const unsigned char *wbuf, const int (&my_pb)[TM], floatx4 (&acc)[TM][G::NT], int lane) {
+    constexpr int CB = G::CB, NCH = G::NCH, SUB = G::SUB, NT = G::NT;
+    const int r = lane & 15, q = lane >> 4;
+#pragma unroll
+    for (int unit = 0; unit < 9 * NCH; ++unit) {
+        const int tap = unit / NCH, plane = unit - tap * NCH;
         const int kh = tap / 3, kw = tap - kh * 3;
         const int toff = kh * SW + kw;
         const unsigned char *splane = src + plane * (SRC_ROWS * CB);
-        const unsigned char *wst = wring + (step & 1) * G::W_STEP;
+        const unsigned char *wst = wbuf + unit * G::W_STEP;
 #pragma unroll
         for (int kk = 0; kk < SUB; ++kk) {
             half8 fa[TM], fb[NT];
@@ -145,6 +217,7 @@ __global__ __launch_bounds__(BN_THREADS) void bottleneck_fused(BneckArgs p) {
     const int tx = blockIdx.x % p.tiles_x, ty = (blockIdx.x / p.tiles_x) % p.tiles_y, b = blockIdx.x / (p.tiles_x * p.tiles_y);
     const int x0 = tx * TW, y0 = ty * TH;
 
+    STAMP(0);
     // ---- 0. input patch -> LDS (2-pixel halo; outside the bordered tensor: zero page) ----
     {
         const int ld_row = CB == 128 ? lane >> 3 : lane >> 2, ld_slot = CB == 128 ? lane & 7 : lane & 3;
@@ -179,7 +252,19 @@ __global__ __launch_bounds__(BN_THREADS) void bottleneck_fused(BneckArgs p) {
         for (int i = 0; i < G::TM1; ++i)
 #pragma unroll
             for (int u = 0; u < NT; ++u) acc[i][u] = *(const floatx4 *)(p.b1 + u * 16 + q * 4);   // bias as the initial accumulator
-        gemm_from_lds<G, G::TM1, G::PW, G::P_ROWS>(patch, wring, p.w1, p.kp, pb, acc, lane, wave);
+        STAMP(1);
+        if constexpr (G::ALLW) {
+            allw_issue<G>(wring, p.w1, p.kp, lane, wave);       // in flight together with the patch
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();                                    // the input patch and w1 have landed
+            STAMP(2);
+            gemm_allw<G, G::TM1, G::PW, G::P_ROWS>(patch, wring, pb, acc, lane);
+            __syncthreads();                                    // every wave is done with w1
+            allw_issue<G>(wring, p.w2, p.kp, lane, wave);       // w2 arrives underneath the epilogue below
+        } else {
+            gemm_from_lds<G, G::TM1, G::PW, G::P_ROWS>(patch, wring, p.w1, p.kp, pb, acc, lane, wave);
+        }
+        STAMP(3);
         // epilogue 1: SiLU -> fp16 -> tbuf; positions outside the image are conv2's zero padding
 #pragma unroll
         for (int i = 0; i < G::TM1; ++i) {
@@ -198,7 +283,9 @@ __global__ __launch_bounds__(BN_THREADS) void bottleneck_fused(BneckArgs p) {
             }
         }
     }
-    __syncthreads();                                            // tbuf complete; weight ring free again
+    if constexpr (G::ALLW) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // w2
+    __syncthreads();                                            // tbuf complete; weight ring free again (ALLW: w2 landed)
+    STAMP(4);
 
     // ---- 2. conv2 over the tile ----
     {
@@ -218,7 +305,9 @@ __global__ __launch_bounds__(BN_THREADS) void bottleneck_fused(BneckArgs p) {
         for (int i = 0; i < G::TM2; ++i)
 #pragma unroll
             for (int u = 0; u < NT; ++u) acc[i][u] = *(const floatx4 *)(p.b2 + u * 16 + q * 4);
-        gemm_from_lds<G, G::TM2, G::IW, G::T_ROWS>(tbuf, wring, p.w2, p.kp, pb, acc, lane, wave);
+        if constexpr (G::ALLW) gemm_allw<G, G::TM2, G::IW, G::T_ROWS>(tbuf, wring, pb, acc, lane);
+        else gemm_from_lds<G, G::TM2, G::IW, G::T_ROWS>(tbuf, wring, p.w2, p.kp, pb, acc, lane, wave);
+        STAMP(5);
         // epilogue 2: SiLU (+ residual) in fp32, one rounding, staged as a [pixel][channel] fp16 tile in the (dead) patch
         // region so that every lane then stores 16 bytes -- whole cache lines of the NHWC output per wave instruction
         constexpr int ROWB = CH * 2 + 16;
@@ -263,6 +352,7 @@ __global__ __launch_bounds__(BN_THREADS) void bottleneck_fused(BneckArgs p) {
             static_assert(W_OFF + K2C * N2T * 1024 <= G::LDS_TAIL && G::M2 * ROWO <= G::LDS_TAIL, "tail buffers");
             static_assert(M2T % BN_WAVES == 0, "pixel tiles must split over the waves");
             __syncthreads();                                   // y tile complete; tbuf / weight ring free
+            STAMP(6);
             {
                 const int ld_row = lane >> 2, ld_chunk = (lane & 3) ^ (((ld_row >> 3) & 1) * 3);
                 for (int pi = wave; pi < K1C * M2T; pi += BN_WAVES) {       // earlier C2f chunks of this tile's pixels
@@ -286,6 +376,7 @@ __global__ __launch_bounds__(BN_THREADS) void bottleneck_fused(BneckArgs p) {
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
+            STAMP(7);
             const int rd_off = r * 64 + ((q ^ (((r >> 3) & 1) * 3)) << 4);
 #pragma unroll
             for (int kc = 0; kc < K2C; ++kc) {
@@ -304,6 +395,7 @@ __global__ __launch_bounds__(BN_THREADS) void bottleneck_fused(BneckArgs p) {
                     for (int u = 0; u < N2T; ++u) acc2[i][u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[u], fa[i], acc2[i][u], 0, 0, 0);
             }
             __syncthreads();                                   // every wave is done with the y tile and the operands
+            STAMP(8);
 #pragma unroll
             for (int i = 0; i < TMT; ++i) {
                 const int m = (wave + BN_WAVES * i) * 16 + r;
@@ -326,6 +418,7 @@ __global__ __launch_bounds__(BN_THREADS) void bottleneck_fused(BneckArgs p) {
             }
         }
     }
+    STAMP(9);
 }
 
 template <int CH, int TH, int TW, int N2T = 0>

@@ -905,7 +905,7 @@ def test_neck_concat_read_from_half_resolution(pkg, wdir, monkeypatch, size, bat
 
 
 def test_benchmarked_shape_parity(pkg, wdir):
-    """BASELINE config 4's per-GPU shard exactly as bench.py builds it: YOLOv8s @ 640, batch 16 (8 streams x 2 consecutive
+    """BASELINE config 4's per-GPU shard exactly as bench.py builds it: YOLOv8s @ 640, batch 32 (8 streams x 4 consecutive
     frames), autotuned tiles, three-stage engine, S + 1 batches in flight, tracker fed on the device.
       * every stored layer of images 0 and 15 of the last batch within fp16 tolerance of the fp32 oracle (teacher-forced);
       * NMS survivors, boxes, scores, classes of all 16 images bit-equal to oracle NMS on the engine's own pre-NMS tensor;
@@ -914,7 +914,7 @@ def test_benchmarked_shape_parity(pkg, wdir):
     from oracle import tracker_oracle as T
     from importlib import import_module
     core_cls = import_module(pkg.__name__ + ".tracking.tracker")._ByteTrackCore
-    S, F, steps, size = 8, 2, 6, 640
+    S, F, steps, size = 8, 4, 6, 640
     B = S * F
     det, w = make_detector(pkg, wdir, "s", size, batch=B, autotune=True, chains=-2, max_det=100)
     assert det.model.stages == 3, "the bench configuration needs all four hardware queues of the process"

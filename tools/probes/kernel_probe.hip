@@ -1,0 +1,87 @@
+// kernel_probe.hip -- DIAGNOSTIC build of single kernels of librtmodt_hip.so with in-kernel phase stamps (s_memtime by lane 0
+// of every workgroup, -DRTMODT_STAMP) on synthetic tensors of the benchmarked shapes; prints per-phase cycle shares and the
+// workgroup timeline.  Read its SHARES, never its run time (the stamps fence the scheduler).
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -DRTMODT_STAMP -o /tmp/kernel_probe tools/probes/kernel_probe.hip && /tmp/kernel_probe
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "../../real-time-multi-object-detection---tracking-system_amd/csrc/bottleneck.hip"
+
+namespace rtmodt {
+std::string &last_error() { static std::string e; return e; }
+int fail(int code, const char *fmt, ...) { va_list ap; va_start(ap, fmt); vfprintf(stderr, fmt, ap); va_end(ap); fputc('\n', stderr); return code; }
+}
+using namespace rtmodt;
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s -> %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
+
+static int run_bneck(int c, int HW, int B, bool tail) {
+    const int C = 3 * c;                                        // the C2f concat tensor: [y0 | y1 | y2]
+    const size_t per = (size_t)(HW + 2) * (HW + 2);
+    f16 *cat, *outt, *w1, *w2, *wt, *zeros; float *b1, *b2, *bt;
+    CK(hipMalloc(&cat, per * B * C * 2)); CK(hipMemset(cat, 0, per * B * C * 2));
+    CK(hipMalloc(&outt, per * B * 2 * c * 2)); CK(hipMemset(outt, 0, per * B * 2 * c * 2));
+    std::vector<f16> hw((size_t)128 * 9 * c);
+    for (auto &v : hw) v = (f16)(((rand() % 200) - 100) * 1e-3f);
+    CK(hipMalloc(&w1, hw.size() * 2)); CK(hipMemcpy(w1, hw.data(), hw.size() * 2, hipMemcpyHostToDevice));
+    CK(hipMalloc(&w2, hw.size() * 2)); CK(hipMemcpy(w2, hw.data(), hw.size() * 2, hipMemcpyHostToDevice));
+    CK(hipMalloc(&wt, (size_t)128 * 3 * c * 2)); CK(hipMemcpy(wt, hw.data(), (size_t)128 * 3 * c * 2, hipMemcpyHostToDevice));
+    CK(hipMalloc(&zeros, 256)); CK(hipMemset(zeros, 0, 256));
+    CK(hipMalloc(&b1, 512)); CK(hipMemset(b1, 0, 512)); CK(hipMalloc(&b2, 512)); CK(hipMemset(b2, 0, 512)); CK(hipMalloc(&bt, 512)); CK(hipMemset(bt, 0, 512));
+    {   // random activations
+        std::vector<f16> h(per * B * C);
+        for (auto &v : h) v = (f16)(((rand() % 2000) - 1000) * 1e-3f);
+        CK(hipMemcpy(cat, h.data(), h.size() * 2, hipMemcpyHostToDevice));
+    }
+    BottleneckLaunch l;
+    auto view = [&](f16 *base, int Ct, int coff, int cc) { TensorView v; v.base = base; v.H = v.W = HW; v.C = Ct; v.pad = 1; v.coff = coff; v.c = cc; return v; };
+    l.in = view(cat, C, c, c); l.out = view(cat, C, 2 * c, c); l.res = view(cat, C, c, c);
+    l.w1 = w1; l.w2 = w2; l.b1 = b1; l.b2 = b2; l.zeros = zeros; l.B = B; l.c = c; l.kp = 9 * c;
+    if (tail) { l.tail_in = view(cat, C, 0, 2 * c); l.tail_out = view(outt, 2 * c, 0, 2 * c); l.tail_wt = wt; l.tail_bias = bt; l.tail_cout = 2 * c; l.tail_kp = 3 * c; l.tail_act = 1; }
+    const int tiles = ((HW + 15) / 16) * ((HW + 15) / 16) * B;
+    unsigned long long *d_st;
+    CK(hipMalloc(&d_st, (size_t)tiles * 16 * 8)); CK(hipMemset(d_st, 0, (size_t)tiles * 16 * 8));
+    CK(hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), &d_st, sizeof(d_st)));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int i = 0; i < 3; ++i) if (launch_bottleneck(l, nullptr) != 0) return 1;
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0, nullptr));
+    for (int i = 0; i < 5; ++i) launch_bottleneck(l, nullptr);
+    CK(hipEventRecord(e1, nullptr)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    std::vector<unsigned long long> st((size_t)tiles * 16);
+    CK(hipMemcpy(st.data(), d_st, st.size() * 8, hipMemcpyDeviceToHost));
+    printf("bottleneck c=%d %dx%d B=%d tail=%d: %.1f us per launch (stamped build), %d workgroups\n", c, HW, HW, B, (int)tail, ms * 1e3 / 5, tiles);
+    const char *names[] = {"patch DMA issue", "wait patch (+barrier)", "conv1 k-loop", "epilogue 1 + barrier", "conv2 k-loop", "epilogue 2 staging + barrier", "tail: DMA issue + wait + barrier", "tail MFMA + barrier", "tail store / plain store"};
+    const int lastk = 9;
+    std::vector<std::vector<double>> d(lastk);
+    unsigned long long t0 = ~0ull, t1 = 0;
+    std::vector<double> life;
+    for (int g = 0; g < tiles; ++g) {
+        const unsigned long long *s = &st[(size_t)g * 16];
+        unsigned long long prev = s[0];
+        for (int k = 1; k <= lastk; ++k) { if (!s[k]) continue; d[k - 1].push_back((double)(s[k] - prev)); prev = s[k]; }
+        t0 = std::min(t0, s[0]); t1 = std::max(t1, s[lastk]);
+        life.push_back((double)(s[lastk] - s[0]));
+    }
+    auto med = [](std::vector<double> v) { if (v.empty()) return 0.0; std::sort(v.begin(), v.end()); return v[v.size() / 2]; };
+    double tot = med(life);
+    printf("  kernel span %llu clk (s_memtime ticks); median workgroup lifetime %.0f clk\n", t1 - t0, tot);
+    for (int k = 0; k < lastk; ++k) printf("  %-36s median %8.0f clk  %5.1f %%\n", names[k], med(d[k]), 100.0 * med(d[k]) / tot);
+    // concurrency: workgroups alive at the middle of the kernel
+    const unsigned long long mid = t0 + (t1 - t0) / 2;
+    int alive = 0;
+    for (int g = 0; g < tiles; ++g) alive += st[(size_t)g * 16] <= mid && st[(size_t)g * 16 + lastk] >= mid;
+    printf("  workgroups alive at mid-kernel: %d (%.2f per CU)\n", alive, alive / 256.0);
+    return 0;
+}
+
+int main() {
+    if (run_bneck(32, 160, 16, true)) return 1;
+    if (run_bneck(32, 160, 16, false)) return 1;
+    if (run_bneck(64, 80, 16, false)) return 1;
+    if (run_bneck(64, 80, 16, true)) return 1;
+    return 0;
+}

@@ -15,7 +15,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--model", default="s")
 ap.add_argument("--size", type=int, default=640)
 ap.add_argument("--streams", type=int, default=8)
-ap.add_argument("--frames-per-stream", type=int, default=2)        # bench.py default: 16 frames per launch set
+ap.add_argument("--frames-per-stream", type=int, default=4)        # bench.py default: 32 frames per launch set
 ap.add_argument("--no-autotune", action="store_true")
 ap.add_argument("--iters", type=int, default=10)
 a = ap.parse_args()
