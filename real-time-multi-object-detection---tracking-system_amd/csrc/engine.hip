@@ -161,6 +161,7 @@ struct Op {
     // fused launch faster, `tail_on` runs it with `tail_tile` and the 1x1's own op is skipped
     bool tail_on = false, skip = false;
     int tail_tile = TILE_TAIL_128x64;
+    bool in_first = false;           // layer "1" when it runs inside the net's first launch (stem_l1.hip), together with its 1x1 tail if tail_on
 };
 
 }  // namespace rtmodt
@@ -208,6 +209,9 @@ struct rtmodt_detector {
     std::map<std::string, TensorView> layer_out;     // fused conv name -> output view
     std::vector<void *> dev_allocs;                   // weights etc.
     int img_t = -1;
+    // stem + layer 1 (+ 2.cv1) as ONE launch (stem_l1.hip): index of layer "1" in the op lists when the shapes allow it, and
+    // whether the tuner (or RTMODT_STEM_L1) switched it on
+    int l1_idx = -1; bool sl1_on = false;
     f16 *d_zeros = nullptr;                           // 256 zero bytes (DMA source for out-of-tensor halo pixels)
     int head_t[3] = {-1, -1, -1};
     // Detect's last 1x1 convs + decode as ONE launch (postprocess.hip: head_final); `stage2_op` = index of the grouped
@@ -595,6 +599,13 @@ static int build_graph(rtmodt_detector *d, WeightFile &wf) {
                 b.skip = a.tail_on;
             }
         }
+    for (size_t i = 1; i < d->ops.size(); ++i) {              // layers 0 + 1 (+ 2.cv1) in one launch: YOLOv8s' shapes only
+        const Op &o = d->ops[i];
+        if (o.kind == OP_CONV && o.name == "1" && d->ops[0].kind == OP_STEM && o.conv.ks == 3 && o.conv.stride == 2 && o.conv.cin == 32 && o.conv.cout == 64 &&
+            d->ops[0].v[1].c == 32 && o.conv.in.base == d->ops[0].v[1].base && !o.conv.res.base && !o.conv.out2.base && o.conv.act == 1 &&
+            stem_l1_supported(32, 64, o.conv.tail_wt ? o.conv.tail_cout : 0, d->in_h, d->in_w) && !getenv("RTMODT_NO_STEM_L1"))
+            d->l1_idx = (int)i;
+    }
     // Detect head: the two first 3x3 convs of a level share their input -> one conv, cout = cbox + ccls
     const int cbox = std::max(16, std::max(c3 / 4, 64)), ccls = std::max(c3, std::min(d->nc, 100));
     const int nc4 = (int)align_up(d->nc, 4), no = 64 + (int)align_up(d->nc, 8);
@@ -741,7 +752,7 @@ static int run_op_on(const Op &op, hipStream_t s) {
     switch (op.kind) {
         case OP_STEM: return launch_stem(op.v[0], op.v[1], op.stem_w, op.stem_b, op.B, op.v[1].c, s);
         case OP_CONV: {
-            if (op.skip) return RTMODT_OK;                 // runs as the tail of the previous launch
+            if (op.skip || op.in_first) return RTMODT_OK;  // runs as the tail of the previous launch / inside the net's first launch
             if (!op.tail_on) return launch_conv(op.conv, s);
             ConvLaunch c = op.conv;
             c.tile = op.tail_tile;
@@ -795,14 +806,33 @@ static int run_decode_sub(rtmodt_detector *d, int b0, int nb, hipStream_t st) {
 }
 static int run_decode(rtmodt_detector *d) { return run_decode_sub(d, 0, d->B, d->stream); }
 
-// the stem conv of every chain, on the main stream: straight from the frames' bytes (fused) or from the
-// letterboxed image tensor
-static int run_stem_chain(rtmodt_detector *d, int c, bool fused, hipStream_t st) {
-    const Op &op = d->chain_ops[c][0];
+// The net's first launch for one op list (whole batch, a sub-batch chain, or an arena copy): the stem -- straight from the
+// frames' bytes (`from_bytes`: letterbox folded in) or from the letterboxed image tensor -- or, when switched on, the stem,
+// layer 1 and layer 1's 1x1 tail in one launch (stem_l1.hip).  frame0: first frame of d->fptrs this op list covers.
+static int run_first(rtmodt_detector *d, const std::vector<Op> &ops, int frame0, bool from_bytes, hipStream_t st) {
+    const Op &op = ops[0];
     RT_CHECK(op.kind == OP_STEM, RTMODT_E_INVALID, "op 0 is not the stem");
-    if (fused) return launch_stem_fused(d->fptrs, c * op.B, d->last_pitch, d->last_lg, d->in_h, d->in_w, d->lut255, op.v[1], op.stem_w,
-                                        op.stem_b, op.B, op.v[1].c, st);
+    if (d->sl1_on && d->l1_idx > 0) {
+        const Op &l1 = ops[d->l1_idx];
+        StemL1Launch L;
+        if (from_bytes) { L.frames = &d->fptrs; L.frame0 = frame0; L.pitch = d->last_pitch; L.g = d->last_lg; }
+        else L.img4 = op.v[0];
+        L.in_h = d->in_h; L.in_w = d->in_w; L.B = op.B;
+        L.w0 = op.stem_w; L.b0 = op.stem_b; L.w1 = l1.conv.wt; L.b1 = l1.conv.bias; L.kp1 = l1.conv.kp;
+        if (l1.tail_on) {
+            L.wt = l1.conv.tail_wt; L.bt = l1.conv.tail_bias; L.kpt = l1.conv.tail_kp; L.t_cout = l1.conv.tail_cout; L.t_act = l1.conv.tail_act;
+            L.out = l1.conv.tail_out;
+        } else {
+            L.out = l1.conv.out;
+        }
+        return launch_stem_l1(L, st);
+    }
+    if (from_bytes) return launch_stem_fused(d->fptrs, frame0, d->last_pitch, d->last_lg, d->in_h, d->in_w, d->lut255, op.v[1], op.stem_w,
+                                             op.stem_b, op.B, op.v[1].c, st);
     return run_op_on(op, st);
+}
+static int run_stem_chain(rtmodt_detector *d, int c, bool fused, hipStream_t st) {
+    return run_first(d, d->chain_ops[c], c * d->chain_ops[c][0].B, fused, st);
 }
 static int run_stems(rtmodt_detector *d, bool fused) {
     for (int c = 0; c < d->n_chains; ++c) RT_TRY(run_stem_chain(d, c, fused, d->stream));
@@ -815,7 +845,7 @@ static int forward_eager(rtmodt_detector *d) {
 }
 // start-up / autotune: the whole net on whatever the image tensor holds
 static int forward_eager_all(rtmodt_detector *d) {
-    for (auto &op : d->ops) if (op.kind == OP_STEM) RT_TRY(run_op(d, op));
+    RT_TRY(run_first(d, d->ops, 0, false, d->stream));
     return forward_eager(d);
 }
 
@@ -860,6 +890,26 @@ static bool tail_tile_legal(const ConvLaunch &c, int t) {
     return tile_is_tail(t) && tile_shape(t).bn == c.cout && !(tile_needs_cin64(t) && (c.cin % 64 != 0 || c.kp % 64 != 0)) && c.cin % 32 == 0;
 }
 
+// LDS bytes a workgroup of tile `t` holds (conv.hip's stage rings): two workgroups of DIFFERENT launches share a CU only if
+// their LDS fits 160 KiB together -- which is what lets the stages of the staged engine overlap
+static int tile_lds_kib(int t) {
+    const TileShape ts = tile_shape(t);
+    if (tile_is_rows(t)) { const int rp = tile_needs_cin64(t) ? 8 : 16; return 2 * (ts.bm / rp + 1 + 3 * (ts.bn / rp)); }
+    if (t >= TILE_WSK_64x64 && t <= TILE_WSK_64x32) return std::max(8 * (ts.bm / 16 + ts.bn / 16), 4 * (ts.bm / 16) * (ts.bn / 16));
+    int stages = 3;
+    switch (t) {
+        case TILE_128x128_S4: stages = 4; break;
+        case TILE_128x64_S5: case TILE_64x128_S5: stages = 5; break;
+        case TILE_64x64_S6: case TILE_128x128_S6: stages = 6; break;
+        case TILE_K64_128x128_S2: case TILE_K64_256x64_S2: case TILE_K64_256x128_S2: case TILE_K64_128x128_S2W: case TILE_K64_128x128_S2_W8:
+        case TILE_K64_256x128_S2_W8: case TILE_K64_256x64_S2_W8: stages = 2; break;
+        case TILE_K64_64x64_S4: stages = 4; break;
+        default: break;
+    }
+    const int rp = tile_needs_cin64(t) ? 8 : 16;
+    return stages * (ts.bm / rp + ts.bn / rp);
+}
+
 // fastest tile for one conv (or one group of convs sharing a tile); returns its time
 static int tune_conv(rtmodt_detector *d, hipEvent_t e0, hipEvent_t e1, const std::string &name, ConvLaunch *c, int n, int &tile_io,
                      float &best_ms) {
@@ -869,7 +919,12 @@ static int tune_conv(rtmodt_detector *d, hipEvent_t e0, hipEvent_t e1, const std
         if (!tile_legal(c, n, t)) continue;
         float ms;
         RT_TRY(time_launch(d, e0, e1, [&]() { return launch_conv_group(c, n, t, d->stream); }, ms));
-        if (getenv("RTMODT_TUNE_LOG")) fprintf(stderr, "[tune] %-28s %-16s %8.2f us\n", name.c_str(), tile_name(t), ms * 1e3f);
+        if (getenv("RTMODT_TUNE_LOG")) fprintf(stderr, "[tune] %-28s %-16s %8.2f us  (%d KiB LDS)\n", name.c_str(), tile_name(t), ms * 1e3f, tile_lds_kib(t));
+        // the launches are timed ALONE, but in the staged engine they share the CUs with the other stages' launches: a tile
+        // whose workgroup takes more than half the LDS keeps every other workgroup off its CU (experiment hook)
+        static const float lds_penalty = getenv("RTMODT_TUNE_LDS_PENALTY") ? (float)atof(getenv("RTMODT_TUNE_LDS_PENALTY")) : 0.f;
+        static const int lds_cap = getenv("RTMODT_TUNE_LDS_CAP") ? atoi(getenv("RTMODT_TUNE_LDS_CAP")) : 80;
+        if (d->pipe && tile_lds_kib(t) > lds_cap) ms *= 1.f + lds_penalty;
         if (ms < best_ms) { best_ms = ms; best_tile = t; }
     }
     tile_io = best_tile;
@@ -989,6 +1044,32 @@ static int autotune_ops(rtmodt_detector *d, std::vector<Op> &ops) {
         if (const char *e = getenv("RTMODT_TAIL")) op.tail_on = atoi(e) != 0 && tile_shape(op.tail_tile).bn == op.conv.cout;   // A/B and test hook
         nx.skip = op.tail_on;
     }
+    // stem + layer 1 (+ its tail) as one launch against the stem followed by layer 1's tuned launch
+    if (d->l1_idx > 0 && ops[0].kind == OP_STEM && (int)ops.size() > d->l1_idx) {
+        Op &l1 = ops[d->l1_idx];
+        char kb[96];
+        snprintf(kb, sizeof(kb), "stem+1|B%d|%dx%d|tail%d", ops[0].B, d->in_h, d->in_w, (int)l1.tail_on);
+        auto hit = cache.find(kb);
+        if (hit != cache.end()) {
+            d->sl1_on = hit->second.fused != 0;
+        } else {
+            float ms_sep, ms_one;
+            d->sl1_on = false;
+            RT_TRY(time_launch(d, e0, e1, [&]() { RT_TRY(run_op_on(ops[0], d->stream)); return run_op_on(l1, d->stream); }, ms_sep));
+            d->sl1_on = true;
+            RT_TRY(time_launch(d, e0, e1, [&]() { return run_first(d, ops, 0, false, d->stream); }, ms_one));
+            // timed here on the image tensor; from the frames' BYTES (the usual source) the one-launch form reads every pixel with
+            // three byte loads and is ~35 % slower than this measurement, while stem_fused assembles rows from aligned dwords: it
+            // must win by a wide margin to be switched on (measured r02: 89 us vs 80 us at 16 frames -- it is not; profiles/r02)
+            d->sl1_on = ms_one < 0.7f * ms_sep;
+            if (getenv("RTMODT_TUNE_LOG")) fprintf(stderr, "[tune] stem + layer 1%s: one launch %8.2f us vs two %8.2f us\n", l1.tail_on ? " + 2.cv1" : "", ms_one * 1e3f, ms_sep * 1e3f);
+            TuneRec r; r.fused = d->sl1_on;
+            cache[kb] = r;
+            dirty = true;
+        }
+        if (const char *e = getenv("RTMODT_STEM_L1")) d->sl1_on = atoi(e) != 0;      // A/B and test hook
+        l1.in_first = d->sl1_on;
+    }
     // fused Bottleneck + C2f.cv2 as its tail against the fused Bottleneck followed by cv2's own launch
     for (size_t i = 0; i + 1 < ops.size(); ++i) {
         Op &op = ops[i], &nx = ops[i + 1];
@@ -1026,6 +1107,13 @@ static int autotune_ops(rtmodt_detector *d, std::vector<Op> &ops) {
     return RTMODT_OK;
 }
 
+// d->sl1_on is the one truth about the net's first launch: every copy of layer "1" carries it
+static void sync_first_launch_flag(rtmodt_detector *d) {
+    if (d->l1_idx <= 0) { d->sl1_on = false; return; }
+    d->ops[d->l1_idx].in_first = d->sl1_on;
+    for (auto &list : d->chain_ops) if ((int)list.size() > d->l1_idx) list[d->l1_idx].in_first = d->sl1_on;
+}
+
 static int autotune_tiles(rtmodt_detector *d) {
     RT_TRY(autotune_ops(d, d->ops));
     // the tuner's decisions travel from the op it timed to the copies that run
@@ -1033,7 +1121,7 @@ static int autotune_tiles(rtmodt_detector *d) {
         dst.conv.tile = src.conv.tile;
         dst.group_tile = src.group_tile;
         dst.fused = src.fused;
-        dst.tail_on = src.tail_on; dst.tail_tile = src.tail_tile; dst.skip = src.skip;
+        dst.tail_on = src.tail_on; dst.tail_tile = src.tail_tile; dst.skip = src.skip; dst.in_first = src.in_first;
         for (size_t g = 0; g < dst.group.size(); ++g) dst.group[g].tile = src.group[g].tile;
     };
     if (d->n_chains > 1) {
@@ -1043,6 +1131,7 @@ static int autotune_tiles(rtmodt_detector *d) {
     } else {
         for (size_t i = 0; i < d->ops.size(); ++i) adopt(d->chain_ops[0][i], d->ops[i]);
     }
+    sync_first_launch_flag(d);
     // the tuning launches left stale activations; run one clean pass
     RT_TRY(forward_eager_all(d));
     RT_HIP(hipStreamSynchronize(d->stream));
@@ -1457,6 +1546,7 @@ static int detector_create_impl(const rtmodt_det_cfg *cfg, rtmodt_detector *d) {
     RT_TRY(forward_eager_all(d));
     RT_HIP(hipStreamSynchronize(d->stream));
     if (cfg->autotune) RT_TRY(autotune_tiles(d));
+    else if (const char *e = getenv("RTMODT_STEM_L1")) { d->sl1_on = atoi(e) != 0; sync_first_launch_flag(d); }      // test hook (no autotune)
     if (cfg->use_graph) RT_TRY(capture_graph(d));
     return RTMODT_OK;
 }
@@ -1588,10 +1678,7 @@ int rtmodt_detector_enqueue_batch(rtmodt_detector *d, const uint8_t *const *fram
     if (graphs && d->pipe) {
         const int S = d->n_stages, par = (int)(d->batch_no % S), inst = (int)((d->batch_no / S) & 1);
         d->run_par = par;
-        const Op &stem = d->par_ops[par][0];
-        if (d->last_fused) RT_TRY(launch_stem_fused(d->fptrs, 0, d->last_pitch, d->last_lg, d->in_h, d->in_w, d->lut255, stem.v[1], stem.stem_w, stem.stem_b,
-                                                    d->B, stem.v[1].c, d->stream));
-        else RT_TRY(run_op_on(stem, d->stream));
+        RT_TRY(run_first(d, d->par_ops[par], 0, d->last_fused, d->stream));
         RT_HIP(hipEventRecord(sl.evp, d->stream));
         for (int k = 0; k < S; ++k) {
             hipStream_t st = d->stage_stream[k];
@@ -1774,6 +1861,8 @@ int rtmodt_detector_debug_layer(rtmodt_detector *d, const char *name, int img, u
         if (d->newest >= 0) d->cur_dense = d->newest;
         RT_TRY(materialize_heads(d));                      // Detect's last convs live inside head_final
     }
+    if (d->sl1_on && d->l1_idx > 0 && (strcmp(name, "0") == 0 || (strcmp(name, "1") == 0 && d->ops[d->l1_idx].tail_on)))
+        return fail(RTMODT_E_UNSUPPORTED, "%s is consumed in LDS by the next conv fused into its launch", name);
     for (auto &op : d->ops)                               // a conv whose 1x1 tail runs in the same launch stores only the tail's output
         if (op.kind == OP_CONV && op.tail_on && op.name == name)
             return fail(RTMODT_E_UNSUPPORTED, "%s is consumed in LDS by the 1x1 conv fused into its launch", name);
@@ -1807,9 +1896,7 @@ int rtmodt_detector_profile(rtmodt_detector *d, int iters, int max_entries, cons
     for (int it = 0; it < iters; ++it) {
         RT_HIP(hipEventRecord(ev[0], d->stream));
         for (int i = 0; i < n - 1; ++i) {
-            if (ops[i].kind == OP_STEM && d->last_fused)
-                RT_TRY(launch_stem_fused(d->fptrs, 0, d->last_pitch, d->last_lg, d->in_h, d->in_w, d->lut255, ops[i].v[1], ops[i].stem_w,
-                                         ops[i].stem_b, PB, ops[i].v[1].c, d->stream));
+            if (ops[i].kind == OP_STEM) RT_TRY(run_first(d, ops, 0, d->last_fused, d->stream));
             else RT_TRY(run_op(d, ops[i]));
             RT_HIP(hipEventRecord(ev[i + 1], d->stream));
         }
@@ -1826,7 +1913,9 @@ int rtmodt_detector_profile(rtmodt_detector *d, int iters, int max_entries, cons
     d->prof_names.clear();
     for (auto &op : ops) {
         char buf[160];
-        if (op.kind == OP_CONV && op.skip) {
+        if (op.kind == OP_CONV && op.in_first) {
+            snprintf(buf, sizeof(buf), "%s [runs inside the first launch]", op.name.c_str());
+        } else if (op.kind == OP_CONV && op.skip) {
             snprintf(buf, sizeof(buf), "%s [runs as the tail of the previous launch]", op.name.c_str());
         } else if (op.kind == OP_CONV) {
             snprintf(buf, sizeof(buf), "%s [M=%d N=%d K=%d k%d s%d tile %s]", op.name.c_str(), PB * op.conv.out.H * op.conv.out.W,
@@ -1838,6 +1927,8 @@ int rtmodt_detector_profile(rtmodt_detector *d, int iters, int max_entries, cons
             snprintf(buf, sizeof(buf), "%s [runs inside head_final]", op.name.c_str());
         } else if (op.kind == OP_GROUP) {
             snprintf(buf, sizeof(buf), "%s [group of %zu, tile %s]", op.name.c_str(), op.group.size(), tile_name(op.group_tile));
+        } else if (op.kind == OP_STEM && d->sl1_on) {
+            snprintf(buf, sizeof(buf), "%s [%sstem + layer 1%s in one launch]", op.name.c_str(), d->last_fused ? "letterbox + " : "", ops[d->l1_idx].tail_on ? " + 2.cv1" : "");
         } else if (op.kind == OP_STEM && d->last_fused) {
             snprintf(buf, sizeof(buf), "%s [letterbox + stem fused]", op.name.c_str());
         } else {

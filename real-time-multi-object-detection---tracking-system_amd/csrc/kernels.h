@@ -84,10 +84,25 @@ int launch_stem(const TensorView &img4, const TensorView &out, const f16 *wm, co
                 int cout, hipStream_t s);
 // the same conv reading the BGR uint8 frames themselves (letterbox folded in); only for frames that need no
 // resize.  lut: 256 fp16 values c/255.  Frames frame0 .. frame0+B-1 of `frames`.
-struct FramePtrs;
-struct LetterboxGeom;
+struct LetterboxGeom { int src_h, src_w, new_w, new_h, top, left, resize; };
+// frames: up to 64 device pointers to BGR uint8 images with row pitch `pitch`, passed by value in
+// the kernel arguments (no pointer table to upload, nothing to race with launch-ahead)
+struct FramePtrs { const uint8_t *p[64]; };
 int launch_stem_fused(const FramePtrs &frames, int frame0, int pitch, const LetterboxGeom &g, int in_h, int in_w, const f16 *lut,
                       const TensorView &out, const f16 *wm, const float *bias, int B, int cout, hipStream_t s);
+// Layers 0 + 1 (+ the 1x1 conv 2.cv1 as a tail) of YOLOv8s in ONE launch, the stem's output kept in LDS (stem_l1.hip).
+// Source: the BGR frames themselves (`frames` != nullptr; no resize) or the letterboxed image tensor `img4`.
+struct StemL1Launch {
+    const FramePtrs *frames = nullptr; int frame0 = 0, pitch = 0; LetterboxGeom g{};
+    TensorView img4;
+    int in_h = 0, in_w = 0, B = 1;
+    const f16 *w0 = nullptr; const float *b0 = nullptr;                       // stem weights in launch_stem's layout
+    const f16 *w1 = nullptr; const float *b1 = nullptr; int kp1 = 0;          // layer 1 in the conv layout
+    const f16 *wt = nullptr; const float *bt = nullptr; int kpt = 0, t_cout = 0, t_act = 1;   // optional 1x1 tail
+    TensorView out;                                                           // the tail's output, or layer 1's without a tail
+};
+bool stem_l1_supported(int c0, int c1, int tail_cout, int in_h, int in_w);
+int launch_stem_l1(const StemL1Launch &l, hipStream_t s);
 // SPPF: y -> (max5(y), max5(max5(y)), max5^3(y)) written to three channel slices of the same tensor
 int launch_sppf_pool(const TensorView &y, const TensorView &p1, const TensorView &p2, const TensorView &p3, int B,
                      hipStream_t s);
@@ -100,10 +115,6 @@ int launch_upsample2(const TensorView &in, const TensorView &out, int B, hipStre
 struct ResizeTables {          // device arrays, cv::resize INTER_LINEAR fixed-point tables
     const int32_t *xofs, *xa0, *xa1, *yofs, *yb0, *yb1;
 };
-struct LetterboxGeom { int src_h, src_w, new_w, new_h, top, left, resize; };
-// frames: up to 64 device pointers to BGR uint8 images with row pitch `pitch`, passed by value in
-// the kernel arguments (no pointer table to upload, nothing to race with launch-ahead)
-struct FramePtrs { const uint8_t *p[64]; };
 int launch_letterbox(const FramePtrs &frames, int pitch, const LetterboxGeom &g, const ResizeTables &t,
                      const TensorView &img4, int B, hipStream_t s);
 
