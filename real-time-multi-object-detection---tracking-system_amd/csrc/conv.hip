@@ -861,6 +861,117 @@ __device__ __forceinline__ void conv_mfma_wsk_body(const ConvArgs &p, const int 
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// conv1x1_ws: WEIGHT-STATIONARY 1x1 convolution.  In the tile kernels above every workgroup streams its BN x K slice of
+// the weights again for every pixel tile -- for the C2f / SPPF 1x1 convs (N = 128..512, K = 256..768) that is HALF of all
+// bytes that cross the global -> LDS path, the path that bounds them.  Here a persistent 4-wave workgroup loads its BN x K
+// weight slice into LDS ONCE (K/64 x BN/8 pieces, resident) and then walks over 128-pixel tiles mt = g, g + G, ..., whose
+// rows arrive through a ring of NSTAGE 16-KiB stages; the (tile, k-step) pairs form ONE stream of steps, so the ring keeps
+// prefetching across tile boundaries and a tile's epilogue (bias, SiLU, stores straight from the accumulators) runs
+// under the next tile's loads.  Same MFMA order per output as conv_mfma64 (k ascending), same swizzled piece layout.
+// ---------------------------------------------------------------------------------------
+template <int BN, int NSTAGE>
+__global__ __launch_bounds__(256) void conv1x1_ws(ConvArgs p, int groups) {
+    constexpr int BM = 128, NW = 4, WM = 2, WN = 2;
+    constexpr int NA = BM / 8, NB = BN / 8, LA = NA / NW, LBp = NB / NW;
+    constexpr int DEPTH = NSTAGE - 1;
+    constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
+    extern __shared__ __attribute__((aligned(1024))) unsigned char ws_lds[];
+    const int nk = p.kp / 64;
+    unsigned char *wbase = ws_lds, *abase = ws_lds + nk * NB * 1024;
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r = lane & 15, q = lane >> 4;
+    const int n0 = blockIdx.y * BN, g = blockIdx.x;
+    const int n_mt = (p.M + BM - 1) / BM;
+    const int n_my = (n_mt - g + groups - 1) / groups;     // pixel tiles g, g + groups, ...
+    const int S = n_my * nk;                                // steps of this workgroup
+    const int ld_row8 = lane >> 3, ld_slot = lane & 7;
+    const int rd_base = (r >> 3) * 1024 + (r & 7) * 128;
+    const int rd_off0 = rd_base + (((0 + q) ^ ((r >> 1) & 7)) << 4);
+    const int rd_off1 = rd_base + (((4 + q) ^ ((r >> 1) & 7)) << 4);
+
+    // ---- the weight slice: resident ----
+    for (int kt = 0; kt < nk; ++kt)
+#pragma unroll
+        for (int i = 0; i < LBp; ++i) {
+            const int row = (wave + NW * i) * 8 + ld_row8;
+            glds16(p.wt + ((n0 + row) * p.kp + ((ld_slot ^ ((row >> 1) & 7)) << 3) + kt * 64), wbase + (kt * NB + wave + NW * i) * 1024);
+        }
+    // ---- the pixel stream ----
+    int a_off[LA];
+    int is_tile = 0, is_kt = 0, is_stage = 0;                // the next step to issue
+    auto tile_offsets = [&](int ti) {
+        const int m0 = (g + ti * groups) * BM;
+#pragma unroll
+        for (int i = 0; i < LA; ++i) {
+            const int row = (wave + NW * i) * 8 + ld_row8;
+            a_off[i] = input_offset(p, m0 + row) + ((ld_slot ^ ((row >> 1) & 7)) << 3);
+        }
+    };
+    auto issue = [&]() {
+        if (is_kt == 0) tile_offsets(is_tile);
+        unsigned char *sbase = abase + is_stage * (NA * 1024);
+#pragma unroll
+        for (int i = 0; i < LA; ++i) glds16(p.in + (a_off[i] + is_kt * 64), sbase + (wave + NW * i) * 1024);
+        if (++is_kt == nk) { is_kt = 0; ++is_tile; }
+        is_stage = is_stage + 1 == NSTAGE ? 0 : is_stage + 1;
+    };
+    const int wm = wave / WN, wn = wave % WN;
+    floatx4 bv[TN];
+#pragma unroll
+    for (int u = 0; u < TN; ++u) bv[u] = *(const floatx4 *)(p.bias + n0 + (wn * TN + u) * 16 + q * 4);
+    floatx4 acc[TM][TN];
+#pragma unroll
+    for (int t = 0; t < TM; ++t)
+#pragma unroll
+        for (int u = 0; u < TN; ++u) acc[t][u] = floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < DEPTH; ++i)
+        if (i < S) issue();
+    int kt = 0, tile = 0, rstage = 0;
+    for (int s = 0; s < S; ++s) {
+        // everything issued before step s's successors has landed: the weights (issued first of all) and stage s
+        wait_steps<LA, DEPTH - 1>(min(DEPTH - 1, S - 1 - s));
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (s + DEPTH < S) issue();                         // refills the stage read in step s - 1
+        const unsigned char *sA = abase + rstage * (NA * 1024);
+        const unsigned char *sB = wbase + kt * (NB * 1024);
+        rstage = rstage + 1 == NSTAGE ? 0 : rstage + 1;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int ro = kk ? rd_off1 : rd_off0;
+            half8 fa[TM], fb[TN];
+#pragma unroll
+            for (int t = 0; t < TM; ++t) fa[t] = *(const half8 *)(sA + (wm * TM + t) * 2048 + ro);
+#pragma unroll
+            for (int u = 0; u < TN; ++u) fb[u] = *(const half8 *)(sB + (wn * TN + u) * 2048 + ro);
+#pragma unroll
+            for (int t = 0; t < TM; ++t)
+#pragma unroll
+                for (int u = 0; u < TN; ++u) acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[u], fa[t], acc[t][u], 0, 0, 0);
+        }
+        if (++kt == nk) {                                   // the tile is complete: epilogue straight from the accumulators
+            kt = 0;
+            const int m0 = (g + tile * groups) * BM;
+            ++tile;
+#pragma unroll
+            for (int t = 0; t < TM; ++t) {
+                long opix, rpix, opix2;
+                const bool live = pixel_offsets(p, m0 + (wm * TM + t) * 16 + r, opix, rpix, opix2);
+#pragma unroll
+                for (int u = 0; u < TN; ++u) {
+                    const int n = n0 + (wn * TN + u) * 16 + q * 4;
+                    if (live && n < p.cout) store_tile(p, acc[t][u], bv[u], opix, rpix, n, opix2);
+                    acc[t][u] = floatx4{0.f, 0.f, 0.f, 0.f};
+                }
+            }
+        }
+    }
+}
+
 // ---- kernel entry points: one problem per launch, or a GROUP of independent problems that
 // share a tile configuration.  Grouping turns the Detect head's 15 small launches into 3.
 constexpr int MAX_GROUP = 6;
@@ -937,15 +1048,19 @@ const char *tile_name(int tile) {
                                             "rows:128x64", "rows:256x32", "rows:128x32", "rows64:128x64", "rows64:128x128", "rows64:64x64", "rows64:256x64",
                                             "tail:128x64", "tail:64x64", "tail:k64:128x128", "tail:k64:64x128",
                                             "k64:128x128s2/8w", "k64:128x128s3/8w", "k64:256x128s2/8w", "k64:128x64s3/8w", "k64:256x64s2/8w",
-                                            "rows:128x64/8w", "rows:256x64/8w", "rows64:128x128/8w", "rows64:256x64/8w"};
+                                            "rows:128x64/8w", "rows:256x64/8w", "rows64:128x128/8w", "rows64:256x64/8w",
+                                            "ws:128x128", "ws:128x64"};
     return tile >= 0 && tile < TILE_COUNT ? names[tile] : "?";
 }
 
 bool tile_needs_cin64(int tile) {
     return (tile >= TILE_K64_128x128_S2 && tile <= TILE_K64_128x128_S2W) || (tile >= TILE_ROWS_K64_128x64 && tile <= TILE_ROWS_K64_256x64) ||
            tile == TILE_TAIL_K64_128x128 || tile == TILE_TAIL_K64_64x128 || (tile >= TILE_K64_128x128_S2_W8 && tile <= TILE_K64_256x64_S2_W8) ||
-           tile == TILE_ROWS_K64_128x128_W8 || tile == TILE_ROWS_K64_256x64_W8;
+           tile == TILE_ROWS_K64_128x128_W8 || tile == TILE_ROWS_K64_256x64_W8 || tile_is_ws(tile);
 }
+bool tile_is_ws(int tile) { return tile == TILE_WS_128x128 || tile == TILE_WS_128x64; }
+// resident weight slice (kp/64 x BN/8 KiB) + the pixel ring (3 x 16 KiB) within 156 KiB of LDS
+bool tile_ws_fits(int tile, int kp) { return tile_is_ws(tile) && (kp / 64) * (tile_shape(tile).bn / 8) + 3 * 16 <= 156; }
 bool tile_is_tail(int tile) { return tile >= TILE_TAIL_128x64 && tile <= TILE_TAIL_K64_64x128; }
 // the 64-deep tile kernels (conv_mfma64_body) know how to read channels [0, lo_c) from a half-resolution tensor
 bool tile_reads_lo(int tile) { return (tile >= TILE_K64_128x128_S2 && tile <= TILE_K64_128x128_S2W) || (tile >= TILE_K64_128x128_S2_W8 && tile <= TILE_K64_256x64_S2_W8); }
@@ -989,6 +1104,8 @@ TileShape tile_shape(int tile) {
         case TILE_ROWS_128x64_W8: return {128, 64};
         case TILE_ROWS_256x64_W8: case TILE_ROWS_K64_256x64_W8: return {256, 64};
         case TILE_ROWS_K64_128x128_W8: return {128, 128};
+        case TILE_WS_128x128: return {128, 128};
+        case TILE_WS_128x64: return {128, 64};
     }
     return {0, 0};
 }
@@ -1050,6 +1167,27 @@ template <int BM, int BN, int WM, int WN, int NSTAGE>
 static int launch_k64_w8(const LaunchPlan &l, hipStream_t s) {
     RT_CHECK(l.n == 1, RTMODT_E_INVALID, "launch_conv: the 8-wave tiles run single problems");
     hipLaunchKernelGGL((conv_mfma64_w8<BM, BN, WM, WN, NSTAGE>), l.grid(BM, BN), dim3(512), 0, s, l.a[0]);
+    return RTMODT_OK;
+}
+
+template <int BN>
+static int launch_ws(const LaunchPlan &l, hipStream_t s) {
+    const ConvArgs &a = l.a[0];
+    RT_CHECK(l.n == 1 && a.ks == 1 && a.stride == 1 && !a.in2 && a.cin % 64 == 0 && a.kp % 64 == 0, RTMODT_E_INVALID,
+             "launch_conv: the weight-stationary tile runs one 1x1 stride-1 conv with cin %% 64 == 0 and no half-resolution source");
+    constexpr int NSTAGE = 3;
+    const int nk = a.kp / 64, smem = (nk * (BN / 8) + NSTAGE * 16) * 1024;
+    RT_CHECK(smem <= 156 * 1024, RTMODT_E_INVALID, "launch_conv: weight slice %d x %d does not fit LDS", BN, a.kp);
+    const int slices = cdiv(a.cout, BN), n_mt = cdiv(a.M, 128);
+    const int groups = std::max(1, std::min(n_mt, 256 / slices));      // one persistent workgroup per CU
+    static int attr[64] = {};
+    int dev = 0;
+    RT_HIP(hipGetDevice(&dev));
+    if (dev >= 0 && dev < 64 && smem > attr[dev]) {
+        RT_HIP(hipFuncSetAttribute((const void *)conv1x1_ws<BN, NSTAGE>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
+        attr[dev] = 156 * 1024;
+    }
+    hipLaunchKernelGGL((conv1x1_ws<BN, NSTAGE>), dim3(groups, slices), dim3(256), smem, s, a, groups);
     return RTMODT_OK;
 }
 
@@ -1216,6 +1354,8 @@ int launch_conv_group(const ConvLaunch *c, int n, int tile, hipStream_t s) {
         case TILE_K64_256x128_S2_W8: RT_TRY((launch_k64_w8<256, 128, 4, 2, 2>(l, s))); break;
         case TILE_K64_128x64_S3_W8: RT_TRY((launch_k64_w8<128, 64, 4, 2, 3>(l, s))); break;
         case TILE_K64_256x64_S2_W8: RT_TRY((launch_k64_w8<256, 64, 8, 1, 2>(l, s))); break;
+        case TILE_WS_128x128: RT_TRY(launch_ws<128>(l, s)); break;
+        case TILE_WS_128x64: RT_TRY(launch_ws<64>(l, s)); break;
         case TILE_TAIL_128x64: hipLaunchKernelGGL((conv_mfma_tail<128, 64, 2, 2, 3, 4>), l.grid(128, 64), dim3(256), 0, s, a[0]); break;
         case TILE_TAIL_64x64: hipLaunchKernelGGL((conv_mfma_tail<64, 64, 2, 2, 3, 4>), l.grid(64, 64), dim3(256), 0, s, a[0]); break;
         case TILE_TAIL_K64_128x128: hipLaunchKernelGGL((conv_mfma64_tail<128, 128, 4, 1, 2, 8>), l.grid(128, 128), dim3(256), 0, s, a[0]); break;

@@ -350,8 +350,8 @@ static int pick_tile(int M, int cout) {
         int t = atoi(e);
         if (t >= 0 && t < TILE_COUNT) return t;
     }
-    static const float eff[TILE_COUNT] = {1.0f, 0.85f, 0.62f, 0.75f, 0.85f, 0.5f, 0.4f, 0.4f, 1.05f, 0.9f, 0.65f, 0.9f, 1.0f, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    static const int occ[TILE_COUNT] = {3, 5, 8, 4, 5, 2, 3, 3, 2, 2, 3, 2, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1};
+    static const float eff[TILE_COUNT] = {1.0f, 0.85f, 0.62f, 0.75f, 0.85f, 0.5f, 0.4f, 0.4f, 1.05f, 0.9f, 0.65f, 0.9f, 1.0f};      // the rest (0): only reachable through the autotuner
+    static const int occ[TILE_COUNT] = {3, 5, 8, 4, 5, 2, 3, 3, 2, 2, 3, 2, 1};
     int best = 0;
     double best_cost = 1e30;
     for (int t = 0; t < TILE_COUNT; ++t) {
@@ -411,7 +411,8 @@ static int make_conv(rtmodt_detector *d, WeightFile &wf, const std::vector<std::
     c.tile = pick_tile(M, cout_eff);
     if (const char *e = getenv("RTMODT_TILE_K64")) {            // test hook: a 64-deep tile (incl. the 8-wave ones) wherever it is legal
         const int t = atoi(e);
-        if (t >= 0 && t < TILE_COUNT && tile_needs_cin64(t) && !tile_is_rows(t) && !tile_is_tail(t) && c.cin % 64 == 0 && kp % 64 == 0 && !dst) c.tile = t;
+        if (t >= 0 && t < TILE_COUNT && tile_needs_cin64(t) && !tile_is_rows(t) && !tile_is_tail(t) && c.cin % 64 == 0 && kp % 64 == 0 && !dst &&
+            (!tile_is_ws(t) || (c.ks == 1 && c.stride == 1 && tile_ws_fits(t, kp)))) c.tile = t;
     }
     if (const char *e = getenv("RTMODT_TILE_3X3S1")) {          // test hook: force a tap-reuse tile wherever it is legal
         int t = atoi(e);
@@ -884,6 +885,7 @@ static bool tile_legal(const ConvLaunch *c, int n, int t) {
     if (tile_is_rows(t) && !rows_ok) return false;
     if (c[0].in_lo.base && !tile_reads_lo(t)) return false;
     if (t >= TILE_K64_128x128_S2_W8 && t <= TILE_K64_256x64_S2_W8 && n != 1) return false;   // the 8-wave tiles have no group entry point
+    if (tile_is_ws(t) && (n != 1 || c[0].ks != 1 || c[0].stride != 1 || c[0].in_lo.base || !tile_ws_fits(t, c[0].kp))) return false;
     return true;
 }
 static bool tail_tile_legal(const ConvLaunch &c, int t) {
@@ -896,6 +898,7 @@ static int tile_lds_kib(int t) {
     const TileShape ts = tile_shape(t);
     if (tile_is_rows(t)) { const int rp = tile_needs_cin64(t) ? 8 : 16; return 2 * (ts.bm / rp + 1 + 3 * (ts.bn / rp)); }
     if (t >= TILE_WSK_64x64 && t <= TILE_WSK_64x32) return std::max(8 * (ts.bm / 16 + ts.bn / 16), 4 * (ts.bm / 16) * (ts.bn / 16));
+    if (tile_is_ws(t)) return 150;                         // persistent, (nearly) the whole LDS
     int stages = 3;
     switch (t) {
         case TILE_128x128_S4: stages = 4; break;
@@ -915,8 +918,13 @@ static int tune_conv(rtmodt_detector *d, hipEvent_t e0, hipEvent_t e1, const std
                      float &best_ms) {
     best_ms = 1e30f;
     int best_tile = tile_io;
+    static const bool tune_ws = getenv("RTMODT_TUNE_WS") != nullptr;
     for (int t = 0; t < TILE_COUNT; ++t) {
         if (!tile_legal(c, n, t)) continue;
+        // the weight-stationary 1x1 kernel halves the bytes through the global -> LDS path but runs ONE workgroup per CU with
+        // 32 KiB in flight: measured 20-40 % slower than the tile kernels on every 1x1 conv of YOLOv8s at 16 and 32 frames
+        // (profiles/r02/README.md), so the tuner skips it unless asked
+        if (tile_is_ws(t) && !tune_ws) continue;
         float ms;
         RT_TRY(time_launch(d, e0, e1, [&]() { return launch_conv_group(c, n, t, d->stream); }, ms));
         if (getenv("RTMODT_TUNE_LOG")) fprintf(stderr, "[tune] %-28s %-16s %8.2f us  (%d KiB LDS)\n", name.c_str(), tile_name(t), ms * 1e3f, tile_lds_kib(t));

@@ -1103,3 +1103,31 @@ def test_stem_and_layer1_in_one_launch(pkg, wdir, monkeypatch, src_hw, size, bat
             assert diff.max() <= 1e-3 * np.abs(x).max() + 1e-3 and (diff > 0).mean() < 2e-2, (float(diff.max()), float((diff > 0).mean()))
         a, b = outs["0"][0][img], outs["1"][0][img]
         assert len(a) == len(b) or abs(len(a) - len(b)) <= 2
+
+
+@pytest.mark.parametrize("tile,size,batch", [(42, 320, 2), (43, 320, 2), (42, 288, 3), (43, 640, 1)])
+def test_weight_stationary_1x1_tiles(pkg, wdir, monkeypatch, tile, size, batch):
+    """conv1x1_ws: a persistent workgroup keeps its cout slice of a 1x1 conv's weights resident in LDS and streams the pixel
+    tiles through a ring that keeps prefetching across tile boundaries.  Forced onto every 1x1 conv where it is legal
+    (cin % 64 == 0, the slice fits LDS, no half-resolution source); all layers against the oracle, pixel counts that are
+    not multiples of the 128-pixel tile (288 -> 36 x 36, 18 x 18, 9 x 9 maps) included."""
+    monkeypatch.setenv("RTMODT_TILE_K64", str(tile))
+    monkeypatch.setenv("RTMODT_BNECK", "0")
+    monkeypatch.setenv("RTMODT_TAIL", "0")
+    monkeypatch.setenv("RTMODT_UP_READ", "0")                # the neck's cv1 then has no half-resolution source: legal for this tile too
+    det, w = make_detector(pkg, wdir, "s", size, autotune=False, batch=batch)
+    used = [n for n, _, _ in det.profile(1) if "ws:" in n]
+    assert len(used) >= 8, used
+    frames = list(pkg.synth.frames(batch, size, size, seed=91 + tile))
+    det.detect_batch(frames)
+    names = [c.name for c in pkg.weights.spec("s")]
+    for img in range(batch):
+        inp, _, _ = det.debug_fetch(img, want_heads=False, want_pred=False)
+        gpu = fetch_layers(pkg, det, names, img)
+        taps = {}
+        Y.forward(inp.astype(np.float32), w, "s", taps=taps, force=gpu)
+        for n in gpu:
+            tol = 2e-3 * np.abs(taps[n]).max() + 2e-3
+            err = float(np.abs(taps[n] - gpu[n]).max())
+            assert err <= tol, f"tile {tile} img {img} layer {n}: max err {err:.4g} > tol {tol:.4g}"
+    det.close()

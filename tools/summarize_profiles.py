@@ -11,8 +11,8 @@ import os
 import shutil
 import sys
 
-src = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/r01"
-dst = sys.argv[2] if len(sys.argv) > 2 else "profiles/r01"
+src = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/r02"
+dst = sys.argv[2] if len(sys.argv) > 2 else "profiles/r02"
 os.makedirs(dst, exist_ok=True)
 
 
@@ -21,7 +21,7 @@ def one(pattern):
     return g[-1] if g else None
 
 
-for name in ("bench_default.json", "bench_host_frames.json", "bench_host_frames_pageable.json", "bench_streams16.json",
+for name in ("bench_default.json", "bench_driver_cmd.json", "bench_frames2.json", "bench_frames8.json", "bench_host_frames_F2.json", "layers_chains1_F2.txt", "layers_chains1_F8.txt", "bench_host_frames.json", "bench_host_frames_pageable.json", "bench_streams16.json",
              "bench_streams32.json", "bench_frames1.json", "bench_frames4.json", "bench_chains1.json", "bench_chains2.json", "bench_stages2.json", "stats_bench.json", "stats_chains1_bench.json", "layers_chains1.txt", "step_gaps_chains1.txt", "pipeline_640.json", "pipeline_1080p.json", "layers.txt", "step_gaps.txt",
              "bandwidth_probe.txt", "tracker_modes.json"):
     p = os.path.join(src, name)
@@ -79,7 +79,7 @@ if fetch and write:
     key = f"s-640-{cfg['streams_per_gpu']}x{cfg.get('frames_per_stream_per_step', 1)}"
     json.dump({"workload_key": key, "hbm_bytes_per_step": hbm, "fetch_size_kb_per_step": round(F, 1),
                "write_size_kb_per_step": round(W, 1),
-               "source": "profiles/r01/pmc_per_kernel.csv: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over "
+               "source": dst + "/pmc_per_kernel.csv: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over "
                          "`bench.py --steps 20`; forward-pass launches of the last 10 steps; bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 "
                          "(gfx950: FETCH_SIZE counts half of a wide coalesced read, MI355X_MICROARCH.md section HBM)"},
               open("profiles/traffic_current.json", "w"), indent=1)
