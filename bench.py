@@ -196,8 +196,11 @@ def main():
         if host:
             make_host_ring()
         mapped = host and args.host_mode == "mapped" and not args.pageable
-        # engine: the staged one with three stages (main, two more stage streams, post-processing = the four hardware queues)
-        stages = args.stages if args.stages > 0 else 3
+        # engine: the staged one.  Frames in HBM: three stages (main + two more stage streams + post-processing = the four hardware
+        # queues of the process).  Frames from the host: two stages, so that the copy stream keeps a queue of its own and the
+        # upload of batch t + 1 runs beside every stage of batch t (measured: 98 % of the HBM-resident rate, against 90 % with
+        # three stages and the upload in front of stage 1 on the main stream; profiles/r02/README.md)
+        stages = args.stages if args.stages > 0 else (2 if host else 3)
         det = pkg.Detector(wpath, input_size=(size, size), max_det=args.max_det, device=f"cuda:{dev}", batch=S * F,
                            use_graph=not args.no_graph, warmup=False, chains=1 - stages if stages > 1 else 1)
         trk = core_cls(device=dev, n_streams=S, max_dets=max(128, args.max_det), max_tracks=2048)

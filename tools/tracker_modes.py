@@ -15,10 +15,12 @@ out = {}
 for name, (n, size) in {"200 boxes @640": (200, 640), "500 boxes @1280": (500, 1280)}.items():
     xy, cf, cl = pkg.synth.box_sequence(n, size, 120, seed=1234)
     row = {}
-    for mode, am in (("greedy", pkg._ffi.ASSIGN_GREEDY), ("lapjv", pkg._ffi.ASSIGN_LAPJV)):
-        core = pkg.tracking.tracker._ByteTrackCore(assign_mode=am)
+    for mode, am in (("greedy", pkg._ffi.ASSIGN_GREEDY), ("lapjv", pkg._ffi.ASSIGN_LAPJV), ("greedy_kalman", pkg._ffi.ASSIGN_GREEDY)):
+        core = pkg.tracking.tracker._ByteTrackCore(assign_mode=am, kalman=mode.endswith("kalman"))
         ts = []
         for rep in range(3):
+            if rep and core.kalman:
+                break                                             # (reset keeps the filter arrays: one pass is enough for the timing)
             core.reset()
             for f in range(120):
                 t0 = time.perf_counter()
