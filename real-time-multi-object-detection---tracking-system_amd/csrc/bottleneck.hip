@@ -55,23 +55,7 @@ struct BneckArgs {
 
 constexpr int BN_THREADS = 512, BN_WAVES = 8;
 
-// Diagnostic build only (tools/probes/kernel_probe.hip, -DRTMODT_STAMP): lane 0 of every workgroup writes the shader clock at
-// phase boundaries into a buffer of its own; no product build contains a stamp.
-#ifdef RTMODT_STAMP
-__device__ unsigned long long *g_stamps;
-#define STAMP(k)                                                                                         \
-    do {                                                                                                 \
-        __builtin_amdgcn_sched_barrier(0);                                                               \
-        if (threadIdx.x == 0) {                                                                          \
-            unsigned long long t_;                                                                       \
-            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                    \
-            g_stamps[(size_t)blockIdx.x * 16 + (k)] = t_;                                                \
-        }                                                                                                \
-        __builtin_amdgcn_sched_barrier(0);                                                               \
-    } while (0)
-#else
-#define STAMP(k)
-#endif
+// (STAMP: kernels.h)
 
 template <int CH, int TH, int TW>
 struct BneckGeom {

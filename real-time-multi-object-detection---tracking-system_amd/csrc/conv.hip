@@ -374,6 +374,18 @@ __device__ __forceinline__ void wait_steps(int steps) {
     }
 }
 
+// the same with EXTRA younger operations (stores) that may stay outstanding
+template <int L, int MAXSTEPS, int EXTRA>
+__device__ __forceinline__ void wait_steps_plus(int steps) {
+    if constexpr (MAXSTEPS == 0) {
+        wait_vmcnt<EXTRA>();
+    } else {
+        static_assert(L * MAXSTEPS + EXTRA <= 63, "vmcnt is a 6-bit counter");
+        if (steps >= MAXSTEPS) wait_vmcnt<L * MAXSTEPS + EXTRA>();
+        else wait_steps_plus<L, MAXSTEPS - 1, EXTRA>(steps);
+    }
+}
+
 template <int BM, int BN, int WM, int WN, int NSTAGE, bool GENERAL, int N2T = 0>
 __device__ __forceinline__ void conv_mfma_body(const ConvArgs &p, const int bx, const int by) {
     static_assert(WM * WN == 4, "4 waves per workgroup");
@@ -871,11 +883,14 @@ __device__ __forceinline__ void conv_mfma_wsk_body(const ConvArgs &p, const int 
 // under the next tile's loads.  Same MFMA order per output as conv_mfma64 (k ascending), same swizzled piece layout.
 // ---------------------------------------------------------------------------------------
 template <int BN, int NSTAGE>
-__global__ __launch_bounds__(256) void conv1x1_ws(ConvArgs p, int groups) {
-    constexpr int BM = 128, NW = 4, WM = 2, WN = 2;
+__global__ __launch_bounds__(512) void conv1x1_ws(ConvArgs p, int groups) {
+    // 8 waves (two per SIMD): one wave's LDS-DMA issues and fragment reads run under its partner's MFMAs -- with four waves a
+    // k-step took 2 000 clk for 512 clk of MFMA (phase stamps, tools/probes/kernel_probe.hip)
+    constexpr int BM = 128, NW = 8, WM = 4, WN = 2;
     constexpr int NA = BM / 8, NB = BN / 8, LA = NA / NW, LBp = NB / NW;
     constexpr int DEPTH = NSTAGE - 1;
     constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
+    static_assert(TN % 2 == 0, "the epilogue pairs neighbouring cout tiles");
     extern __shared__ __attribute__((aligned(1024))) unsigned char ws_lds[];
     const int nk = p.kp / 64;
     unsigned char *wbase = ws_lds, *abase = ws_lds + nk * NB * 1024;
@@ -892,6 +907,7 @@ __global__ __launch_bounds__(256) void conv1x1_ws(ConvArgs p, int groups) {
     const int rd_off0 = rd_base + (((0 + q) ^ ((r >> 1) & 7)) << 4);
     const int rd_off1 = rd_base + (((4 + q) ^ ((r >> 1) & 7)) << 4);
 
+    STAMP(0);
     // ---- the weight slice: resident ----
     for (int kt = 0; kt < nk; ++kt)
 #pragma unroll
@@ -919,6 +935,11 @@ __global__ __launch_bounds__(256) void conv1x1_ws(ConvArgs p, int groups) {
         is_stage = is_stage + 1 == NSTAGE ? 0 : is_stage + 1;
     };
     const int wm = wave / WN, wn = wave % WN;
+    // Epilogue layout: a lane holds 4 consecutive couts (8 bytes) of one pixel per accumulator tile.  Neighbouring cout tiles
+    // u, u + 1 are exchanged between the lane pair (q, q ^ 1): the even-q lane ends up with 8 consecutive couts of tile u, the
+    // odd-q lane with 8 of tile u + 1 -- 16-byte stores, 64 contiguous bytes per pixel and instruction, no LDS round trip
+    // (the direct 8-byte stores of the first version took 11 000 clk per 128 x 128 tile).
+    const int qe = q & ~1, odd = q & 1;
     floatx4 bv[TN];
 #pragma unroll
     for (int u = 0; u < TN; ++u) bv[u] = *(const floatx4 *)(p.bias + n0 + (wn * TN + u) * 16 + q * 4);
@@ -930,12 +951,26 @@ __global__ __launch_bounds__(256) void conv1x1_ws(ConvArgs p, int groups) {
 #pragma unroll
     for (int i = 0; i < DEPTH; ++i)
         if (i < S) issue();
+    STAMP(1);
     int kt = 0, tile = 0, rstage = 0;
+    // vmcnt counts the epilogue's global STORES together with the LDS-DMAs, in issue order: for the DEPTH steps after a tile's
+    // epilogue its stores are YOUNGER than the stage being waited for and must be allowed to stay outstanding -- a wait that
+    // ignores them drains the whole ring at every tile boundary.  The count is exact because this kernel only runs shapes whose
+    // every tile is full (M % 128 == 0, cout % BN == 0, no second destination): each of the TM x TN store instructions executes.
+    constexpr int NST = TM * TN / 2;                        // one 16-byte store per pair of cout tiles
+    int store_credit = 0;
     for (int s = 0; s < S; ++s) {
         // everything issued before step s's successors has landed: the weights (issued first of all) and stage s
-        wait_steps<LA, DEPTH - 1>(min(DEPTH - 1, S - 1 - s));
+        const int ahead = min(DEPTH - 1, S - 1 - s);
+        if (store_credit > 0) { wait_steps_plus<LA, DEPTH - 1, NST>(ahead); --store_credit; }
+        else wait_steps<LA, DEPTH - 1>(ahead);
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+        if (s == 0) STAMP(2);
+        if (s == 1) STAMP(3);
+        if (s == 2) STAMP(4);
+        if (s == 3) STAMP(5);
+        if (s == 4) STAMP(6);
         if (s + DEPTH < S) issue();                         // refills the stage read in step s - 1
         const unsigned char *sA = abase + rstage * (NA * 1024);
         const unsigned char *sB = wbase + kt * (NB * 1024);
@@ -960,16 +995,34 @@ __global__ __launch_bounds__(256) void conv1x1_ws(ConvArgs p, int groups) {
 #pragma unroll
             for (int t = 0; t < TM; ++t) {
                 long opix, rpix, opix2;
-                const bool live = pixel_offsets(p, m0 + (wm * TM + t) * 16 + r, opix, rpix, opix2);
+                pixel_offsets(p, m0 + (wm * TM + t) * 16 + r, opix, rpix, opix2);      // (every tile is full: always live)
 #pragma unroll
-                for (int u = 0; u < TN; ++u) {
-                    const int n = n0 + (wn * TN + u) * 16 + q * 4;
-                    if (live && n < p.cout) store_tile(p, acc[t][u], bv[u], opix, rpix, n, opix2);
+                for (int u = 0; u < TN; u += 2) {
+                    floatx4 v0 = acc[t][u] + bv[u], v1 = acc[t][u + 1] + bv[u + 1];
+                    if (p.act) {
+                        v0[0] = silu_f(v0[0]); v0[1] = silu_f(v0[1]); v0[2] = silu_f(v0[2]); v0[3] = silu_f(v0[3]);
+                        v1[0] = silu_f(v1[0]); v1[1] = silu_f(v1[1]); v1[2] = silu_f(v1[2]); v1[3] = silu_f(v1[3]);
+                    }
+                    const half4 h0 = {(f16)v0[0], (f16)v0[1], (f16)v0[2], (f16)v0[3]}, h1 = {(f16)v1[0], (f16)v1[1], (f16)v1[2], (f16)v1[3]};
+                    // the even-q lane keeps tile u and receives its partner's tile u; the odd-q lane keeps tile u + 1
+                    const half4 give = odd ? h0 : h1, keep = odd ? h1 : h0;
+                    u32x2 gw = __builtin_bit_cast(u32x2, give);
+                    gw[0] = (unsigned)__shfl_xor((int)gw[0], 16);
+                    gw[1] = (unsigned)__shfl_xor((int)gw[1], 16);
+                    const half4 got = __builtin_bit_cast(half4, gw);
+                    const half4 lo = odd ? got : keep, hi = odd ? keep : got;
+                    const half8 o = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    const int n = n0 + (wn * TN + u + odd) * 16 + qe * 4;
+                    store16(p.out, opix + n, o, p.wthru);
                     acc[t][u] = floatx4{0.f, 0.f, 0.f, 0.f};
+                    acc[t][u + 1] = floatx4{0.f, 0.f, 0.f, 0.f};
                 }
             }
+            store_credit = DEPTH;
+            if (tile == 1) STAMP(7);
         }
     }
+    STAMP(9);
 }
 
 // ---- kernel entry points: one problem per launch, or a GROUP of independent problems that
@@ -1170,25 +1223,38 @@ static int launch_k64_w8(const LaunchPlan &l, hipStream_t s) {
     return RTMODT_OK;
 }
 
+template <int BN, int NSTAGE>
+static int launch_ws_n(const ConvArgs &a, int smem, hipStream_t s) {
+    const int slices = cdiv(a.cout, BN), n_mt = cdiv(a.M, 128);
+    const int groups = std::max(1, std::min(n_mt, 256 / slices));      // one persistent workgroup per CU
+    static bool attr[64] = {};
+    int dev = 0;
+    RT_HIP(hipGetDevice(&dev));
+    if (dev >= 0 && dev < 64 && !attr[dev]) {
+        RT_HIP(hipFuncSetAttribute((const void *)conv1x1_ws<BN, NSTAGE>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
+        attr[dev] = true;
+    }
+    hipLaunchKernelGGL((conv1x1_ws<BN, NSTAGE>), dim3(groups, slices), dim3(512), smem, s, a, groups);
+    return RTMODT_OK;
+}
 template <int BN>
 static int launch_ws(const LaunchPlan &l, hipStream_t s) {
     const ConvArgs &a = l.a[0];
-    RT_CHECK(l.n == 1 && a.ks == 1 && a.stride == 1 && !a.in2 && a.cin % 64 == 0 && a.kp % 64 == 0, RTMODT_E_INVALID,
-             "launch_conv: the weight-stationary tile runs one 1x1 stride-1 conv with cin %% 64 == 0 and no half-resolution source");
-    constexpr int NSTAGE = 3;
-    const int nk = a.kp / 64, smem = (nk * (BN / 8) + NSTAGE * 16) * 1024;
-    RT_CHECK(smem <= 156 * 1024, RTMODT_E_INVALID, "launch_conv: weight slice %d x %d does not fit LDS", BN, a.kp);
-    const int slices = cdiv(a.cout, BN), n_mt = cdiv(a.M, 128);
-    const int groups = std::max(1, std::min(n_mt, 256 / slices));      // one persistent workgroup per CU
-    static int attr[64] = {};
-    int dev = 0;
-    RT_HIP(hipGetDevice(&dev));
-    if (dev >= 0 && dev < 64 && smem > attr[dev]) {
-        RT_HIP(hipFuncSetAttribute((const void *)conv1x1_ws<BN, NSTAGE>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
-        attr[dev] = 156 * 1024;
+    RT_CHECK(l.n == 1 && a.ks == 1 && a.stride == 1 && !a.in2 && a.cin % 64 == 0 && a.kp % 64 == 0 && a.M % 128 == 0 && a.cout % BN == 0 && !a.out2 && !a.res && a.epi16,
+             RTMODT_E_INVALID, "launch_conv: the weight-stationary tile runs one 1x1 stride-1 conv with cin %% 64 == 0, full tiles (M %% 128 == 0, cout %% BN == 0), "
+             "no half-resolution source, residual or second destination");
+    const int nk = a.kp / 64, wkib = nk * (BN / 8);
+    RT_CHECK(wkib + 3 * 16 <= 156, RTMODT_E_INVALID, "launch_conv: weight slice %d x %d does not fit LDS", BN, a.kp);
+    // the pixel ring takes what the weight slice leaves: the bytes in flight towards LDS are what sets the rate
+    int nst = std::min(6, (156 - wkib) / 16);
+    if (const char *e = getenv("RTMODT_WS_STAGES")) nst = std::max(3, std::min(nst, atoi(e)));
+    const int smem = (wkib + nst * 16) * 1024;
+    switch (nst) {
+        case 3: return launch_ws_n<BN, 3>(a, smem, s);
+        case 4: return launch_ws_n<BN, 4>(a, smem, s);
+        case 5: return launch_ws_n<BN, 5>(a, smem, s);
+        default: return launch_ws_n<BN, 6>(a, smem, s);
     }
-    hipLaunchKernelGGL((conv1x1_ws<BN, NSTAGE>), dim3(groups, slices), dim3(256), smem, s, a, groups);
-    return RTMODT_OK;
 }
 
 template <int BM, int BN, int WM, int WN, bool K64>

@@ -412,7 +412,7 @@ static int make_conv(rtmodt_detector *d, WeightFile &wf, const std::vector<std::
     if (const char *e = getenv("RTMODT_TILE_K64")) {            // test hook: a 64-deep tile (incl. the 8-wave ones) wherever it is legal
         const int t = atoi(e);
         if (t >= 0 && t < TILE_COUNT && tile_needs_cin64(t) && !tile_is_rows(t) && !tile_is_tail(t) && c.cin % 64 == 0 && kp % 64 == 0 && !dst &&
-            (!tile_is_ws(t) || (c.ks == 1 && c.stride == 1 && tile_ws_fits(t, kp)))) c.tile = t;
+            (!tile_is_ws(t) || (c.ks == 1 && c.stride == 1 && tile_ws_fits(t, kp) && ((long)d->B * out.H * out.W) % 128 == 0 && cout_eff % tile_shape(t).bn == 0 && !res && out.coff % 8 == 0 && out.C % 8 == 0))) c.tile = t;
     }
     if (const char *e = getenv("RTMODT_TILE_3X3S1")) {          // test hook: force a tap-reuse tile wherever it is legal
         int t = atoi(e);
@@ -546,6 +546,7 @@ static int build_graph(rtmodt_detector *d, WeightFile &wf) {
     // a conv that also writes the nearest-2x copy cannot run as the tail of the Bottleneck before it
     auto fold_into_last = [&](const TensorView &up) {
         d->ops.back().conv.out2 = up;
+        if (tile_is_ws(d->ops.back().conv.tile)) d->ops.back().conv.tile = TILE_K64_128x128_S2;      // (test hook's forced tile: no second destination there)
         d->ops.back().skip = false;
         if (d->ops.size() >= 2) { Op &bn = d->ops[d->ops.size() - 2]; if (bn.kind == OP_BNECK) { bn.bneck.tail_wt = nullptr; bn.tail_on = false; } }
     };
@@ -885,7 +886,8 @@ static bool tile_legal(const ConvLaunch *c, int n, int t) {
     if (tile_is_rows(t) && !rows_ok) return false;
     if (c[0].in_lo.base && !tile_reads_lo(t)) return false;
     if (t >= TILE_K64_128x128_S2_W8 && t <= TILE_K64_256x64_S2_W8 && n != 1) return false;   // the 8-wave tiles have no group entry point
-    if (tile_is_ws(t) && (n != 1 || c[0].ks != 1 || c[0].stride != 1 || c[0].in_lo.base || !tile_ws_fits(t, c[0].kp))) return false;
+    if (tile_is_ws(t) && (n != 1 || c[0].ks != 1 || c[0].stride != 1 || c[0].in_lo.base || c[0].res.base || c[0].out2.base || !tile_ws_fits(t, c[0].kp) ||
+                          ((long)c[0].B * c[0].out.H * c[0].out.W) % 128 != 0 || c[0].cout % tile_shape(t).bn != 0 || c[0].out.coff % 8 != 0 || c[0].out.C % 8 != 0)) return false;
     return true;
 }
 static bool tail_tile_legal(const ConvLaunch &c, int t) {
@@ -932,7 +934,9 @@ static int tune_conv(rtmodt_detector *d, hipEvent_t e0, hipEvent_t e1, const std
         // whose workgroup takes more than half the LDS keeps every other workgroup off its CU (experiment hook)
         static const float lds_penalty = getenv("RTMODT_TUNE_LDS_PENALTY") ? (float)atof(getenv("RTMODT_TUNE_LDS_PENALTY")) : 0.f;
         static const int lds_cap = getenv("RTMODT_TUNE_LDS_CAP") ? atoi(getenv("RTMODT_TUNE_LDS_CAP")) : 80;
-        if (d->pipe && tile_lds_kib(t) > lds_cap) ms *= 1.f + lds_penalty;
+        if (d->pipe && tile_lds_kib(t) > lds_cap && !tile_is_ws(t)) ms *= 1.f + lds_penalty;
+        static const float ws_bias = getenv("RTMODT_TUNE_WS_BIAS") ? (float)atof(getenv("RTMODT_TUNE_WS_BIAS")) : 1.f;      // experiment hook
+        if (tile_is_ws(t)) ms *= ws_bias;
         if (ms < best_ms) { best_ms = ms; best_tile = t; }
     }
     tile_io = best_tile;

@@ -5,6 +5,24 @@
 
 namespace rtmodt {
 
+// Diagnostic build only (tools/probes/kernel_probe.hip, -DRTMODT_STAMP): lane 0 of every workgroup writes the shader clock at
+// phase boundaries into a buffer of its own; no product build contains a stamp.
+#ifdef RTMODT_STAMP
+extern __device__ unsigned long long *g_stamps;
+#define STAMP(k)                                                                                         \
+    do {                                                                                                 \
+        __builtin_amdgcn_sched_barrier(0);                                                               \
+        if (threadIdx.x == 0) {                                                                          \
+            unsigned long long t_;                                                                       \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                    \
+            g_stamps[(size_t)(blockIdx.x + blockIdx.y * gridDim.x) * 16 + (k)] = t_;                                                \
+        }                                                                                                \
+        __builtin_amdgcn_sched_barrier(0);                                                               \
+    } while (0)
+#else
+#define STAMP(k)
+#endif
+
 // ---------------------------------------------------------------------------------------
 // Activation tensors: fp16 NHWC with an optional 1-pixel zero border,
 //   element (b, y, x, c) at ((b*(H+2*pad) + y + pad)*(W+2*pad) + x + pad)*C + c.

@@ -1105,23 +1105,24 @@ def test_stem_and_layer1_in_one_launch(pkg, wdir, monkeypatch, src_hw, size, bat
         assert len(a) == len(b) or abs(len(a) - len(b)) <= 2
 
 
-@pytest.mark.parametrize("tile,size,batch", [(42, 320, 2), (43, 320, 2), (42, 288, 3), (43, 640, 1)])
+@pytest.mark.parametrize("tile,size,batch", [(42, 320, 32), (43, 320, 32), (42, 640, 8), (43, 288, 3)])
 def test_weight_stationary_1x1_tiles(pkg, wdir, monkeypatch, tile, size, batch):
     """conv1x1_ws: a persistent workgroup keeps its cout slice of a 1x1 conv's weights resident in LDS and streams the pixel
     tiles through a ring that keeps prefetching across tile boundaries.  Forced onto every 1x1 conv where it is legal
-    (cin % 64 == 0, the slice fits LDS, no half-resolution source); all layers against the oracle, pixel counts that are
-    not multiples of the 128-pixel tile (288 -> 36 x 36, 18 x 18, 9 x 9 maps) included."""
+    (cin % 64 == 0, the slice fits LDS, full tiles: pixels % 128 == 0 and cout % BN == 0, no half-resolution source); all
+    layers of the first and the last image against the oracle.  288 x 288 x 3: no map is a multiple of 128 pixels -- the tile
+    is legal nowhere and every conv must fall back to its default tile."""
     monkeypatch.setenv("RTMODT_TILE_K64", str(tile))
     monkeypatch.setenv("RTMODT_BNECK", "0")
     monkeypatch.setenv("RTMODT_TAIL", "0")
     monkeypatch.setenv("RTMODT_UP_READ", "0")                # the neck's cv1 then has no half-resolution source: legal for this tile too
     det, w = make_detector(pkg, wdir, "s", size, autotune=False, batch=batch)
     used = [n for n, _, _ in det.profile(1) if "ws:" in n]
-    assert len(used) >= 8, used
+    assert (len(used) >= 5) if size != 288 else (len(used) == 0), used
     frames = list(pkg.synth.frames(batch, size, size, seed=91 + tile))
     det.detect_batch(frames)
     names = [c.name for c in pkg.weights.spec("s")]
-    for img in range(batch):
+    for img in sorted({0, batch - 1}):
         inp, _, _ = det.debug_fetch(img, want_heads=False, want_pred=False)
         gpu = fetch_layers(pkg, det, names, img)
         taps = {}
