@@ -39,6 +39,19 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 
+// Division by a launch constant: n / d == (n * mul) >> shift for every 0 <= n < 2^31 (shift = 31 + ceil(log2 d),
+// mul = ceil(2^shift / d) < 2^32: the error term n * (mul * d - 2^shift) stays below 2^shift).  One 32x32->64 multiply and
+// one shift instead of the ~30-instruction expansion of an integer division: the epilogues turn a pixel index into
+// (image, row, column) once per 16-byte store.
+struct FastDiv { unsigned mul, shift; };
+static inline FastDiv make_fastdiv(int d) {
+    unsigned s = 0;
+    while ((1u << s) < (unsigned)d) ++s;
+    const unsigned long long p2 = 1ull << (31 + s);
+    return FastDiv{(unsigned)((p2 + (unsigned)d - 1) / (unsigned)d), 31 + s};
+}
+__device__ __forceinline__ int fdiv(int n, const FastDiv &f) { return (int)(((unsigned long long)(unsigned)n * f.mul) >> f.shift); }
+
 struct ConvArgs {
     const f16 *in;      // input tensor base + channel offset
     const f16 *wt;
@@ -49,6 +62,8 @@ struct ConvArgs {
     int out_Hp, out_Wp, out_cs, out_pad;
     int res_Hp, res_Wp, res_cs, res_pad;
     int Ho, Wo, M;                       // M = B*Ho*Wo
+    FastDiv d_howo, d_wo;                // m -> (image, row, column) of the output
+    FastDiv d_hwp, d_wp;                 // the same over the PADDED input grid (tap-reuse kernel)
     f16 *out2;                           // optional second destination: nearest-2x upsampled copy (neck concat slice)
     int out2_Hp, out2_Wp, out2_cs, out2_pad;
     int cin, cout, ks, stride, act, kp, K;
@@ -182,8 +197,8 @@ __device__ __forceinline__ long upsampled_offset(const ConvArgs &p, int b, int o
 __device__ __forceinline__ bool pixel_offsets(const ConvArgs &p, int m, long &opix, long &rpix, long &opix2) {
     if (m >= p.M) return false;
     const int HoWo = p.Ho * p.Wo;
-    int b = m / HoWo, rem = m - b * HoWo;
-    int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+    int b = fdiv(m, p.d_howo), rem = m - b * HoWo;
+    int oy = fdiv(rem, p.d_wo), ox = rem - oy * p.Wo;
     opix = ((long)(b * p.out_Hp + oy + p.out_pad) * p.out_Wp + ox + p.out_pad) * p.out_cs;
     rpix = p.res ? ((long)(b * p.res_Hp + oy + p.res_pad) * p.res_Wp + ox + p.res_pad) * p.res_cs : 0;
     opix2 = upsampled_offset(p, b, oy, ox);
@@ -194,16 +209,16 @@ __device__ __forceinline__ bool pixel_offsets(const ConvArgs &p, int m, long &op
 __device__ __forceinline__ int input_offset_lo(const ConvArgs &p, int m) {
     m = m < p.M ? m : p.M - 1;
     const int HoWo = p.Ho * p.Wo;
-    int b = m / HoWo, rem = m - b * HoWo;
-    int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+    int b = fdiv(m, p.d_howo), rem = m - b * HoWo;
+    int oy = fdiv(rem, p.d_wo), ox = rem - oy * p.Wo;
     return ((b * p.in2_Hp + (oy >> 1) + p.in2_pad) * p.in2_Wp + (ox >> 1) + p.in2_pad) * p.in2_cs;
 }
 
 __device__ __forceinline__ int input_offset(const ConvArgs &p, int m) {
     m = m < p.M ? m : p.M - 1;                           // tail rows re-read the last pixel (masked at store)
     const int HoWo = p.Ho * p.Wo;
-    int b = m / HoWo, rem = m - b * HoWo;
-    int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+    int b = fdiv(m, p.d_howo), rem = m - b * HoWo;
+    int oy = fdiv(rem, p.d_wo), ox = rem - oy * p.Wo;
     return ((b * p.in_Hp + oy * p.stride + p.in_org) * p.in_Wp + ox * p.stride + p.in_org) * p.in_cs;
 }
 
@@ -219,6 +234,7 @@ __device__ __forceinline__ void epilogue_lds(const ConvArgs &p, const int n0, co
     constexpr int ROWB = BN * 2 + 16;                      // +16: the b64 writes of a 16-pixel group land in distinct banks
     const int lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
     __syncthreads();                                       // every wave is done reading the last stage
+    STAMP(7);
 #pragma unroll
     for (int t = 0; t < TM; ++t) {
         const int pm = (wm * TM + t) * 16 + r;
@@ -236,7 +252,9 @@ __device__ __forceinline__ void epilogue_lds(const ConvArgs &p, const int n0, co
             *(half4 *)(lds + pm * ROWB + nl * 2) = half4{(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
         }
     }
+    STAMP(8);
     __syncthreads();
+    STAMP(9);
     constexpr int CPR = BN / 8;                            // 16-byte chunks per pixel
     for (int c = threadIdx.x; c < BM * CPR; c += NTHREADS) {
         const int pm = c / CPR, k8 = c - pm * CPR, n = n0 + k8 * 8;
@@ -352,8 +370,8 @@ constexpr int tail_lds_bytes() {
 __device__ __forceinline__ bool tail_pixel_offset(const ConvArgs &p, int m, long &opix) {
     if (m >= p.M) return false;
     const int HoWo = p.Ho * p.Wo;
-    const int b = m / HoWo, rem = m - b * HoWo;
-    const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+    const int b = fdiv(m, p.d_howo), rem = m - b * HoWo;
+    const int oy = fdiv(rem, p.d_wo), ox = rem - oy * p.Wo;
     opix = ((long)(b * p.t_out_Hp + oy + p.t_out_pad) * p.t_out_Wp + ox + p.t_out_pad) * p.t_out_cs;
     return true;
 }
@@ -444,9 +462,11 @@ __device__ __forceinline__ void conv_mfma_body(const ConvArgs &p, const int bx, 
     floatx4 bv[TN];                                        // bias fetched now, consumed after the k-loop (padded to 128 rows)
 #pragma unroll
     for (int u = 0; u < TN; ++u) bv[u] = *(const floatx4 *)(p.bias + n0 + (wn * TN + u) * 16 + q * 4);
+    STAMP(0);
 #pragma unroll
     for (int i = 0; i < DEPTH; ++i)
         if (i < nk) issue(i, i);
+    STAMP(1);
     int rstage = 0, wstage = DEPTH % NSTAGE;              // stage read this step / stage refilled this step
     for (int kt = 0; kt < nk; ++kt) {
         // stage kt has landed once only the pieces of the (up to DEPTH-1) later steps are outstanding
@@ -454,6 +474,7 @@ __device__ __forceinline__ void conv_mfma_body(const ConvArgs &p, const int bx, 
         if (LBR != 0 && wave < LBR) wait_steps<LA + LBF + 1, DEPTH - 1>(ahead); else wait_steps<LA + LBF, DEPTH - 1>(ahead);
         __builtin_amdgcn_s_barrier();                     // everyone's stage kt landed; everyone is done reading stage kt-1
         asm volatile("" ::: "memory");
+        if (kt < 3) STAMP(2 + kt);
         if (kt + DEPTH < nk) issue(kt + DEPTH, wstage);   // refills the stage read in step kt-1
         const unsigned char *sbase = lds + rstage * STAGE;
         rstage = rstage + 1 == NSTAGE ? 0 : rstage + 1;
@@ -470,13 +491,16 @@ __device__ __forceinline__ void conv_mfma_body(const ConvArgs &p, const int bx, 
                 acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[u], fa[t], acc[t][u], 0, 0, 0);
     }
 
+    STAMP(5);
     // ---- epilogue: D[row = cout (lane>>4)*4+j][col = pixel lane&15] ----
     if constexpr (N2T > 0) {
         epilogue_tail<BM, BN, TM, TN, N2T>(p, acc, bv, lds, wm, wn, [&](int pm, long &o) { return tail_pixel_offset(p, m0 + pm, o); });
+        STAMP(6);
         return;
     }
     if (p.epi16) {
         epilogue_lds<BM, BN, TM, TN>(p, n0, acc, bv, lds, wm, wn, [&](int pm, long &o, long &rp, long &o2) { return pixel_offsets(p, m0 + pm, o, rp, o2); });
+        STAMP(6);
         return;
     }
 #pragma unroll
@@ -751,8 +775,8 @@ __device__ __forceinline__ void conv3x3_rows_body(const ConvArgs &p, const int b
         epilogue_lds<BM, BN, TM, TN, NW * 64>(p, n0, acc, bv, lds, wm, wn, [&](int pm, long &opix, long &rpix, long &opix2) {
             const int m = m0 + pm;
             if (m >= Mp) return false;
-            const int b = m / HW, rem = m - b * HW;
-            const int oy = rem / p.in_Wp, ox = rem - oy * p.in_Wp;
+            const int b = fdiv(m, p.d_hwp), rem = m - b * HW;
+            const int oy = fdiv(rem, p.d_wp), ox = rem - oy * p.in_Wp;
             if (oy >= p.Ho || ox >= p.Wo) return false;
             opix = ((long)(b * p.out_Hp + oy + p.out_pad) * p.out_Wp + ox + p.out_pad) * p.out_cs;
             rpix = p.res ? ((long)(b * p.res_Hp + oy + p.res_pad) * p.res_Wp + ox + p.res_pad) * p.res_cs : 0;
@@ -765,8 +789,8 @@ __device__ __forceinline__ void conv3x3_rows_body(const ConvArgs &p, const int b
     for (int t = 0; t < TM; ++t) {
         int m = m0 + (wm * TM + t) * 16 + r;
         if (m >= Mp) continue;
-        int b = m / HW, rem = m - b * HW;
-        int oy = rem / p.in_Wp, ox = rem - oy * p.in_Wp;
+        int b = fdiv(m, p.d_hwp), rem = m - b * HW;
+        int oy = fdiv(rem, p.d_wp), ox = rem - oy * p.in_Wp;
         if (oy >= p.Ho || ox >= p.Wo) continue;
         long opix = ((long)(b * p.out_Hp + oy + p.out_pad) * p.out_Wp + ox + p.out_pad) * p.out_cs;
         long rpix = p.res ? ((long)(b * p.res_Hp + oy + p.res_pad) * p.res_Wp + ox + p.res_pad) * p.res_cs : 0;
@@ -1327,6 +1351,8 @@ static int make_args(const ConvLaunch &c, ConvArgs &a) {
         a.split = c.lo_c;
     }
     a.M = c.B * a.Ho * a.Wo;
+    a.d_howo = make_fastdiv(a.Ho * a.Wo); a.d_wo = make_fastdiv(a.Wo);
+    a.d_hwp = make_fastdiv(a.in_Hp * a.in_Wp); a.d_wp = make_fastdiv(a.in_Wp);
     a.cin = c.cin; a.cout = c.cout; a.ks = c.ks; a.stride = c.stride; a.act = c.act;
     a.K = c.ks * c.ks * c.cin;
     a.kp = c.kp;
@@ -1566,51 +1592,25 @@ __global__ __launch_bounds__(256) void stem_fused(StemSrc src, const f16 *__rest
     const int p = lane & 15, q = lane >> 4;
     const int b = blockIdx.x / Ho, oy = blockIdx.x - b * Ho;
     (void)lut_g;                                           // (the c/255 table of the first version; kept in the signature)
-    // ---- assemble the three rows ----
+    STAMP(0);
+    // ---- the three source rows, RAW: whole aligned 16-byte chunks by LDS-DMA (1 KiB per wave instruction, no VGPR trip,
+    // no byte shifting here).  Row r of the canvas rows 2oy-1 .. 2oy+1 lands at raw + r * rowb with its first source byte
+    // at offset mis[r] = (address of the source row) & 15.  Chunk addresses are clamped to the chunks that hold at least
+    // one frame byte (a 16-byte aligned chunk never crosses a page), so nothing outside the frame's pages is touched;
+    // clamped chunks only ever cover bytes no canvas pixel maps to. ----
     const uint8_t *f = src.frames.p[src.frame0 + b];
-    const int ndw = rowb >> 2;
-    // the frame as aligned dwords: fw[0] holds the frame's first byte at byte offset fa (all address arithmetic stays on
-    // the global pointer -- going through uintptr_t turned these loads into flat loads inside branches)
-    const int fa = (int)((uintptr_t)f & 3);
-    const unsigned *fw = (const unsigned *)(f - fa);
-    const int fdw = (fa + src.frame_bytes + 3) >> 2;      // dwords that hold frame bytes
-    // every load of a pass is issued before the first one is used: one trip to memory per pass instead of one per dword
-    constexpr int PF = 6;                                  // 3 rows x 480 dwords at 640 wide = 5.6 per thread
-    for (int base = 0; base < 3 * ndw; base += 256 * PF) {
-        unsigned v0[PF], v1[PF];
-        // canvas bytes [4 dwi, 4 dwi + 4) <- source row bytes [4 dwi - 3 left, ...) where inside [0, 3 new_w)
-        auto locate = [&](int k, int &i, int &s0, int &a) -> bool {
-            i = base + k * 256 + threadIdx.x;
-            const int r = (i >= ndw) + (i >= 2 * ndw), dwi = i - r * ndw;
-            const int y = 2 * oy - 1 + r, sy = y - src.top;
-            s0 = 4 * dwi - 3 * src.left;
-            const bool live = i < 3 * ndw && y >= 0 && y < src.in_h && sy >= 0 && sy < src.new_h && s0 > -4 && s0 < 3 * src.new_w;
-            a = live ? sy * src.pitch + s0 + fa : 0;      // byte offset from fw (>= -3; the frame is < 2^31 bytes)
-            return live;
-        };
-#pragma unroll
-        for (int k = 0; k < PF; ++k) {                     // loads only (clamped addresses, always legal)
-            int i, s0, a;
-            locate(k, i, s0, a);
-            const int w0 = a >> 2;                         // arithmetic shift: floor
-            v0[k] = fw[min(max(w0, 0), fdw - 1)];
-            v1[k] = fw[min(max(w0 + 1, 0), fdw - 1)];
-        }
-#pragma unroll
-        for (int k = 0; k < PF; ++k) {
-            int i, s0, a;
-            const bool live = locate(k, i, s0, a);
-            if (i >= 3 * ndw) continue;
-            const int w0 = a >> 2, sh = (a & 3) * 8;
-            const unsigned lo = live && w0 >= 0 && w0 < fdw ? v0[k] : 0u;
-            const unsigned hi = live && sh != 0 && w0 + 1 >= 0 && w0 + 1 < fdw ? v1[k] : 0u;
-            const unsigned w = sh ? (lo >> sh) | (hi << (32 - sh)) : lo;
-            unsigned m = 0u;                               // bytes of this dword that fall inside the source row
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (live && s0 + j >= 0 && s0 + j < 3 * src.new_w) m |= 0xFFu << (8 * j);
-            ((unsigned *)rows)[i] = (w & m) | (0x72727272u & ~m);      // 114 everywhere the canvas has no image
-        }
+    const uint8_t *flo = f - ((uintptr_t)f & 15);
+    const long fspan = (((uintptr_t)f & 15) + src.frame_bytes + 15) & ~15L;     // bytes from flo to the end of the last chunk
+    const int ipr = rowb >> 10;                              // wave instructions per row
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    for (int i = wave_u; i < 3 * ipr; i += 4) {
+        const int r = i / ipr, part = i - r * ipr;
+        const int y = 2 * oy - 1 + r, sy = y - src.top;
+        if (y < 0 || y >= src.in_h || sy < 0 || sy >= src.new_h) continue;       // (wave-uniform) pad row or outside the canvas
+        const long row0 = ((uintptr_t)f & 15) + (long)sy * src.pitch;            // source row's first byte, from flo
+        long off = (row0 & ~15L) + (part * 64 + lane) * 16;
+        off = off < 0 ? 0 : (off > fspan - 16 ? fspan - 16 : off);
+        glds16((const f16 *)(flo + off), rows + r * rowb + part * 1024);
     }
     half8 wf[NT][2];
 #pragma unroll
@@ -1620,18 +1620,45 @@ __global__ __launch_bounds__(256) void stem_fused(StemSrc src, const f16 *__rest
     floatx4 bv[NT];
 #pragma unroll
     for (int u = 0; u < NT; ++u) bv[u] = *(const floatx4 *)(bias + u * 16 + q * 4);
+    STAMP(1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    // ---- bytes -> (R, G, B, 0) fp16 pixels; canvas column x sits at index x + 1, zeros outside the canvas ----
-    // Four pixels = three aligned dwords per work item; byte -> float -> * (1/255) -> half equals the letterbox kernel's
-    // (half)(c / 255.f) for all 256 byte values (checked exhaustively: tests/test_oracle_yolo.py), so no table is needed.
+    STAMP(2);
+    // ---- bytes -> (R, G, B, 0) fp16 pixels; canvas column x sits at index x + 1, zeros outside the canvas, 114 where the
+    // canvas has no image ----
+    // Four pixels = twelve source bytes per work item, read as four aligned dwords and byte-aligned with v_alignbyte;
+    // byte -> float -> * (1/255) -> half equals the letterbox kernel's (half)(c / 255.f) for all 256 byte values (checked
+    // exhaustively: tests/test_oracle_yolo.py), so no table is needed.
     const int pw = src.in_w + 2;
     const int qpr = src.in_w >> 2;                         // groups of four pixels per row
     for (int i = threadIdx.x; i < 3 * qpr; i += 256) {
         const int r = i / qpr, g = i - r * qpr;
-        const int y = 2 * oy - 1 + r;
-        const unsigned *rp = (const unsigned *)(rows + r * rowb) + 3 * g;
-        const unsigned d0 = rp[0], d1 = rp[1], d2 = rp[2];
-        const float k = y >= 0 && y < src.in_h ? 1.0f / 255.0f : 0.0f;
+        const int y = 2 * oy - 1 + r, sy = y - src.top;
+        const bool in_canvas = y >= 0 && y < src.in_h, in_img = in_canvas && sy >= 0 && sy < src.new_h;
+        unsigned d0 = 0x72727272u, d1 = 0x72727272u, d2 = 0x72727272u;
+        if (in_img) {
+            const int mis = (int)((((uintptr_t)f & 15) + (long)sy * src.pitch) & 15);
+            const int o = mis + 3 * (4 * g - src.left);    // raw-row offset of this group's first byte
+            const unsigned char *rr = rows + r * rowb;
+            if (4 * g >= src.left && 4 * g + 3 < src.left + src.new_w) {
+                const unsigned *rp = (const unsigned *)(rr + (o & ~3));
+                const unsigned q0 = rp[0], q1 = rp[1], q2 = rp[2], q3 = rp[3];
+                const unsigned sh = (unsigned)(o & 3);
+                d0 = __builtin_amdgcn_alignbyte(q1, q0, sh);
+                d1 = __builtin_amdgcn_alignbyte(q2, q1, sh);
+                d2 = __builtin_amdgcn_alignbyte(q3, q2, sh);
+            } else {                                       // group straddles an edge of the image: byte by byte
+                unsigned dd[3] = {0u, 0u, 0u};
+#pragma unroll
+                for (int j = 0; j < 12; ++j) {
+                    const int x = 4 * g + j / 3;
+                    const unsigned v = x >= src.left && x < src.left + src.new_w ? rr[o + j] : 114u;
+                    dd[j >> 2] |= v << (8 * (j & 3));
+                }
+                d0 = dd[0]; d1 = dd[1]; d2 = dd[2];
+            }
+        }
+        const float k = in_canvas ? 1.0f / 255.0f : 0.0f;
         auto cv = [&](unsigned byte) -> f16 { return (f16)((float)byte * k); };
         half4 *dst = pix + r * pw + 1 + 4 * g;
         dst[0] = half4{cv((d0 >> 16) & 255u), cv((d0 >> 8) & 255u), cv(d0 & 255u), (f16)0.f};
@@ -1640,7 +1667,9 @@ __global__ __launch_bounds__(256) void stem_fused(StemSrc src, const f16 *__rest
         dst[3] = half4{cv(d2 >> 24), cv((d2 >> 16) & 255u), cv((d2 >> 8) & 255u), (f16)0.f};
     }
     if (threadIdx.x < 6) pix[(threadIdx.x >> 1) * pw + (threadIdx.x & 1) * (src.in_w + 1)] = half4{(f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f};
+    STAMP(3);
     __syncthreads();
+    STAMP(4);
 
     auto pair = [&](int r, int x0) -> half8 {              // pixels (x0, x0 + 1) of canvas row 2oy - 1 + r as {R,G,B,0,R,G,B,0}
         if (r < 0) return half8{(f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f};
@@ -1670,6 +1699,7 @@ __global__ __launch_bounds__(256) void stem_fused(StemSrc src, const f16 *__rest
             }
         }
     }
+    STAMP(5);
 }
 
 int launch_stem_fused(const FramePtrs &frames, int frame0, int pitch, const LetterboxGeom &g, int in_h, int in_w, const f16 *lut,
@@ -1681,7 +1711,7 @@ int launch_stem_fused(const FramePtrs &frames, int frame0, int pitch, const Lett
     RT_CHECK(frame0 >= 0 && frame0 + B <= 64, RTMODT_E_INVALID, "launch_stem_fused: frames %d..%d", frame0, frame0 + B);
     RT_CHECK((long)g.src_h * pitch < (1L << 31), RTMODT_E_INVALID, "launch_stem_fused: frame too large");
     StemSrc src{frames, pitch, g.top, g.left, g.new_h, g.new_w, in_h, in_w, frame0, (g.src_h - 1) * pitch + 3 * g.src_w};
-    const int rowb = (int)align_up((size_t)3 * in_w, 16);
+    const int rowb = (int)align_up((size_t)3 * in_w + 32, 1024);     // raw source row in LDS: whole 1 KiB DMA pieces, misalignment + read-ahead slack
     const int nt = cout / 16;
     const size_t smem = (size_t)3 * rowb + 512 + (size_t)3 * (in_w + 2) * 8 + (size_t)4 * 16 * (32 * nt + 8);
     dim3 grid(B * Ho);

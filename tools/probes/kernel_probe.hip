@@ -125,7 +125,124 @@ static int run_conv1x1(int tile, int cin, int cout, int HW, int B) {
     return 0;
 }
 
+static int run_stem(int B) {
+    const int H = 640, W = 640, Ho = 320, Wo = 320, cout = 32;
+    uint8_t *frames; f16 *out, *w; float *bias;
+    CK(hipMalloc(&frames, (size_t)B * H * W * 3));
+    std::vector<uint8_t> hf((size_t)B * H * W * 3);
+    for (auto &v : hf) v = (uint8_t)(rand() & 255);
+    CK(hipMemcpy(frames, hf.data(), hf.size(), hipMemcpyHostToDevice));
+    const size_t per = (size_t)(Ho + 2) * (Wo + 2);
+    CK(hipMalloc(&out, per * B * cout * 2)); CK(hipMemset(out, 0, per * B * cout * 2));
+    std::vector<f16> hw((size_t)cout * 64);
+    for (auto &v : hw) v = (f16)(((rand() % 200) - 100) * 1e-2f);
+    CK(hipMalloc(&w, hw.size() * 2)); CK(hipMemcpy(w, hw.data(), hw.size() * 2, hipMemcpyHostToDevice));
+    CK(hipMalloc(&bias, 4096)); CK(hipMemset(bias, 0, 4096));
+    FramePtrs fp{};
+    for (int b = 0; b < B; ++b) fp.p[b] = frames + (size_t)b * H * W * 3;
+    LetterboxGeom g{H, W, W, H, 0, 0, 0};
+    TensorView o; o.base = out; o.H = Ho; o.W = Wo; o.C = cout; o.pad = 1; o.coff = 0; o.c = cout;
+    const int wgs = B * Ho;
+    unsigned long long *d_st;
+    CK(hipMalloc(&d_st, (size_t)wgs * 16 * 8)); CK(hipMemset(d_st, 0, (size_t)wgs * 16 * 8));
+    CK(hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), &d_st, sizeof(d_st)));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int i = 0; i < 3; ++i) if (launch_stem_fused(fp, 0, W * 3, g, H, W, nullptr, o, w, bias, B, cout, nullptr) != 0) return 1;
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0, nullptr));
+    for (int i = 0; i < 5; ++i) launch_stem_fused(fp, 0, W * 3, g, H, W, nullptr, o, w, bias, B, cout, nullptr);
+    CK(hipEventRecord(e1, nullptr)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    printf("stem_fused %d frames: %.1f us per launch (stamped build), %d workgroups\n", B, ms * 1e3 / 5, wgs);
+    std::vector<unsigned long long> st((size_t)wgs * 16);
+    CK(hipMemcpy(st.data(), d_st, st.size() * 8, hipMemcpyDeviceToHost));
+    const char *nm[] = {"rows: loads + shift + LDS write", "barrier", "bytes -> fp16 pixels", "barrier", "MFMA + SiLU + transpose + store"};
+    for (int k = 1; k < 6; ++k) {
+        std::vector<double> d;
+        for (int g2 = 0; g2 < wgs; ++g2) { const unsigned long long *s = &st[(size_t)g2 * 16]; if (s[k] && s[k - 1]) d.push_back((double)(s[k] - s[k - 1])); }
+        std::sort(d.begin(), d.end());
+        printf("  %-40s median %8.0f clk\n", nm[k - 1], d[d.size() / 2]);
+    }
+    {   std::vector<double> d; unsigned long long t0 = ~0ull, t1 = 0;
+        for (int g2 = 0; g2 < wgs; ++g2) { const unsigned long long *s = &st[(size_t)g2 * 16]; d.push_back((double)(s[5] - s[0])); t0 = std::min(t0, s[0]); t1 = std::max(t1, s[5]); }
+        std::sort(d.begin(), d.end());
+        printf("  workgroup life median %.0f clk; launch span %.0f clk (s_memtime ticks at 100 MHz: x clock ratio)\n", d[d.size() / 2], (double)(t1 - t0));
+    }
+    return 0;
+}
+
+// a 3x3 conv (optionally with the fused 1x1 tail) on the 4-wave tile kernel conv_mfma_body: phase stamps 0..6
+static int run_conv3(int tile, int cin, int cout, int stride, int HWin, int B, int tail_cout) {
+    const int HWo = (HWin - 1) / stride + 1;
+    const size_t per_in = (size_t)(HWin + 2) * (HWin + 2), per_out = (size_t)(HWo + 2) * (HWo + 2);
+    f16 *in, *out, *w, *wt; float *bias;
+    CK(hipMalloc(&in, per_in * B * cin * 2)); CK(hipMalloc(&out, per_out * B * std::max(cout, tail_cout) * 2));
+    CK(hipMemset(out, 0, per_out * B * std::max(cout, tail_cout) * 2));
+    std::vector<f16> h(per_in * B * cin);
+    for (auto &v : h) v = (f16)(((rand() % 2000) - 1000) * 1e-3f);
+    CK(hipMemcpy(in, h.data(), h.size() * 2, hipMemcpyHostToDevice));
+    const int kp = 9 * cin;
+    std::vector<f16> hw((size_t)128 * kp);
+    for (auto &v : hw) v = (f16)(((rand() % 200) - 100) * 1e-3f);
+    CK(hipMalloc(&w, hw.size() * 2)); CK(hipMemcpy(w, hw.data(), hw.size() * 2, hipMemcpyHostToDevice));
+    CK(hipMalloc(&wt, (size_t)128 * 128 * 2)); CK(hipMemcpy(wt, hw.data(), (size_t)128 * 128 * 2, hipMemcpyHostToDevice));
+    CK(hipMalloc(&bias, 4096)); CK(hipMemset(bias, 0, 4096));
+    ConvLaunch c;
+    auto view = [&](f16 *base, int HW, int Ct) { TensorView v; v.base = base; v.H = v.W = HW; v.C = Ct; v.pad = 1; v.coff = 0; v.c = Ct; return v; };
+    c.in = view(in, HWin, cin); c.wt = w; c.bias = bias; c.B = B; c.cin = cin; c.cout = cout; c.ks = 3; c.stride = stride; c.act = 1; c.kp = kp; c.tile = tile;
+    if (tail_cout) { c.out = view(out, HWo, cout); c.tail_out = view(out, HWo, tail_cout); c.tail_wt = wt; c.tail_bias = bias; c.tail_cout = tail_cout; c.tail_kp = cout; }
+    else c.out = view(out, HWo, cout);
+    const int wgs = 65536;
+    unsigned long long *d_st;
+    CK(hipMalloc(&d_st, (size_t)wgs * 16 * 8)); CK(hipMemset(d_st, 0, (size_t)wgs * 16 * 8));
+    CK(hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), &d_st, sizeof(d_st)));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int i = 0; i < 3; ++i) if (launch_conv(c, nullptr) != 0) return 1;
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0, nullptr));
+    for (int i = 0; i < 5; ++i) launch_conv(c, nullptr);
+    CK(hipEventRecord(e1, nullptr)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    printf("conv 3x3/s%d %d -> %d (tail %d), %dx%d x %d, tile %s: %.1f us per launch (stamped build)\n", stride, cin, cout, tail_cout, HWin, HWin, B, tile_name(tile), ms * 1e3 / 5);
+    std::vector<unsigned long long> st((size_t)wgs * 16);
+    CK(hipMemcpy(st.data(), d_st, st.size() * 8, hipMemcpyDeviceToHost));
+    const char *nm[] = {"prologue DMA issue", "wait step 0 (+barrier)", "step 0 -> barrier of step 1", "step 1 -> barrier of step 2", "rest of the k-loop", "epilogue (tail GEMM + stores)"};
+    int live = 0;
+    for (int k = 1; k < 7; ++k) {
+        std::vector<double> d;
+        for (int g = 0; g < wgs; ++g) { const unsigned long long *s2 = &st[(size_t)g * 16]; if (s2[k] && s2[k - 1]) d.push_back((double)(s2[k] - s2[k - 1])); }
+        if (d.empty()) continue;
+        live = (int)d.size();
+        std::sort(d.begin(), d.end());
+        printf("  %-40s median %8.0f clk\n", nm[k - 1], d[d.size() / 2]);
+    }
+    {   const int seq[] = {5, 7, 8, 9, 6};
+        const char *en[] = {"  epilogue: barrier", "  epilogue: bias + SiLU -> LDS", "  epilogue: barrier", "  epilogue: LDS -> 16-byte stores"};
+        for (int k = 1; k < 5; ++k) {
+            std::vector<double> d;
+            for (int g = 0; g < wgs; ++g) { const unsigned long long *s2 = &st[(size_t)g * 16]; if (s2[seq[k]] && s2[seq[k - 1]]) d.push_back((double)(s2[seq[k]] - s2[seq[k - 1]])); }
+            if (d.empty()) continue;
+            std::sort(d.begin(), d.end());
+            printf("  %-40s median %8.0f clk\n", en[k - 1], d[d.size() / 2]);
+        }
+    }
+    {   std::vector<double> d;
+        for (int g = 0; g < wgs; ++g) { const unsigned long long *s2 = &st[(size_t)g * 16]; if (s2[6] && s2[0]) d.push_back((double)(s2[6] - s2[0])); }
+        std::sort(d.begin(), d.end());
+        if (!d.empty()) printf("  workgroup life median %.0f clk, %d workgroups stamped\n", d[d.size() / 2], live);
+    }
+    hipFree(in); hipFree(out); hipFree(w); hipFree(wt); hipFree(bias); hipFree(d_st);
+    return 0;
+}
+
 int main(int argc, char **argv) {
+    if (argc > 1 && !strcmp(argv[1], "l1")) {
+        if (run_conv3(TILE_TAIL_128x64, 32, 64, 2, 320, 32, 64)) return 1;       // layer 1 + 2.cv1 at 32 frames
+        if (run_conv3(TILE_128x64, 32, 64, 2, 320, 32, 0)) return 1;             // layer 1 alone
+        if (run_conv3(TILE_64x64, 32, 64, 2, 320, 32, 0)) return 1;
+        return 0;
+    }
+    if (argc > 1 && !strcmp(argv[1], "stem")) return run_stem(argc > 2 ? atoi(argv[2]) : 32);
     if (argc > 1 && !strcmp(argv[1], "ws")) {
         if (run_conv1x1(TILE_WS_128x128, 256, 128, 80, 32)) return 1;          // 4.cv2 at 32 frames
         if (run_conv1x1(TILE_128x64, 256, 128, 80, 32)) return 1;
