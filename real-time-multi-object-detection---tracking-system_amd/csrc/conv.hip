@@ -744,11 +744,14 @@ __device__ __forceinline__ void conv3x3_rows_body(const ConvArgs &p, const int b
         if (c0 >= p.cin) { c0 = 0; ++kh; }
     };
 
+    STAMP(0);
     issue(0);
+    STAMP(1);
     for (int st = 0; st < ns; ++st) {
         wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();                   // stage st landed; everyone finished stage st-1
         asm volatile("" ::: "memory");
+        if (st < 3) STAMP(2 + st);
         if (st + 1 < ns) issue((st + 1) & 1);
         const unsigned char *sA = lds + (st & 1) * STAGE + wm * TM * TILE_BYTES;
         const unsigned char *sB = lds + (st & 1) * STAGE + NAS * 1024 + wn * TN * TILE_BYTES;
@@ -769,6 +772,7 @@ __device__ __forceinline__ void conv3x3_rows_body(const ConvArgs &p, const int b
             }
     }
 
+    STAMP(5);
     // ---- epilogue: padded position -> (b, y, x); border rows/columns are junk ----
     const int HW = p.in_Hp * p.in_Wp;
     if (p.epi16 > 1) {                                     // measured: the extra LDS round trip costs this MFMA-heavier kernel more than its stores do
@@ -783,6 +787,7 @@ __device__ __forceinline__ void conv3x3_rows_body(const ConvArgs &p, const int b
             opix2 = upsampled_offset(p, b, oy, ox);
             return true;
         });
+        STAMP(6);
         return;
     }
 #pragma unroll
@@ -801,6 +806,7 @@ __device__ __forceinline__ void conv3x3_rows_body(const ConvArgs &p, const int b
             if (n < p.cout) store_tile(p, acc[t][u], bv[u], opix, rpix, n, opix2);
         }
     }
+    STAMP(6);
 }
 
 // ---------------------------------------------------------------------------------------

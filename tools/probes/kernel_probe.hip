@@ -207,6 +207,7 @@ static int run_conv3(int tile, int cin, int cout, int stride, int HWin, int B, i
     std::vector<unsigned long long> st((size_t)wgs * 16);
     CK(hipMemcpy(st.data(), d_st, st.size() * 8, hipMemcpyDeviceToHost));
     const char *nm[] = {"prologue DMA issue", "wait step 0 (+barrier)", "step 0 -> barrier of step 1", "step 1 -> barrier of step 2", "rest of the k-loop", "epilogue (tail GEMM + stores)"};
+    printf("  (k-steps: %d of 32, or %d super-steps of the tap-reuse kernel at 32 deep / %d at 64 deep)\n", kp / 32, 3 * (cin / 32), 3 * (cin / 64));
     int live = 0;
     for (int k = 1; k < 7; ++k) {
         std::vector<double> d;
@@ -236,6 +237,14 @@ static int run_conv3(int tile, int cin, int cout, int stride, int HWin, int B, i
 }
 
 int main(int argc, char **argv) {
+    if (argc > 1 && !strcmp(argv[1], "rows")) {                                  // 3x3 stride-1 convs on the tap-reuse kernel (stamps 0..6)
+        const int t6[] = {TILE_ROWS_256x64_W8, TILE_ROWS_128x64_W8, TILE_ROWS_K64_256x64_W8};
+        for (int t : t6) if (run_conv3(t, 128, 128, 1, 40, 32, 0)) return 1;      // 6.m / 12.m / 18.m
+        for (int t : t6) if (run_conv3(t, 64, 64, 1, 80, 32, 0)) return 1;        // 4.m / 15.m
+        for (int t : t6) if (run_conv3(t, 128, 64, 1, 80, 32, 0)) return 1;       // Detect cv2.0 at P3
+        for (int t : t6) if (run_conv3(t, 256, 128, 1, 40, 32, 0)) return 1;      // Detect cv3.0 at P4
+        return 0;
+    }
     if (argc > 1 && !strcmp(argv[1], "l1")) {
         if (run_conv3(TILE_TAIL_128x64, 32, 64, 2, 320, 32, 64)) return 1;       // layer 1 + 2.cv1 at 32 frames
         if (run_conv3(TILE_128x64, 32, 64, 2, 320, 32, 0)) return 1;             // layer 1 alone
