@@ -239,7 +239,7 @@ __device__ __forceinline__ void epilogue_lds(const ConvArgs &p, const int n0, co
     for (int t = 0; t < TM; ++t) {
         const int pm = (wm * TM + t) * 16 + r;
         long opix = 0, rpix = 0, opix2 = 0;
-        const bool live = pix(pm, opix, rpix, opix2);
+        const bool live = p.res ? pix(pm, opix, rpix, opix2) : false;      // (only the residual needs the pixel's position here)
 #pragma unroll
         for (int u = 0; u < TN; ++u) {
             const int nl = (wn * TN + u) * 16 + q * 4;
