@@ -1055,6 +1055,177 @@ __global__ __launch_bounds__(512) void conv1x1_ws(ConvArgs p, int groups) {
     STAMP(9);
 }
 
+// ---------------------------------------------------------------------------------------
+// conv_mfma64_pt: PERSISTENT-TILE variant of conv_mfma64_w8 (8 waves, 64-deep k-steps, BM = 128).  A workgroup owns one
+// cout slice and walks over pixel tiles g, g + G, ...; the (tile, k-step) pairs form ONE stream of steps through the
+// stage ring, so the first operands of the next tile are already in flight while this tile's epilogue runs -- in the plain
+// tile kernels every workgroup starts with an empty ring (phase stamps: ~2 600 clk before the first MFMA of a tile, 15-35 %
+// of a workgroup's life on the short-K layers).  The epilogue stores straight from the accumulators (the lane-pair
+// exchange of conv1x1_ws: 16-byte stores, no LDS round trip), so it does not need the stage buffers the prefetch is using.
+// Two stages = 64 KiB at BN = 128: two workgroups per CU, as in the plain kernel.  Runs full tiles only (M % 128 == 0,
+// cout % BN == 0), any kernel size / stride, no residual / second destination / half-resolution source.
+// Same MFMA order per output as conv_mfma64 (k ascending), same swizzled piece layout.
+// ---------------------------------------------------------------------------------------
+template <int BN, int NSTAGE>
+__global__ __launch_bounds__(512) void conv_mfma64_pt(ConvArgs p, int groups) {
+    constexpr int BM = 128, NW = 8, WM = 4, WN = 2;
+    constexpr int NA = BM / 8, NB = BN / 8, LA = NA / NW, LBp = NB / NW, L = LA + LBp;
+    constexpr int DEPTH = NSTAGE - 1;
+    constexpr int STAGE = (NA + NB) * 1024;
+    constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
+    static_assert(TN % 2 == 0, "the epilogue pairs neighbouring cout tiles");
+    static_assert(NB % NW == 0, "weight pieces must split evenly over the waves");
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[NSTAGE * STAGE];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r = lane & 15, q = lane >> 4;
+    const int n0 = blockIdx.y * BN, g = blockIdx.x;
+    const int nk = p.kp / 64;
+    const int n_mt = p.M / BM;
+    const int n_my = (n_mt - g + groups - 1) / groups;     // pixel tiles g, g + groups, ...
+    const int S = n_my * nk;                                // steps of this workgroup
+    const int ld_row8 = lane >> 3, ld_slot = lane & 7;
+    const int rd_base = (r >> 3) * 1024 + (r & 7) * 128;
+    const int rd_off0 = rd_base + (((0 + q) ^ ((r >> 1) & 7)) << 4);
+    const int rd_off1 = rd_base + (((4 + q) ^ ((r >> 1) & 7)) << 4);
+
+    int a_off[LA], a_lo[LA], b_off[LBp];
+#pragma unroll
+    for (int i = 0; i < LBp; ++i) {
+        const int row = (wave + NW * i) * 8 + ld_row8;
+        b_off[i] = (n0 + row) * p.kp + ((ld_slot ^ ((row >> 1) & 7)) << 3);
+    }
+    int is_tile = 0, is_kt = 0, is_stage = 0, kh = 0, kw = 0, c0 = 0;      // the next step to issue
+    auto issue = [&]() {
+        if (is_kt == 0) {
+            const int m0 = (g + is_tile * groups) * BM;
+#pragma unroll
+            for (int i = 0; i < LA; ++i) {
+                const int row = (wave + NW * i) * 8 + ld_row8;
+                a_off[i] = input_offset(p, m0 + row) + ((ld_slot ^ ((row >> 1) & 7)) << 3);
+                a_lo[i] = p.in2 ? input_offset_lo(p, m0 + row) + ((ld_slot ^ ((row >> 1) & 7)) << 3) : 0;
+            }
+            kh = kw = c0 = 0;
+        }
+        unsigned char *sbase = lds + is_stage * STAGE;
+        const int tap_off = (kh * p.in_Wp + kw) * p.in_cs + c0;
+        if (p.in2 && c0 < p.split) {                       // the upsampled half of a neck concat, read where it was produced
+#pragma unroll
+            for (int i = 0; i < LA; ++i) glds16(p.in2 + (a_lo[i] + c0), sbase + (wave + NW * i) * 1024);
+        } else {
+#pragma unroll
+            for (int i = 0; i < LA; ++i) glds16(p.in + (a_off[i] + tap_off), sbase + (wave + NW * i) * 1024);
+        }
+#pragma unroll
+        for (int i = 0; i < LBp; ++i) glds16(p.wt + (b_off[i] + is_kt * 64), sbase + (NA + wave + NW * i) * 1024);
+        c0 += 64;
+        if (c0 >= p.cin) { c0 = 0; if (++kw == p.ks) { kw = 0; ++kh; } }
+        if (++is_kt == nk) { is_kt = 0; ++is_tile; }
+        is_stage = is_stage + 1 == NSTAGE ? 0 : is_stage + 1;
+    };
+    const int wm = wave / WN, wn = wave % WN;
+    const int qe = q & ~1, odd = q & 1;
+    floatx4 bv[TN];
+#pragma unroll
+    for (int u = 0; u < TN; ++u) bv[u] = *(const floatx4 *)(p.bias + n0 + (wn * TN + u) * 16 + q * 4);
+    floatx4 acc[TM][TN];
+#pragma unroll
+    for (int t = 0; t < TM; ++t)
+#pragma unroll
+        for (int u = 0; u < TN; ++u) acc[t][u] = floatx4{0.f, 0.f, 0.f, 0.f};
+    STAMP(0);
+#pragma unroll
+    for (int i = 0; i < DEPTH; ++i)
+        if (i < S) issue();
+    STAMP(1);
+    int kt = 0, tile = 0, rstage = 0;
+    // vmcnt counts the epilogue's global stores together with the LDS-DMAs, in issue order (see conv1x1_ws): for the DEPTH steps
+    // after a tile's epilogue its stores are younger than the stage being waited for and may stay outstanding
+    constexpr int NST = TM * TN / 2;
+    int store_credit = 0;
+    for (int s = 0; s < S; ++s) {
+        const int ahead = min(DEPTH - 1, S - 1 - s);
+        if (store_credit > 0) { wait_steps_plus<L, DEPTH - 1, NST>(ahead); --store_credit; }
+        else wait_steps<L, DEPTH - 1>(ahead);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (s < 4) STAMP(2 + s);
+        // residual (Bottleneck shortcut): this tile's values are requested at the start of its LAST k-step, before the next
+        // DMA pieces, so they are OLDER than everything the epilogue leaves in flight (vmcnt retires in issue order)
+        half4 rv[TM][TN];
+        if (p.res && kt == nk - 1) {
+            const int m0r = (g + tile * groups) * BM;
+#pragma unroll
+            for (int t = 0; t < TM; ++t) {
+                long opix, rpix, opix2;
+                pixel_offsets(p, m0r + (wm * TM + t) * 16 + r, opix, rpix, opix2);
+#pragma unroll
+                for (int u = 0; u < TN; ++u) rv[t][u] = *(const half4 *)(p.res + rpix + n0 + (wn * TN + u) * 16 + q * 4);
+            }
+        }
+        const bool issued = s + DEPTH < S;
+        if (issued) issue();                                // refills the stage read in step s - 1
+        const unsigned char *sbase = lds + rstage * STAGE;
+        rstage = rstage + 1 == NSTAGE ? 0 : rstage + 1;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int ro = kk ? rd_off1 : rd_off0;
+            half8 fa[TM], fb[TN];
+#pragma unroll
+            for (int t = 0; t < TM; ++t) fa[t] = *(const half8 *)(sbase + (wm * TM + t) * 2048 + ro);
+#pragma unroll
+            for (int u = 0; u < TN; ++u) fb[u] = *(const half8 *)(sbase + NA * 1024 + (wn * TN + u) * 2048 + ro);
+#pragma unroll
+            for (int t = 0; t < TM; ++t)
+#pragma unroll
+                for (int u = 0; u < TN; ++u) acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[u], fa[t], acc[t][u], 0, 0, 0);
+        }
+        if (++kt == nk) {                                   // the tile is complete: epilogue straight from the accumulators
+            kt = 0;
+            const int m0 = (g + tile * groups) * BM;
+            ++tile;
+            if (tile == 1) STAMP(6);
+            if (p.res) {                                    // the residual loads have landed; the DMA pieces issued after them may stay in flight
+                if (issued) wait_vmcnt<L>(); else wait_vmcnt<0>();
+            }
+#pragma unroll
+            for (int t = 0; t < TM; ++t) {
+                long opix, rpix, opix2;
+                pixel_offsets(p, m0 + (wm * TM + t) * 16 + r, opix, rpix, opix2);      // (every tile is full: always live)
+#pragma unroll
+                for (int u = 0; u < TN; u += 2) {
+                    floatx4 v0 = acc[t][u] + bv[u], v1 = acc[t][u + 1] + bv[u + 1];
+                    if (p.act) {
+                        v0[0] = silu_f(v0[0]); v0[1] = silu_f(v0[1]); v0[2] = silu_f(v0[2]); v0[3] = silu_f(v0[3]);
+                        v1[0] = silu_f(v1[0]); v1[1] = silu_f(v1[1]); v1[2] = silu_f(v1[2]); v1[3] = silu_f(v1[3]);
+                    }
+                    if (p.res) {
+                        const half4 r0 = rv[t][u], r1 = rv[t][u + 1];
+                        v0[0] += (float)r0[0]; v0[1] += (float)r0[1]; v0[2] += (float)r0[2]; v0[3] += (float)r0[3];
+                        v1[0] += (float)r1[0]; v1[1] += (float)r1[1]; v1[2] += (float)r1[2]; v1[3] += (float)r1[3];
+                    }
+                    const half4 h0 = {(f16)v0[0], (f16)v0[1], (f16)v0[2], (f16)v0[3]}, h1 = {(f16)v1[0], (f16)v1[1], (f16)v1[2], (f16)v1[3]};
+                    const half4 give = odd ? h0 : h1, keep = odd ? h1 : h0;
+                    u32x2 gw = __builtin_bit_cast(u32x2, give);
+                    gw[0] = (unsigned)__shfl_xor((int)gw[0], 16);
+                    gw[1] = (unsigned)__shfl_xor((int)gw[1], 16);
+                    const half4 got = __builtin_bit_cast(half4, gw);
+                    const half4 lo = odd ? got : keep, hi = odd ? keep : got;
+                    const half8 o = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    const int n = n0 + (wn * TN + u + odd) * 16 + qe * 4;
+                    store16(p.out, opix + n, o, p.wthru);
+                    acc[t][u] = floatx4{0.f, 0.f, 0.f, 0.f};
+                    acc[t][u + 1] = floatx4{0.f, 0.f, 0.f, 0.f};
+                }
+            }
+            store_credit = DEPTH;
+            if (tile == 1) STAMP(7);
+        }
+    }
+    STAMP(9);
+}
+
 // ---- kernel entry points: one problem per launch, or a GROUP of independent problems that
 // share a tile configuration.  Grouping turns the Detect head's 15 small launches into 3.
 constexpr int MAX_GROUP = 6;
@@ -1132,21 +1303,22 @@ const char *tile_name(int tile) {
                                             "tail:128x64", "tail:64x64", "tail:k64:128x128", "tail:k64:64x128",
                                             "k64:128x128s2/8w", "k64:128x128s3/8w", "k64:256x128s2/8w", "k64:128x64s3/8w", "k64:256x64s2/8w",
                                             "rows:128x64/8w", "rows:256x64/8w", "rows64:128x128/8w", "rows64:256x64/8w",
-                                            "ws:128x128", "ws:128x64"};
+                                            "ws:128x128", "ws:128x64", "pt:128x128s2", "pt:128x128s3", "pt:128x64s3", "pt:128x64s2"};
     return tile >= 0 && tile < TILE_COUNT ? names[tile] : "?";
 }
 
 bool tile_needs_cin64(int tile) {
     return (tile >= TILE_K64_128x128_S2 && tile <= TILE_K64_128x128_S2W) || (tile >= TILE_ROWS_K64_128x64 && tile <= TILE_ROWS_K64_256x64) ||
            tile == TILE_TAIL_K64_128x128 || tile == TILE_TAIL_K64_64x128 || (tile >= TILE_K64_128x128_S2_W8 && tile <= TILE_K64_256x64_S2_W8) ||
-           tile == TILE_ROWS_K64_128x128_W8 || tile == TILE_ROWS_K64_256x64_W8 || tile_is_ws(tile);
+           tile == TILE_ROWS_K64_128x128_W8 || tile == TILE_ROWS_K64_256x64_W8 || tile_is_ws(tile) || tile_is_pt(tile);
 }
 bool tile_is_ws(int tile) { return tile == TILE_WS_128x128 || tile == TILE_WS_128x64; }
+bool tile_is_pt(int tile) { return tile >= TILE_PT_128x128_S2 && tile <= TILE_PT_128x64_S2; }
 // resident weight slice (kp/64 x BN/8 KiB) + the pixel ring (3 x 16 KiB) within 156 KiB of LDS
 bool tile_ws_fits(int tile, int kp) { return tile_is_ws(tile) && (kp / 64) * (tile_shape(tile).bn / 8) + 3 * 16 <= 156; }
 bool tile_is_tail(int tile) { return tile >= TILE_TAIL_128x64 && tile <= TILE_TAIL_K64_64x128; }
 // the 64-deep tile kernels (conv_mfma64_body) know how to read channels [0, lo_c) from a half-resolution tensor
-bool tile_reads_lo(int tile) { return (tile >= TILE_K64_128x128_S2 && tile <= TILE_K64_128x128_S2W) || (tile >= TILE_K64_128x128_S2_W8 && tile <= TILE_K64_256x64_S2_W8); }
+bool tile_reads_lo(int tile) { return (tile >= TILE_K64_128x128_S2 && tile <= TILE_K64_128x128_S2W) || (tile >= TILE_K64_128x128_S2_W8 && tile <= TILE_K64_256x64_S2_W8) || tile_is_pt(tile); }
 bool tile_is_rows(int tile) { return (tile >= TILE_ROWS_128x64 && tile <= TILE_ROWS_K64_256x64) || (tile >= TILE_ROWS_128x64_W8 && tile <= TILE_ROWS_K64_256x64_W8); }
 
 TileShape tile_shape(int tile) {
@@ -1189,6 +1361,8 @@ TileShape tile_shape(int tile) {
         case TILE_ROWS_K64_128x128_W8: return {128, 128};
         case TILE_WS_128x128: return {128, 128};
         case TILE_WS_128x64: return {128, 64};
+        case TILE_PT_128x128_S2: case TILE_PT_128x128_S3: return {128, 128};
+        case TILE_PT_128x64_S3: case TILE_PT_128x64_S2: return {128, 64};
     }
     return {0, 0};
 }
@@ -1285,6 +1459,18 @@ static int launch_ws(const LaunchPlan &l, hipStream_t s) {
         case 5: return launch_ws_n<BN, 5>(a, smem, s);
         default: return launch_ws_n<BN, 6>(a, smem, s);
     }
+}
+
+template <int BN, int NSTAGE>
+static int launch_pt(const LaunchPlan &l, hipStream_t s) {
+    const ConvArgs &a = l.a[0];
+    RT_CHECK(l.n == 1 && !l.general && a.cin % 64 == 0 && a.kp % 64 == 0 && a.M % 128 == 0 && a.cout % BN == 0 && !a.out2 && a.epi16,
+             RTMODT_E_INVALID, "launch_conv: the persistent tile runs one conv with cin %% 64 == 0, full tiles (M %% 128 == 0, cout %% BN == 0), no second destination");
+    const int slices = a.cout / BN, n_mt = a.M / 128;
+    constexpr int per_cu = (160 * 1024) / (NSTAGE * (128 / 8 + BN / 8) * 1024);          // workgroups of this kernel that fit one CU's LDS
+    const int groups = std::max(1, std::min(n_mt, per_cu * 256 / slices));
+    hipLaunchKernelGGL((conv_mfma64_pt<BN, NSTAGE>), dim3(groups, slices), dim3(512), 0, s, a, groups);
+    return RTMODT_OK;
 }
 
 template <int BM, int BN, int WM, int WN, bool K64>
@@ -1454,6 +1640,10 @@ int launch_conv_group(const ConvLaunch *c, int n, int tile, hipStream_t s) {
         case TILE_K64_256x64_S2_W8: RT_TRY((launch_k64_w8<256, 64, 8, 1, 2>(l, s))); break;
         case TILE_WS_128x128: RT_TRY(launch_ws<128>(l, s)); break;
         case TILE_WS_128x64: RT_TRY(launch_ws<64>(l, s)); break;
+        case TILE_PT_128x128_S2: RT_TRY((launch_pt<128, 2>(l, s))); break;
+        case TILE_PT_128x128_S3: RT_TRY((launch_pt<128, 3>(l, s))); break;
+        case TILE_PT_128x64_S3: RT_TRY((launch_pt<64, 3>(l, s))); break;
+        case TILE_PT_128x64_S2: RT_TRY((launch_pt<64, 2>(l, s))); break;
         case TILE_TAIL_128x64: hipLaunchKernelGGL((conv_mfma_tail<128, 64, 2, 2, 3, 4>), l.grid(128, 64), dim3(256), 0, s, a[0]); break;
         case TILE_TAIL_64x64: hipLaunchKernelGGL((conv_mfma_tail<64, 64, 2, 2, 3, 4>), l.grid(64, 64), dim3(256), 0, s, a[0]); break;
         case TILE_TAIL_K64_128x128: hipLaunchKernelGGL((conv_mfma64_tail<128, 128, 4, 1, 2, 8>), l.grid(128, 128), dim3(256), 0, s, a[0]); break;

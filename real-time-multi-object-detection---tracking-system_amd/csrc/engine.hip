@@ -412,7 +412,8 @@ static int make_conv(rtmodt_detector *d, WeightFile &wf, const std::vector<std::
     if (const char *e = getenv("RTMODT_TILE_K64")) {            // test hook: a 64-deep tile (incl. the 8-wave ones) wherever it is legal
         const int t = atoi(e);
         if (t >= 0 && t < TILE_COUNT && tile_needs_cin64(t) && !tile_is_rows(t) && !tile_is_tail(t) && c.cin % 64 == 0 && kp % 64 == 0 && !dst &&
-            (!tile_is_ws(t) || (c.ks == 1 && c.stride == 1 && tile_ws_fits(t, kp) && ((long)d->B * out.H * out.W) % 128 == 0 && cout_eff % tile_shape(t).bn == 0 && !res && out.coff % 8 == 0 && out.C % 8 == 0))) c.tile = t;
+            (!tile_is_ws(t) || (c.ks == 1 && c.stride == 1 && tile_ws_fits(t, kp) && ((long)d->B * out.H * out.W) % 128 == 0 && cout_eff % tile_shape(t).bn == 0 && !res && out.coff % 8 == 0 && out.C % 8 == 0)) &&
+            (!tile_is_pt(t) || (((long)d->B * out.H * out.W) % 128 == 0 && cout_eff % tile_shape(t).bn == 0 && out.coff % 8 == 0 && out.C % 8 == 0))) c.tile = t;
     }
     if (const char *e = getenv("RTMODT_TILE_3X3S1")) {          // test hook: force a tap-reuse tile wherever it is legal
         int t = atoi(e);
@@ -546,7 +547,7 @@ static int build_graph(rtmodt_detector *d, WeightFile &wf) {
     // a conv that also writes the nearest-2x copy cannot run as the tail of the Bottleneck before it
     auto fold_into_last = [&](const TensorView &up) {
         d->ops.back().conv.out2 = up;
-        if (tile_is_ws(d->ops.back().conv.tile)) d->ops.back().conv.tile = TILE_K64_128x128_S2;      // (test hook's forced tile: no second destination there)
+        if (tile_is_ws(d->ops.back().conv.tile) || tile_is_pt(d->ops.back().conv.tile)) d->ops.back().conv.tile = TILE_K64_128x128_S2;      // (test hook's forced tile: no second destination there)
         d->ops.back().skip = false;
         if (d->ops.size() >= 2) { Op &bn = d->ops[d->ops.size() - 2]; if (bn.kind == OP_BNECK) { bn.bneck.tail_wt = nullptr; bn.tail_on = false; } }
     };
@@ -886,6 +887,8 @@ static bool tile_legal(const ConvLaunch *c, int n, int t) {
     if (tile_is_rows(t) && !rows_ok) return false;
     if (c[0].in_lo.base && !tile_reads_lo(t)) return false;
     if (t >= TILE_K64_128x128_S2_W8 && t <= TILE_K64_256x64_S2_W8 && n != 1) return false;   // the 8-wave tiles have no group entry point
+    if (tile_is_pt(t) && (n != 1 || c[0].out2.base || ((long)c[0].B * c[0].out.H * c[0].out.W) % 128 != 0 ||
+                          c[0].cout % tile_shape(t).bn != 0 || c[0].out.coff % 8 != 0 || c[0].out.C % 8 != 0)) return false;
     if (tile_is_ws(t) && (n != 1 || c[0].ks != 1 || c[0].stride != 1 || c[0].in_lo.base || c[0].res.base || c[0].out2.base || !tile_ws_fits(t, c[0].kp) ||
                           ((long)c[0].B * c[0].out.H * c[0].out.W) % 128 != 0 || c[0].cout % tile_shape(t).bn != 0 || c[0].out.coff % 8 != 0 || c[0].out.C % 8 != 0)) return false;
     return true;
@@ -901,6 +904,7 @@ static int tile_lds_kib(int t) {
     if (tile_is_rows(t)) { const int rp = tile_needs_cin64(t) ? 8 : 16; return 2 * (ts.bm / rp + 1 + 3 * (ts.bn / rp)); }
     if (t >= TILE_WSK_64x64 && t <= TILE_WSK_64x32) return std::max(8 * (ts.bm / 16 + ts.bn / 16), 4 * (ts.bm / 16) * (ts.bn / 16));
     if (tile_is_ws(t)) return 150;                         // persistent, (nearly) the whole LDS
+    if (tile_is_pt(t)) return (t == TILE_PT_128x128_S2 || t == TILE_PT_128x64_S2 ? 2 : 3) * (ts.bm / 8 + ts.bn / 8);
     int stages = 3;
     switch (t) {
         case TILE_128x128_S4: stages = 4; break;

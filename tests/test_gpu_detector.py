@@ -1132,3 +1132,33 @@ def test_weight_stationary_1x1_tiles(pkg, wdir, monkeypatch, tile, size, batch):
             err = float(np.abs(taps[n] - gpu[n]).max())
             assert err <= tol, f"tile {tile} img {img} layer {n}: max err {err:.4g} > tol {tol:.4g}"
     det.close()
+
+
+@pytest.mark.parametrize("tile,size,batch,up_read", [(44, 320, 32, "0"), (45, 320, 32, "1"), (46, 320, 32, "1"), (47, 320, 32, "0"), (44, 640, 8, "1"), (45, 288, 3, "0")])
+def test_persistent_tile_kernel(pkg, wdir, monkeypatch, tile, size, batch, up_read):
+    """conv_mfma64_pt: a persistent workgroup walks over pixel tiles of one cout slice; the stage ring keeps prefetching
+    across tile boundaries and the epilogue stores straight from the accumulators.  Forced onto every conv where it is legal
+    (any kernel size / stride with cin % 64 == 0, full tiles, no second destination; the Bottleneck shortcuts and -- with
+    `up_read` -- the neck's half-resolution concat sources included); all layers of the first and the last image against the
+    oracle.  288 x 288 x 3: legal nowhere, every conv keeps its default."""
+    monkeypatch.setenv("RTMODT_TILE_K64", str(tile))
+    monkeypatch.setenv("RTMODT_BNECK", "0")
+    monkeypatch.setenv("RTMODT_TAIL", "0")
+    monkeypatch.setenv("RTMODT_TILE_3X3S1", "-1")            # (no tap-reuse tiles: the 3x3 convs take the forced tile too)
+    monkeypatch.setenv("RTMODT_UP_READ", up_read)
+    det, w = make_detector(pkg, wdir, "s", size, autotune=False, batch=batch)
+    used = [n for n, _, _ in det.profile(1) if "pt:" in n]
+    assert (len(used) >= 8) if size != 288 else (len(used) == 0), used
+    frames = list(pkg.synth.frames(batch, size, size, seed=17 + tile))
+    det.detect_batch(frames)
+    names = [c.name for c in pkg.weights.spec("s")]
+    for img in sorted({0, batch - 1}):
+        inp, _, _ = det.debug_fetch(img, want_heads=False, want_pred=False)
+        gpu = fetch_layers(pkg, det, names, img)
+        taps = {}
+        Y.forward(inp.astype(np.float32), w, "s", taps=taps, force=gpu)
+        for n in gpu:
+            tol = 2e-3 * np.abs(taps[n]).max() + 2e-3
+            err = float(np.abs(taps[n] - gpu[n]).max())
+            assert err <= tol, f"tile {tile} img {img} layer {n}: max err {err:.4g} > tol {tol:.4g}"
+    det.close()

@@ -108,7 +108,7 @@ static int run_conv1x1(int tile, int cin, int cout, int HW, int B) {
     CK(hipEventRecord(e1, nullptr)); CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
     printf("conv 1x1 %d -> %d, %dx%d x %d, tile %s: %.1f us per launch (stamped build)\n", cin, cout, HW, HW, B, tile_name(tile), ms * 1e3 / 5);
-    if (tile_is_ws(tile)) {
+    if (tile_is_ws(tile) || tile_is_pt(tile)) {
         std::vector<unsigned long long> st((size_t)wgs * 16);
         CK(hipMemcpy(st.data(), d_st, st.size() * 8, hipMemcpyDeviceToHost));
         const char *nm[] = {"issue weights + ring prologue", "wait for weights + stage 0 (+barrier)", "step 0", "step 1", "step 2", "step 3", "rest of tile 0 incl. epilogue", "", "remaining tiles"};
@@ -252,6 +252,13 @@ int main(int argc, char **argv) {
         return 0;
     }
     if (argc > 1 && !strcmp(argv[1], "stem")) return run_stem(argc > 2 ? atoi(argv[2]) : 32);
+    if (argc > 1 && !strcmp(argv[1], "pt")) {                                     // persistent tiles against the plain 8-wave tile kernel
+        const int shapes[][3] = {{256, 256, 40}, {512, 256, 40}, {384, 128, 80}, {768, 512, 20}};
+        for (auto &sh : shapes)
+            for (int t : {TILE_K64_128x128_S2_W8, TILE_PT_128x128_S2, TILE_PT_128x128_S3, TILE_PT_128x64_S3})
+                if (run_conv1x1(t, sh[0], sh[1], sh[2], 32)) return 1;
+        return 0;
+    }
     if (argc > 1 && !strcmp(argv[1], "ws")) {
         if (run_conv1x1(TILE_WS_128x128, 256, 128, 80, 32)) return 1;          // 4.cv2 at 32 frames
         if (run_conv1x1(TILE_128x64, 256, 128, 80, 32)) return 1;

@@ -3,7 +3,7 @@
 mkdir -p gpurun_out/v
 L="real-time-multi-object-detection---tracking-system_amd/lib"
 cp $L/librtmodt_hip.so $L/new.so.keep
-timeout -k 10 600 python -m pytest tests/test_gpu_detector.py -q -m gpu -x -k "forward_layers or benchmarked or tile or batch_equals" > gpurun_out/v/tests.txt 2>&1 || { tail -5 gpurun_out/v/tests.txt; exit 1; }
+timeout -k 10 600 python -m pytest tests/test_gpu_detector.py -q -m gpu -x -k "forward_layers or benchmarked or tile or batch_equals or persistent" > gpurun_out/v/tests.txt 2>&1 || { tail -5 gpurun_out/v/tests.txt; exit 1; }
 tail -1 gpurun_out/v/tests.txt
 Q="--no-cpu-baseline --no-latency --no-compare --no-host-leg --no-verify --long 0"
 for rep in 1 2 3; do
