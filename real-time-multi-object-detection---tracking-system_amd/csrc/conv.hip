@@ -1083,8 +1083,17 @@ __global__ __launch_bounds__(512) void conv_mfma64_pt(ConvArgs p, int groups) {
     const int n0 = blockIdx.y * BN, g = blockIdx.x;
     const int nk = p.kp / 64;
     const int n_mt = p.M / BM;
-    const int n_my = (n_mt - g + groups - 1) / groups;     // pixel tiles g, g + groups, ...
+    // Which pixel tiles: workgroups go round-robin over the 8 XCDs, and XCD x works on the x-th contiguous eighth of the tile
+    // list (as in xcd_tile: neighbouring tiles of a 3x3 conv share input rows, which should meet in ONE L2); inside that run
+    // the XCD's workgroups (rank j of Gx) take tiles j, j + Gx, ... -- at any time the XCD is busy with Gx consecutive tiles.
+    const int xcd = (g + blockIdx.y * groups) & 7;
+    const int g0 = (xcd - blockIdx.y * groups) & 7;        // the first workgroup of this slice on that XCD
+    const int j = (g - g0) >> 3, Gx = (groups - g0 + 7) >> 3;
+    const int q8 = n_mt >> 3, r8 = n_mt & 7;
+    const int run0 = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8, run_n = q8 + (xcd < r8 ? 1 : 0);
+    const int n_my = j < run_n ? (run_n - j + Gx - 1) / Gx : 0;
     const int S = n_my * nk;                                // steps of this workgroup
+    auto tile_m0 = [&](int ti) { return (run0 + j + ti * Gx) * BM; };
     const int ld_row8 = lane >> 3, ld_slot = lane & 7;
     const int rd_base = (r >> 3) * 1024 + (r & 7) * 128;
     const int rd_off0 = rd_base + (((0 + q) ^ ((r >> 1) & 7)) << 4);
@@ -1099,7 +1108,7 @@ __global__ __launch_bounds__(512) void conv_mfma64_pt(ConvArgs p, int groups) {
     int is_tile = 0, is_kt = 0, is_stage = 0, kh = 0, kw = 0, c0 = 0;      // the next step to issue
     auto issue = [&]() {
         if (is_kt == 0) {
-            const int m0 = (g + is_tile * groups) * BM;
+            const int m0 = tile_m0(is_tile);
 #pragma unroll
             for (int i = 0; i < LA; ++i) {
                 const int row = (wave + NW * i) * 8 + ld_row8;
@@ -1155,7 +1164,7 @@ __global__ __launch_bounds__(512) void conv_mfma64_pt(ConvArgs p, int groups) {
         // DMA pieces, so they are OLDER than everything the epilogue leaves in flight (vmcnt retires in issue order)
         half4 rv[TM][TN];
         if (p.res && kt == nk - 1) {
-            const int m0r = (g + tile * groups) * BM;
+            const int m0r = tile_m0(tile);
 #pragma unroll
             for (int t = 0; t < TM; ++t) {
                 long opix, rpix, opix2;
@@ -1183,7 +1192,7 @@ __global__ __launch_bounds__(512) void conv_mfma64_pt(ConvArgs p, int groups) {
         }
         if (++kt == nk) {                                   // the tile is complete: epilogue straight from the accumulators
             kt = 0;
-            const int m0 = (g + tile * groups) * BM;
+            const int m0 = tile_m0(tile);
             ++tile;
             if (tile == 1) STAMP(6);
             if (p.res) {                                    // the residual loads have landed; the DMA pieces issued after them may stay in flight
