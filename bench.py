@@ -57,6 +57,8 @@ def parse():
     ap.add_argument("--pageable", action="store_true", help="with --host-frames: ordinary pageable NumPy frames instead of the pinned ring")
     ap.add_argument("--host-mode", default="copy", choices=["copy", "mapped"],
                     help="host frames reach the device by DMA into a staging area (copy) or are read by the stem kernel straight from the mapped page-locked ring (mapped)")
+    ap.add_argument("--frames-kind", default="noise", choices=["noise", "structured"],
+                    help="synthetic frames: uniform-random bytes (default, the hardest case for the chip's power limit) or smooth blobs on a gradient")
     ap.add_argument("--no-host-leg", action="store_true", help="skip the extra PCIe-inclusive measurement")
     ap.add_argument("--no-verify", action="store_true", help="skip the untimed output self-check")
     ap.add_argument("--prewarm", type=float, default=1.0, help="seconds of untimed full-pipeline running before the timed region (besides --warmup steps)")
@@ -154,8 +156,9 @@ def main():
     per = size * size * 3
     ring = pkg._ffi.DeviceBuffer(S * R * per, dev)
     my_streams = pkg.streams.shard(S * world, world, rank)
+    gen = pkg.synth.frames if args.frames_kind == "noise" else pkg.synth.structured_frames
     for s, gid in enumerate(my_streams):
-        ring.upload(pkg.synth.frames(R, size, size, seed=1234 + gid), offset=s * R * per)
+        ring.upload(gen(R, size, size, seed=1234 + gid), offset=s * R * per)
 
     F = max(1, args.frames_per_stream)
 

@@ -65,7 +65,7 @@ def test_nms_planted_clusters(pkg):
     check_nms(pkg, pred, conf=0.6, iou=0.2)
 
 
-@pytest.mark.parametrize("n_anchors,frac", [(8400, 0.05), (8400, 0.6), (2100, 1.0), (33600, 0.3)])
+@pytest.mark.parametrize("n_anchors,frac", [(8400, 0.05), (8400, 0.6), (2100, 1.0), (33600, 0.3), (8400, 1.0), (33600, 1.0)])
 def test_nms_dense_random(pkg, n_anchors, frac):
     """Hundreds to ~10k candidates, heavy overlap, duplicated scores (stable order matters);
     the 33600-anchor case drives the > 8192-candidate global rank-sort path."""
