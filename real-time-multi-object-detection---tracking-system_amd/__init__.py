@@ -17,6 +17,8 @@ library being built):
 * ``profiling``          -- ``LatencyProfiler`` (reference: src/profiling/latency_profiler.py:35-143)
 * ``events``             -- ``ZoneEventEngine`` on device-resident tracks (reference: src/events/zone_engine.py:64-157)
 * ``pipeline``           -- the reference's per-frame loop (tools/run_pipeline.py:121-158) around the native classes
+* ``ingestion``          -- ``FrameReader`` / ``RTSPReader``: latest-frame reader thread with pluggable capture back-ends,
+                            decoding into a page-locked ring (reference: src/ingestion/rtsp_reader.py:27-158)
 """
 import importlib as _importlib
 
@@ -28,6 +30,8 @@ _LAZY = {
     "MultiObjectTracker": ".tracking.tracker",
     "Track": ".tracking.tracker",
     "ZoneEventEngine": ".events.zone_engine",
+    "FrameReader": ".ingestion.reader",
+    "RTSPReader": ".ingestion.reader",
 }
 
 
@@ -35,6 +39,6 @@ def __getattr__(name):
     if name in _LAZY:
         mod = _importlib.import_module(_LAZY[name], __name__)
         return getattr(mod, name)
-    if name in ("synth", "weights", "_ffi", "detection", "tracking", "yolo_spec", "streams", "profiling", "pipeline", "events"):
+    if name in ("synth", "weights", "_ffi", "detection", "tracking", "yolo_spec", "streams", "profiling", "pipeline", "events", "ingestion"):
         return _importlib.import_module("." + name, __name__)
     raise AttributeError(name)

@@ -456,6 +456,31 @@ def test_pipeline_loop_and_stage_profiler(pkg, wdir, handoff):
     det.close()
 
 
+def test_pipeline_fed_by_frame_reader_through_pinned_ring(pkg, wdir):
+    """the ingest reader (reference interface: src/ingestion/rtsp_reader.py) decodes straight into a
+    page-locked ring; the loop of rank 1 runs on it unchanged, and a frame handed out without a copy (`read(copy=False)`)
+    is uploaded from where the reader put it -- same detections as from an ordinary NumPy copy of it."""
+    det, _ = make_detector(pkg, wdir, "s", 320)
+    trk = pkg.MultiObjectTracker("bytetrack")
+    frames = pkg.synth.frames(6, 320, 320, seed=12)
+    ring = pkg.pipeline.PinnedFrameRing(3, 320, 320)
+    with pkg.ingestion.FrameReader("synthetic", backend="synthetic", resolution=(320, 320), frames=frames, fps=500.0, ring=ring) as reader:
+        import time
+        t0 = time.perf_counter()
+        while not reader.read()[0] and time.perf_counter() - t0 < 3.0:
+            time.sleep(0.002)
+        prof = pkg.profiling.LatencyProfiler(gpu_sync=True, warmup_frames=5, log_interval=20)
+        out = pkg.pipeline.run(reader, det, trk, prof, max_frames=30)
+        assert out["total_p50_ms"] > 0 and out["decode_p50_ms"] > 0
+        ok, f, fid = reader.read(copy=False)
+        assert ok and fid >= 1 and np.array_equal(f, frames[(fid - 1) % 6])
+        a = det.detect(f)                                    # page-locked slot: asynchronous DMA path
+        b = det.detect(frames[(fid - 1) % 6].copy())          # pageable copy
+        assert np.array_equal(a.xyxy, b.xyxy) and np.array_equal(a.class_id, b.class_id) and np.array_equal(a.confidence, b.confidence)
+    ring.close()
+    det.close()
+
+
 # ------------------------------------------------------------------ rect (LetterBox auto=True) mode
 @pytest.mark.parametrize("h,w,shape", [(1080, 1920, (384, 640)), (480, 640, (480, 640)), (720, 405, (640, 384)), (333, 500, (448, 640))])
 def test_rect_letterbox_mode(pkg, wdir, h, w, shape):
