@@ -59,9 +59,13 @@ def test_latest_frame_only_and_ids():
         ok, f2, id2 = r.read(copy=False)
         assert np.array_equal(f2, frames[(id2 - 1) % 5])
         assert any(f2.base is ring.mem or f2 is ring.frame(k) or np.shares_memory(f2, ring.mem) for k in range(3))   # the slot itself, not a copy
-        assert r.dropped >= 1                      # frames nobody read were overwritten, never queued
+        d0 = r.dropped
+        time.sleep(0.05)                           # nobody reads for 20 frame periods
+        assert wait_for(lambda: r.dropped >= d0 + 5)   # those frames were overwritten, never queued
+        ok, f3, id3 = r.read()
+        assert id3 >= id2 + 5 and np.array_equal(f3, frames[(id3 - 1) % 5])
     assert not r.is_alive
-    ok, f3, _ = r.read()
+    ok, f4, _ = r.read()
     assert ok                                     # the last frame stays readable after stop, like the reference's
 
 
