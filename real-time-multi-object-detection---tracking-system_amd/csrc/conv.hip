@@ -906,7 +906,7 @@ __device__ __forceinline__ void conv_mfma_wsk_body(const ConvArgs &p, const int 
 // ---------------------------------------------------------------------------------------
 // conv1x1_ws: WEIGHT-STATIONARY 1x1 convolution.  In the tile kernels above every workgroup streams its BN x K slice of
 // the weights again for every pixel tile -- for the C2f / SPPF 1x1 convs (N = 128..512, K = 256..768) that is HALF of all
-// bytes that cross the global -> LDS path, the path that bounds them.  Here a persistent 4-wave workgroup loads its BN x K
+// bytes that cross the global -> LDS path, the path that bounds them.  Here a persistent 8-wave workgroup loads its BN x K
 // weight slice into LDS ONCE (K/64 x BN/8 pieces, resident) and then walks over 128-pixel tiles mt = g, g + G, ..., whose
 // rows arrive through a ring of NSTAGE 16-KiB stages; the (tile, k-step) pairs form ONE stream of steps, so the ring keeps
 // prefetching across tile boundaries and a tile's epilogue (bias, SiLU, stores straight from the accumulators) runs

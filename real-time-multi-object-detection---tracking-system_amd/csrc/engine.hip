@@ -927,9 +927,10 @@ static int tune_conv(rtmodt_detector *d, hipEvent_t e0, hipEvent_t e1, const std
     static const bool tune_ws = getenv("RTMODT_TUNE_WS") != nullptr;
     for (int t = 0; t < TILE_COUNT; ++t) {
         if (!tile_legal(c, n, t)) continue;
-        // the weight-stationary 1x1 kernel halves the bytes through the global -> LDS path but runs ONE workgroup per CU with
-        // 32 KiB in flight: measured 20-40 % slower than the tile kernels on every 1x1 conv of YOLOv8s at 16 and 32 frames
-        // (profiles/r02/README.md), so the tuner skips it unless asked
+        // the weight-stationary 1x1 kernel halves the bytes through the global -> LDS path but runs ONE workgroup per CU: it ties
+        // with the best tile kernel on every 1x1 conv of YOLOv8s at 32 frames and changes nothing in the staged bench
+        // (profiles/r02/README.md); the persistent-tile kernel (TILE_PT_*) took over its cross-tile prefetch with two
+        // workgroups per CU, so the tuner skips this one unless asked
         if (tile_is_ws(t) && !tune_ws) continue;
         float ms;
         RT_TRY(time_launch(d, e0, e1, [&]() { return launch_conv_group(c, n, t, d->stream); }, ms));
