@@ -1086,10 +1086,13 @@ __global__ __launch_bounds__(512) void conv_mfma64_pt(ConvArgs p, int groups) {
     // Which pixel tiles: workgroups go round-robin over the 8 XCDs, and XCD x works on the x-th contiguous eighth of the tile
     // list (as in xcd_tile: neighbouring tiles of a 3x3 conv share input rows, which should meet in ONE L2); inside that run
     // the XCD's workgroups (rank j of Gx) take tiles j, j + Gx, ... -- at any time the XCD is busy with Gx consecutive tiles.
-    const int xcd = (g + blockIdx.y * groups) & 7;
-    const int g0 = (xcd - blockIdx.y * groups) & 7;        // the first workgroup of this slice on that XCD
-    const int j = (g - g0) >> 3, Gx = (groups - g0 + 7) >> 3;
-    const int q8 = n_mt >> 3, r8 = n_mt & 7;
+    // (fewer than 8 workgroups per slice: one run per workgroup, so that every run has an owner)
+    const bool few = groups < 8;
+    const int X = few ? groups : 8;
+    const int xcd = few ? g : (g + blockIdx.y * groups) & 7;
+    const int g0 = few ? g : (xcd - blockIdx.y * groups) & 7;        // the first workgroup of this slice on that XCD
+    const int j = (g - g0) >> 3, Gx = few ? 1 : (groups - g0 + 7) >> 3;
+    const int q8 = n_mt / X, r8 = n_mt - q8 * X;
     const int run0 = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8, run_n = q8 + (xcd < r8 ? 1 : 0);
     const int n_my = j < run_n ? (run_n - j + Gx - 1) / Gx : 0;
     const int S = n_my * nk;                                // steps of this workgroup

@@ -1159,7 +1159,8 @@ def test_weight_stationary_1x1_tiles(pkg, wdir, monkeypatch, tile, size, batch):
     det.close()
 
 
-@pytest.mark.parametrize("tile,size,batch,up_read", [(44, 320, 32, "0"), (45, 320, 32, "1"), (46, 320, 32, "1"), (47, 320, 32, "0"), (44, 640, 8, "1"), (45, 288, 3, "0")])
+@pytest.mark.parametrize("tile,size,batch,up_read", [(44, 320, 32, "0"), (45, 320, 32, "1"), (46, 320, 32, "1"), (47, 320, 32, "0"), (44, 640, 8, "1"), (45, 288, 3, "0"),
+                                                           (44, 64, 8, "1"), (47, 64, 24, "0")])      # 64 x 64: one to twelve pixel tiles per conv -- fewer workgroups than XCDs
 def test_persistent_tile_kernel(pkg, wdir, monkeypatch, tile, size, batch, up_read):
     """conv_mfma64_pt: a persistent workgroup walks over pixel tiles of one cout slice; the stage ring keeps prefetching
     across tile boundaries and the epilogue stores straight from the accumulators.  Forced onto every conv where it is legal
