@@ -172,9 +172,10 @@ static int run_stem(int B) {
 }
 
 // a 3x3 conv (optionally with the fused 1x1 tail) on the 4-wave tile kernel conv_mfma_body: phase stamps 0..6
-static int run_conv3(int tile, int cin, int cout, int stride, int HWin, int B, int tail_cout) {
-    const int HWo = (HWin - 1) / stride + 1;
-    const size_t per_in = (size_t)(HWin + 2) * (HWin + 2), per_out = (size_t)(HWo + 2) * (HWo + 2);
+static int run_conv3(int tile, int cin, int cout, int stride, int HWin, int B, int tail_cout, int Win = 0) {
+    if (Win == 0) Win = HWin;                                  // (non-square only for the surrogate experiments)
+    const int HWo = (HWin - 1) / stride + 1, Wo = (Win - 1) / stride + 1;
+    const size_t per_in = (size_t)(HWin + 2) * (Win + 2), per_out = (size_t)(HWo + 2) * (Wo + 2);
     f16 *in, *out, *w, *wt; float *bias;
     CK(hipMalloc(&in, per_in * B * cin * 2)); CK(hipMalloc(&out, per_out * B * std::max(cout, tail_cout) * 2));
     CK(hipMemset(out, 0, per_out * B * std::max(cout, tail_cout) * 2));
@@ -188,10 +189,10 @@ static int run_conv3(int tile, int cin, int cout, int stride, int HWin, int B, i
     CK(hipMalloc(&wt, (size_t)128 * 128 * 2)); CK(hipMemcpy(wt, hw.data(), (size_t)128 * 128 * 2, hipMemcpyHostToDevice));
     CK(hipMalloc(&bias, 4096)); CK(hipMemset(bias, 0, 4096));
     ConvLaunch c;
-    auto view = [&](f16 *base, int HW, int Ct) { TensorView v; v.base = base; v.H = v.W = HW; v.C = Ct; v.pad = 1; v.coff = 0; v.c = Ct; return v; };
-    c.in = view(in, HWin, cin); c.wt = w; c.bias = bias; c.B = B; c.cin = cin; c.cout = cout; c.ks = 3; c.stride = stride; c.act = 1; c.kp = kp; c.tile = tile;
-    if (tail_cout) { c.out = view(out, HWo, cout); c.tail_out = view(out, HWo, tail_cout); c.tail_wt = wt; c.tail_bias = bias; c.tail_cout = tail_cout; c.tail_kp = cout; }
-    else c.out = view(out, HWo, cout);
+    auto view = [&](f16 *base, int Hh, int Ww, int Ct) { TensorView v; v.base = base; v.H = Hh; v.W = Ww; v.C = Ct; v.pad = 1; v.coff = 0; v.c = Ct; return v; };
+    c.in = view(in, HWin, Win, cin); c.wt = w; c.bias = bias; c.B = B; c.cin = cin; c.cout = cout; c.ks = 3; c.stride = stride; c.act = 1; c.kp = kp; c.tile = tile;
+    if (tail_cout) { c.out = view(out, HWo, Wo, cout); c.tail_out = view(out, HWo, Wo, tail_cout); c.tail_wt = wt; c.tail_bias = bias; c.tail_cout = tail_cout; c.tail_kp = cout; }
+    else c.out = view(out, HWo, Wo, cout);
     const int wgs = 65536;
     unsigned long long *d_st;
     CK(hipMalloc(&d_st, (size_t)wgs * 16 * 8)); CK(hipMemset(d_st, 0, (size_t)wgs * 16 * 8));
@@ -203,7 +204,7 @@ static int run_conv3(int tile, int cin, int cout, int stride, int HWin, int B, i
     for (int i = 0; i < 5; ++i) launch_conv(c, nullptr);
     CK(hipEventRecord(e1, nullptr)); CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
-    printf("conv 3x3/s%d %d -> %d (tail %d), %dx%d x %d, tile %s: %.1f us per launch (stamped build)\n", stride, cin, cout, tail_cout, HWin, HWin, B, tile_name(tile), ms * 1e3 / 5);
+    printf("conv 3x3/s%d %d -> %d (tail %d), %dx%d x %d, tile %s: %.1f us per launch (stamped build)\n", stride, cin, cout, tail_cout, HWin, Win, B, tile_name(tile), ms * 1e3 / 5);
     std::vector<unsigned long long> st((size_t)wgs * 16);
     CK(hipMemcpy(st.data(), d_st, st.size() * 8, hipMemcpyDeviceToHost));
     const char *nm[] = {"prologue DMA issue", "wait step 0 (+barrier)", "step 0 -> barrier of step 1", "step 1 -> barrier of step 2", "rest of the k-loop", "epilogue (tail GEMM + stores)"};
@@ -243,6 +244,14 @@ int main(int argc, char **argv) {
         for (int t : t6) if (run_conv3(t, 64, 64, 1, 80, 32, 0)) return 1;        // 4.m / 15.m
         for (int t : t6) if (run_conv3(t, 128, 64, 1, 80, 32, 0)) return 1;       // Detect cv2.0 at P3
         for (int t : t6) if (run_conv3(t, 256, 128, 1, 40, 32, 0)) return 1;      // Detect cv3.0 at P4
+        return 0;
+    }
+    if (argc > 1 && !strcmp(argv[1], "l1lines")) {
+        // Is layer 1 held back by its 64-byte (half-line) requests?  A surrogate with the SAME bytes and FLOPs whose pixels are whole
+        // 128-byte lines: the 320 x 320 x 32 input viewed as 320 x 160 pixel pairs of 64 channels, 3x3 / stride 2 -> 160 x 80 x 64.
+        if (run_conv3(TILE_128x64, 32, 64, 2, 320, 32, 0)) return 1;                       // layer 1 as it is (no tail)
+        for (int t : {TILE_K64_128x64_S3, TILE_K64_128x64_S3_W8, TILE_K64_64x64_S3, TILE_PT_128x64_S2, TILE_PT_128x64_S3})
+            if (run_conv3(t, 64, 64, 2, 320, 32, 0, 160)) return 1;
         return 0;
     }
     if (argc > 1 && !strcmp(argv[1], "l1")) {
