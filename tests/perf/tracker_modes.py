@@ -1,10 +1,11 @@
 #!/usr/bin/env python3
-"""Device time per frame of the single-launch tracker in its two assignment modes and of the zone kernel, on the
+"""(Lives under tests/ because it times the CPU oracle next to the kernels; only tests, smoke() and the bench's CPU baseline may touch oracle/.)
+Device time per frame of the single-launch tracker in its two assignment modes and of the zone kernel, on the
 BASELINE config-3 / config-5 sequences (200 boxes at 640, 500 boxes at 1280), beside the CPU oracle (one thread).
 HIP-event-free: wall clock around synchronous C-ABI calls, so PCIe round trips of the host-array path are included;
 the device-resident path (update_from_detector) hides all of it behind the forward pass."""
 import json, os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import rtmodt_amd  # noqa
 from types import SimpleNamespace

@@ -48,6 +48,6 @@ $B --steps 300 --warmup 30 --host-frames --frames-per-stream 2 > $O/bench_host_f
 $B --steps 200 --warmup 30 --host-frames --pageable > $O/bench_host_frames_pageable.json 2> /dev/null
 python tools/run_pipeline_synth.py > $O/pipeline_640.json 2> /dev/null
 python tools/run_pipeline_synth.py --source 1920x1080 > $O/pipeline_1080p.json 2> /dev/null
-python tools/tracker_modes.py > $O/tracker_modes.json 2> /dev/null
+python tests/perf/tracker_modes.py > $O/tracker_modes.json 2> /dev/null
 python tools/bw_probe.py > $O/bandwidth_probe.txt 2> /dev/null
 echo "[collect] all done"
