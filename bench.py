@@ -27,6 +27,63 @@ import time
 
 import numpy as np
 
+
+class HwmonSampler:
+    """Clock and package power of one GPU from its hwmon files (`freq1_input`, `power1_input`), read by a thread every 50 ms
+    while the LONG window runs (never during the K timed steps that give `value`).  Evidence for where the staged bench sits
+    against the chip's power limit (`power1_cap`); every field is None when the files are not there or not readable."""
+
+    def __init__(self, device: int):
+        self.dir = None
+        self.samples = []
+        self._stop = None
+        try:
+            import ctypes, glob
+            hip = ctypes.CDLL("libamdhip64.so")
+            buf = ctypes.create_string_buffer(64)
+            if hip.hipDeviceGetPCIBusId(buf, 64, int(device)) != 0:
+                return
+            bdf = buf.value.decode().lower()
+            cand = glob.glob(f"/sys/bus/pci/devices/{bdf}/hwmon/hwmon*")
+            if cand and os.path.exists(os.path.join(cand[0], "freq1_input")):
+                self.dir = cand[0]
+        except Exception:
+            self.dir = None
+
+    def _read(self, name):
+        try:
+            with open(os.path.join(self.dir, name)) as f:
+                return int(f.read().strip())
+        except Exception:
+            return None
+
+    def start(self):
+        if self.dir is None:
+            return
+        import threading
+        self._stop = threading.Event()
+
+        def loop():
+            while not self._stop.wait(0.05):
+                self.samples.append((self._read("freq1_input"), self._read("power1_input")))
+        self._thread = threading.Thread(target=loop, daemon=True)
+        self._thread.start()
+
+    def stop(self):
+        if self._stop is None:
+            return None
+        self._stop.set()
+        self._thread.join(timeout=1.0)
+        f = [a for a, _ in self.samples if a]
+        w = [b for _, b in self.samples if b]
+        if not f or not w:
+            return None
+        cap = self._read("power1_cap")
+        return {"sclk_mhz_mean": round(sum(f) / len(f) / 1e6, 0), "sclk_mhz_min": round(min(f) / 1e6, 0), "sclk_mhz_max": round(max(f) / 1e6, 0),
+                "package_power_w_mean": round(sum(w) / len(w) / 1e6, 0), "package_power_w_max": round(max(w) / 1e6, 0),
+                "power_cap_w": round(cap / 1e6, 0) if cap else None, "samples": len(f),
+                "source": "hwmon freq1_input / power1_input every 50 ms during the long window (rank 0's GPU)"}
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
@@ -282,11 +339,14 @@ def main():
         # ---- the same steady state over a longer window (>= long_s seconds), for the record ----
         long_run = None
         if long_s > 0:
+            hw = HwmonSampler(dev) if rank == 0 else None
+            if hw:
+                hw.start()
             k = 0
             tl0 = pc()
             while pc() - tl0 < long_s or k * S * F < 1000:
                 step(t); t += 1; k += 1
-            long_run = {"steps": k, "seconds": pc() - tl0}
+            long_run = {"steps": k, "seconds": pc() - tl0, "power_clock": hw.stop() if hw else None}
         drain()                                          # the batches still in flight (outside the timed region)
         sync_all(det)
         if collective:
@@ -356,7 +416,13 @@ def main():
     if m["long"]:
         lr = m["long"]
         res["timing"]["long_window"] = {"value": round(world * S * F * lr["steps"] / lr["seconds"], 1), "unit": "frames/s (rank 0's own clock)",
-                                        "steps": lr["steps"], "seconds": round(lr["seconds"], 3)}
+                                        "steps": lr["steps"], "seconds": round(lr["seconds"], 3), "power_clock": lr.get("power_clock")}
+        pcw = lr.get("power_clock")
+        if pcw and isinstance(res.get("roofline"), dict) and res["roofline"].get("achieved"):
+            # informational: `peak` / `frac` stay priced at 2.4 GHz; this is the same peak at the clock the chip held under its power limit
+            held = 2500.0 * pcw["sclk_mhz_mean"] / 2400.0
+            res["roofline"]["at_held_clock"] = {"sclk_mhz": pcw["sclk_mhz_mean"], "peak": round(held, 1), "frac": round(res["roofline"]["achieved"] / held, 4),
+                                                "package_power_w": pcw["package_power_w_mean"], "power_cap_w": pcw["power_cap_w"]}
 
     tpath = os.path.join(ROOT, "profiles", "traffic_current.json")
     if os.path.exists(tpath) and not args.host_frames:
