@@ -237,7 +237,85 @@ static int run_conv3(int tile, int cin, int cout, int stride, int HWin, int B, i
     return 0;
 }
 
+// ---- energy per launch: one tile configuration run back to back for `secs` seconds while a host thread samples the GPU's hwmon
+// package power and clock every 20 ms (the staged bench runs at the package power limit: of two tiles that take the same time
+// the one that draws less is the better one there)
+#include <thread>
+#include <atomic>
+#include <chrono>
+#include <glob.h>
+static std::string hwmon_dir() {
+    char bdf[64] = {0};
+    if (hipDeviceGetPCIBusId(bdf, sizeof(bdf), 0) != hipSuccess) return "";
+    for (char *c = bdf; *c; ++c) *c = (char)tolower(*c);
+    std::string pat = std::string("/sys/bus/pci/devices/") + bdf + "/hwmon/hwmon*";
+    glob_t g; std::string out;
+    if (glob(pat.c_str(), 0, nullptr, &g) == 0 && g.gl_pathc > 0) out = g.gl_pathv[0];
+    globfree(&g);
+    return out;
+}
+static long read_long(const std::string &path) { FILE *f = fopen(path.c_str(), "r"); if (!f) return -1; long v = -1; if (fscanf(f, "%ld", &v) != 1) v = -1; fclose(f); return v; }
+static int run_energy(int tile, int ks, int cin, int cout, int HW, int B, double secs) {
+    const size_t per = (size_t)(HW + 2) * (HW + 2);
+    f16 *in, *out, *w; float *bias;
+    CK(hipMalloc(&in, per * B * cin * 2)); CK(hipMalloc(&out, per * B * cout * 2)); CK(hipMemset(out, 0, per * B * cout * 2));
+    {   std::vector<f16> h(per * B * cin);
+        for (auto &v : h) v = (f16)(((rand() % 2000) - 1000) * 1e-3f);
+        CK(hipMemcpy(in, h.data(), h.size() * 2, hipMemcpyHostToDevice)); }
+    const int kp = ks * ks * cin;
+    std::vector<f16> hw((size_t)((cout + 127) / 128 * 128) * kp);
+    for (auto &v : hw) v = (f16)(((rand() % 200) - 100) * 1e-3f);
+    CK(hipMalloc(&w, hw.size() * 2)); CK(hipMemcpy(w, hw.data(), hw.size() * 2, hipMemcpyHostToDevice));
+    CK(hipMalloc(&bias, 4096)); CK(hipMemset(bias, 0, 4096));
+    unsigned long long *d_st;
+    CK(hipMalloc(&d_st, (size_t)65536 * 16 * 8)); CK(hipMemset(d_st, 0, (size_t)65536 * 16 * 8));
+    CK(hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), &d_st, sizeof(d_st)));
+    ConvLaunch c;
+    auto view = [&](f16 *base, int Ct) { TensorView v; v.base = base; v.H = v.W = HW; v.C = Ct; v.pad = 1; v.coff = 0; v.c = Ct; return v; };
+    c.in = view(in, cin); c.out = view(out, cout); c.wt = w; c.bias = bias; c.B = B; c.cin = cin; c.cout = cout; c.ks = ks; c.stride = 1; c.act = 1; c.kp = kp; c.tile = tile;
+    if (launch_conv(c, nullptr) != 0) { printf("  (tile %s is not legal for this conv)\n", tile_name(tile)); hipFree(in); hipFree(out); hipFree(w); hipFree(bias); hipFree(d_st); return 0; }
+    CK(hipDeviceSynchronize());
+    const std::string dir = hwmon_dir();
+    std::atomic<bool> stop{false};
+    std::vector<long> pw, fq;
+    std::thread sampler([&]() {
+        while (!stop.load()) {
+            if (!dir.empty()) { pw.push_back(read_long(dir + "/power1_input")); fq.push_back(read_long(dir + "/freq1_input")); }
+            std::this_thread::sleep_for(std::chrono::milliseconds(20));
+        }
+    });
+    const auto t0 = std::chrono::steady_clock::now();
+    long launches = 0;
+    double el = 0;
+    do {
+        for (int i = 0; i < 200; ++i) launch_conv(c, nullptr);
+        CK(hipDeviceSynchronize());
+        launches += 200;
+        el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    } while (el < secs);
+    stop.store(true); sampler.join();
+    // drop the first 30 % of the samples (ramp of the power reading)
+    double p = 0, f = 0; int n = 0;
+    for (size_t i = pw.size() * 3 / 10; i < pw.size(); ++i) if (pw[i] > 0 && fq[i] > 0) { p += pw[i] * 1e-6; f += fq[i] * 1e-6; ++n; }
+    if (n) { p /= n; f /= n; }
+    const double us = el / launches * 1e6;
+    printf("%dx%d conv %d -> %d, %dx%d x %d, tile %-18s %7.1f us/launch  %6.0f W  %5.0f MHz  -> %7.1f mJ/launch (above the 290 W of an idle chip: %6.1f mJ)\n", ks, ks, cin, cout, HW, HW, B,
+           tile_name(tile), us, p, f, p * us * 1e-3, (p - 290.0) * us * 1e-3);
+    hipFree(in); hipFree(out); hipFree(w); hipFree(bias); hipFree(d_st);
+    return 0;
+}
+
 int main(int argc, char **argv) {
+    if (argc > 1 && !strcmp(argv[1], "energy")) {
+        const double secs = argc > 2 ? atof(argv[2]) : 1.5;
+        for (int t : {TILE_K64_128x128_S2_W8, TILE_PT_128x128_S2, TILE_K64_256x128_S2_W8, TILE_128x128, TILE_128x64, TILE_WS_128x128, TILE_K64_128x128_S3_W8})
+            if (run_energy(t, 1, 512, 256, 40, 32, secs)) return 1;                      // 6.cv2
+        for (int t : {TILE_K64_128x128_S2_W8, TILE_PT_128x128_S2, TILE_K64_256x128_S2_W8, TILE_128x64, TILE_WS_128x128})
+            if (run_energy(t, 1, 256, 128, 80, 32, secs)) return 1;                      // 4.cv2
+        for (int t : {TILE_ROWS_256x64_W8, TILE_ROWS_128x64_W8, TILE_ROWS_K64_256x64_W8, TILE_ROWS_K64_128x128_W8, TILE_PT_128x128_S2, TILE_K64_128x128_S2_W8, TILE_K64_256x128_S2_W8})
+            if (run_energy(t, 3, 128, 128, 40, 32, secs)) return 1;                      // 6.m / 12.m / 18.m
+        return 0;
+    }
     if (argc > 1 && !strcmp(argv[1], "rows")) {                                  // 3x3 stride-1 convs on the tap-reuse kernel (stamps 0..6)
         const int t6[] = {TILE_ROWS_256x64_W8, TILE_ROWS_128x64_W8, TILE_ROWS_K64_256x64_W8};
         for (int t : t6) if (run_conv3(t, 128, 128, 1, 40, 32, 0)) return 1;      // 6.m / 12.m / 18.m
