@@ -32,25 +32,13 @@
 #include <algorithm>
 
 #include "kernels.h"
+#include "tile_math.h"
 
 namespace rtmodt {
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 typedef float floatx4 __attribute__((ext_vector_type(4)));
-
-// Division by a launch constant: n / d == (n * mul) >> shift for every 0 <= n < 2^31 (shift = 31 + ceil(log2 d),
-// mul = ceil(2^shift / d) < 2^32: the error term n * (mul * d - 2^shift) stays below 2^shift).  One 32x32->64 multiply and
-// one shift instead of the ~30-instruction expansion of an integer division: the epilogues turn a pixel index into
-// (image, row, column) once per 16-byte store.
-struct FastDiv { unsigned mul, shift; };
-static inline FastDiv make_fastdiv(int d) {
-    unsigned s = 0;
-    while ((1u << s) < (unsigned)d) ++s;
-    const unsigned long long p2 = 1ull << (31 + s);
-    return FastDiv{(unsigned)((p2 + (unsigned)d - 1) / (unsigned)d), 31 + s};
-}
-__device__ __forceinline__ int fdiv(int n, const FastDiv &f) { return (int)(((unsigned long long)(unsigned)n * f.mul) >> f.shift); }
 
 struct ConvArgs {
     const f16 *in;      // input tensor base + channel offset
@@ -105,10 +93,7 @@ __device__ __forceinline__ void store8(f16 *base, long off, const half4 &v, int 
 // remapped (bijectively) so that ids congruent mod 8 -- one XCD under round-robin placement --
 // cover one contiguous run of pixel tiles with all their cout tiles.
 __device__ __forceinline__ void xcd_tile(int gx, int gy, int bx, int by, int &mt, int &nt) {
-    const int n = gx * gy, lin = bx + by * gx;
-    const int q = n >> 3, r = n & 7, xcd = lin & 7, k = lin >> 3;
-    const int start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-    const int id = start + k;
+    const int id = xcd_tile_id(gx * gy, bx + by * gx);          // tile_math.h
     mt = id / gy;
     nt = id - mt * gy;
 }
@@ -1086,14 +1071,8 @@ __global__ __launch_bounds__(512) void conv_mfma64_pt(ConvArgs p, int groups) {
     // Which pixel tiles: workgroups go round-robin over the 8 XCDs, and XCD x works on the x-th contiguous eighth of the tile
     // list (as in xcd_tile: neighbouring tiles of a 3x3 conv share input rows, which should meet in ONE L2); inside that run
     // the XCD's workgroups (rank j of Gx) take tiles j, j + Gx, ... -- at any time the XCD is busy with Gx consecutive tiles.
-    // (fewer than 8 workgroups per slice: one run per workgroup, so that every run has an owner)
-    const bool few = groups < 8;
-    const int X = few ? groups : 8;
-    const int xcd = few ? g : (g + blockIdx.y * groups) & 7;
-    const int g0 = few ? g : (xcd - blockIdx.y * groups) & 7;        // the first workgroup of this slice on that XCD
-    const int j = (g - g0) >> 3, Gx = few ? 1 : (groups - g0 + 7) >> 3;
-    const int q8 = n_mt / X, r8 = n_mt - q8 * X;
-    const int run0 = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8, run_n = q8 + (xcd < r8 ? 1 : 0);
+    const PtRun run = pt_run(g, blockIdx.y, groups, n_mt);       // tile_math.h (checked exhaustively on the host)
+    const int j = run.j, Gx = run.Gx, run0 = run.run0, run_n = run.run_n;
     const int n_my = j < run_n ? (run_n - j + Gx - 1) / Gx : 0;
     const int S = n_my * nk;                                // steps of this workgroup
     auto tile_m0 = [&](int ti) { return (run0 + j + ti * Gx) * BM; };

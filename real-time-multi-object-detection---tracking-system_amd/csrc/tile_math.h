@@ -1,0 +1,53 @@
+// tile_math.h -- the integer arithmetic the conv kernels share with their host-side tests: plain C++, no HIP types, so that
+// tests/test_tile_math_cpu.py can compile it with g++ and check it exhaustively on the build box (no GPU).
+#pragma once
+
+#if defined(__HIPCC__)
+#define RT_HD __host__ __device__ __forceinline__
+#else
+#define RT_HD inline
+#endif
+
+namespace rtmodt {
+
+// Division by a launch constant: n / d == (n * mul) >> shift for every 0 <= n < 2^31 (shift = 31 + ceil(log2 d),
+// mul = ceil(2^shift / d) < 2^32: the error term n * (mul * d - 2^shift) stays below 2^shift).  One 32x32->64 multiply and
+// one shift instead of the ~30-instruction expansion of an integer division: the epilogues turn a pixel index into
+// (image, row, column) once per 16-byte store.
+struct FastDiv { unsigned mul, shift; };
+inline FastDiv make_fastdiv(int d) {
+    unsigned s = 0;
+    while ((1u << s) < (unsigned)d) ++s;
+    const unsigned long long p2 = 1ull << (31 + s);
+    return FastDiv{(unsigned)((p2 + (unsigned)d - 1) / (unsigned)d), 31 + s};
+}
+RT_HD int fdiv(int n, const FastDiv &f) { return (int)(((unsigned long long)(unsigned)n * f.mul) >> f.shift); }
+
+// XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (launch-linear id & 7); XCD x works on the x-th
+// contiguous eighth of the n tiles.  Returns the tile id of workgroup `lin`.
+RT_HD int xcd_tile_id(int n, int lin) {
+    const int q = n >> 3, r = n & 7, xcd = lin & 7, k = lin >> 3;
+    const int start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return start + k;
+}
+
+// Persistent tile kernel (conv_mfma64_pt): which pixel tiles workgroup g of cout slice `slice` walks over.  `groups` workgroups
+// per slice, n_mt pixel tiles.  XCD x owns the x-th contiguous run of the tile list; inside it the XCD's workgroups of this
+// slice (rank j of Gx) take tiles run0 + j, run0 + j + Gx, ...  With fewer than 8 workgroups per slice every workgroup gets a
+// run of its own, so that every run has an owner.
+struct PtRun { int run0, run_n, j, Gx; };
+RT_HD PtRun pt_run(int g, int slice, int groups, int n_mt) {
+    const bool few = groups < 8;
+    const int X = few ? groups : 8;
+    const int xcd = few ? g : (g + slice * groups) & 7;
+    const int g0 = few ? g : (xcd - slice * groups) & 7;           // the first workgroup of this slice on that XCD
+    PtRun r;
+    r.j = (g - g0) >> 3;
+    r.Gx = few ? 1 : (groups - g0 + 7) >> 3;
+    const int q = n_mt / X, rem = n_mt - q * X;
+    r.run0 = xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q;
+    r.run_n = q + (xcd < rem ? 1 : 0);
+    return r;
+}
+
+}  // namespace rtmodt

@@ -1,0 +1,79 @@
+// Host-side check of the integer arithmetic the conv kernels use (csrc/tile_math.h), compiled with g++ by
+// tests/test_tile_math_cpu.py.  Exit code 0 and a line "ok ..." on success; the first counter-example otherwise.
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include <random>
+#include "tile_math.h"
+using namespace rtmodt;
+
+static int check_fastdiv() {
+    long checked = 0;
+    std::mt19937_64 rng(1234);
+    auto one = [&](int n, int d) -> bool {
+        const FastDiv f = make_fastdiv(d);
+        if (fdiv(n, f) != n / d) { printf("fastdiv: %d / %d = %d, got %d (mul %u shift %u)\n", n, d, n / d, fdiv(n, f), f.mul, f.shift); return false; }
+        ++checked;
+        return true;
+    };
+    for (int d = 1; d <= (1 << 20); d += (d < 70000 ? 1 : 257)) {           // every divisor a feature map can produce, then a stride
+        const int top = 2147483647;
+        const int ns[] = {0, 1, d - 1, d, d + 1, 2 * d - 1, 2 * d, top, top - 1, top / d * d, top / d * d - 1};
+        for (int n : ns) if (n >= 0 && !one(n, d)) return 1;
+        for (int k = 0; k < 6; ++k) {
+            const long long m = (long long)(rng() % (unsigned long long)(top / d + 1)) * d;      // a multiple of d and its neighbours
+            for (long long n : {m - 1, m, m + 1}) if (n >= 0 && n <= top && !one((int)n, d)) return 1;
+            if (!one((int)(rng() & 0x7FFFFFFF), d)) return 1;
+        }
+    }
+    for (int d : {102400, 409600, 6400, 1600, 400, 25600, 215168, 56448, 15488, 82, 42, 22, 162, 322, 2147483647, 1073741824, 1073741825})
+        for (int k = 0; k < 200000; ++k) if (!one((int)(rng() & 0x7FFFFFFF), d)) return 1;
+    printf("ok fastdiv %ld cases\n", checked);
+    return 0;
+}
+
+static int check_xcd_tile() {
+    for (int n = 1; n <= 5000; ++n) {
+        std::vector<int> seen(n, 0);
+        for (int lin = 0; lin < n; ++lin) {
+            const int id = xcd_tile_id(n, lin);
+            if (id < 0 || id >= n || seen[id]++) { printf("xcd_tile_id: n %d lin %d -> %d\n", n, lin, id); return 1; }
+        }
+        // one XCD's tiles are one contiguous run, visited in order
+        for (int x = 0; x < 8 && x < n; ++x) {
+            int prev = -1;
+            for (int lin = x; lin < n; lin += 8) { const int id = xcd_tile_id(n, lin); if (prev >= 0 && id != prev + 1) { printf("xcd run broken: n %d xcd %d\n", n, x); return 1; } prev = id; }
+        }
+    }
+    printf("ok xcd_tile_id\n");
+    return 0;
+}
+
+static int check_pt_run() {
+    long cfgs = 0;
+    for (int n_mt = 1; n_mt <= 700; ++n_mt)
+        for (int slices = 1; slices <= 5; ++slices)
+            for (int per_cu = 1; per_cu <= 3; ++per_cu) {
+                int groups = per_cu * 256 / slices;
+                if (groups > n_mt) groups = n_mt;
+                if (groups < 1) groups = 1;
+                for (int slice = 0; slice < slices; ++slice) {
+                    std::vector<int> seen(n_mt, 0);
+                    for (int g = 0; g < groups; ++g) {
+                        const PtRun r = pt_run(g, slice, groups, n_mt);
+                        if (r.Gx < 1 || r.j < 0 || r.j >= r.Gx || r.run0 < 0 || r.run0 + r.run_n > n_mt) { printf("pt_run: bad run n_mt %d groups %d slice %d g %d\n", n_mt, groups, slice, g); return 1; }
+                        const int n_my = r.j < r.run_n ? (r.run_n - r.j + r.Gx - 1) / r.Gx : 0;      // as the kernel computes it
+                        for (int t = 0; t < n_my; ++t) {
+                            const int tile = r.run0 + r.j + t * r.Gx;
+                            if (tile >= r.run0 + r.run_n || seen[tile]++) { printf("pt_run: tile %d twice or outside (n_mt %d groups %d slice %d g %d)\n", tile, n_mt, groups, slice, g); return 1; }
+                        }
+                    }
+                    for (int t = 0; t < n_mt; ++t) if (!seen[t]) { printf("pt_run: tile %d has no owner (n_mt %d groups %d slices %d slice %d)\n", t, n_mt, groups, slices, slice); return 1; }
+                    ++cfgs;
+                }
+            }
+    printf("ok pt_run %ld configurations, every pixel tile of every slice owned exactly once\n", cfgs);
+    return 0;
+}
+
+int main() { return check_fastdiv() || check_xcd_tile() || check_pt_run(); }
