@@ -308,7 +308,8 @@ static int run_energy(int tile, int ks, int cin, int cout, int HW, int B, double
 int main(int argc, char **argv) {
     if (argc > 1 && !strcmp(argv[1], "energy")) {
         const double secs = argc > 2 ? atof(argv[2]) : 1.5;
-        for (int t : {TILE_K64_128x128_S2_W8, TILE_PT_128x128_S2, TILE_K64_256x128_S2_W8, TILE_128x128, TILE_128x64, TILE_WS_128x128, TILE_K64_128x128_S3_W8})
+        for (int t : {TILE_K64_128x128_S2_W8, TILE_PT_128x128_S2, TILE_K64_256x128_S2_W8, TILE_128x128, TILE_128x64, TILE_WS_128x128, TILE_K64_128x128_S3_W8,
+                      TILE_K64_128x128_S2, TILE_K64_128x128_S2W, TILE_K64_256x128_S2, TILE_K64_128x128_S3})      // (the last four: 4 waves, 64 x 64 or 32 x 128 per wave)
             if (run_energy(t, 1, 512, 256, 40, 32, secs)) return 1;                      // 6.cv2
         for (int t : {TILE_K64_128x128_S2_W8, TILE_PT_128x128_S2, TILE_K64_256x128_S2_W8, TILE_128x64, TILE_WS_128x128})
             if (run_energy(t, 1, 256, 128, 80, 32, secs)) return 1;                      // 4.cv2
