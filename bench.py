@@ -119,6 +119,8 @@ def parse():
     ap.add_argument("--no-host-leg", action="store_true", help="skip the extra PCIe-inclusive measurement")
     ap.add_argument("--no-verify", action="store_true", help="skip the untimed output self-check")
     ap.add_argument("--prewarm", type=float, default=1.0, help="seconds of untimed full-pipeline running before the timed region (besides --warmup steps)")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="rendez-vous only: every rank joins the process group, rank 0 prints {n_gpus, ranks}, nobody touches a GPU (CPU test of the launcher path)")
     ap.add_argument("--long", type=float, default=1.0, help="seconds of the additional long steady-state window reported beside the K timed steps (0: off)")
     return ap.parse_args()
 
@@ -160,9 +162,16 @@ def cpu_baseline(pkg, weights, args, budget_s=20.0):
             "p50_ms": round(float(np.median(t)) * 1e3, 2)}
 
 
-def verify_outputs(pkg, det, frame_ptrs, size, max_det):
-    """One more batch through the benchmarked detector (same engine, tiles and streams); for every image the fetched
-    detections must equal oracle NMS + scale_boxes applied to the engine's own pre-NMS tensor, bit for bit."""
+def verify_outputs(pkg, det, frame_ptrs, size, max_det, weights, scale):
+    """One more batch through the benchmarked detector (same engine, tiles, stages and streams), after the timed region:
+      (1) for every image the fetched detections must equal oracle NMS + scale_boxes applied to the engine's own pre-NMS
+          tensor, bit for bit;
+      (2) the convs that were just timed: every stored layer of the first and the last image of the batch against the fp32
+          oracle fed the engine's own fp16 inputs (teacher forcing), tolerance 2e-3 * max|ref| + 2e-3 as in tests/ (4e-3 where
+          the tuner may keep an fp16 intermediate in LDS: fused Bottlenecks, conv -> 1x1 pairs) -- a wrong tile in
+          conv_mfma64_pt, conv3x3_rows_grp, bottleneck_fused or a tail kernel cannot hide behind (1);
+      (3) decode on the engine's own head logits, rtol = atol = 2e-4.
+    The oracle is the checker; any mismatch aborts the bench."""
     from oracle import yolo_oracle as Y
     det.enqueue(frame_ptrs, height=size, width=size)
     got = det.fetch()
@@ -178,18 +187,110 @@ def verify_outputs(pkg, det, frame_ptrs, size, max_det):
             raise SystemExit(f"bench self-check FAILED on image {i}: engine detections differ from oracle NMS on the engine's own pre-NMS tensor")
         n_img += 1
         n_box += len(d)
+    # (2) + (3)
+    names = [c.name for c in pkg.weights.spec(scale)]
+    loose = {"2.cv1", "4.cv1", "6.cv1", "8.cv1", "2.cv2", "15.cv2"}
+    worst, checked = ("", 0.0), 0
+    images = sorted({0, len(got) - 1})
+    for img in images:
+        inp, heads, pred = det.debug_fetch(img)
+        gpu = {}
+        for n in names:
+            try:
+                gpu[n] = det.debug_layer(n, img).astype(np.float32)
+            except pkg._ffi.RtmodtError as e:                  # fused away: lives in LDS only (the consumer is checked instead)
+                if e.code != pkg._ffi.E_UNSUPPORTED:
+                    raise
+        taps = {}
+        Y.forward(inp.astype(np.float32), weights, scale, taps=taps, force=gpu)
+        for n, g in gpu.items():
+            k = 4e-3 if (n in loose or (".m." in n and n.endswith(".cv2"))) else 2e-3
+            tol = k * float(np.abs(taps[n]).max()) + 2e-3
+            err = float(np.abs(taps[n] - g).max())
+            if not np.isfinite(err) or err > tol:
+                raise SystemExit(f"bench self-check FAILED: image {img} layer {n}: max err {err:.4g} > tol {tol:.4g} vs the fp32 oracle (teacher-forced)")
+            if err / tol > worst[1]:
+                worst = (n, err / tol)
+            checked += 1
+        A, maps, off = det.model.n_anchors, [], 0
+        for s_ in (size // 8, size // 16, size // 32):
+            maps.append(heads[off:off + s_ * s_ * 144].reshape(s_, s_, 144).astype(np.float32)); off += s_ * s_ * 144
+        if not np.allclose(pred, Y.decode(maps), rtol=2e-4, atol=2e-4):
+            raise SystemExit(f"bench self-check FAILED: image {img}: decode differs from the oracle on the engine's own head logits")
+    launches = [n for n, _, _ in det.profile(1)]
+    fam = {"conv_mfma64_pt": sum("pt:" in n for n in launches), "conv3x3_rows(_grp)": sum("rows" in n for n in launches),
+           "bottleneck_fused": sum("bottleneck" in n for n in launches), "conv_mfma_tail": sum("tail:" in n for n in launches),
+           "8-wave tiles": sum("/8w" in n for n in launches), "head_final": sum("head_final" in n for n in launches)}
     return {"ok": True, "images": n_img, "boxes": n_box,
-            "what": "fetched detections == oracle non_max_suppression + scale_boxes on the engine's pre-NMS tensor (bit-exact), every image of one batch"}
+            "what": "fetched detections == oracle non_max_suppression + scale_boxes on the engine's pre-NMS tensor (bit-exact), every image of one batch",
+            "layers_ok": True, "layers_checked": checked, "layer_images": images,
+            "layers_what": "every stored conv output of these images vs the fp32 oracle fed the engine's own inputs, |err| <= 2e-3 (4e-3 behind an LDS-resident "
+                           "fp16 intermediate) * max|ref| + 2e-3; decode on the engine's head logits rtol = atol = 2e-4",
+            "worst_layer": {"name": worst[0], "err_over_tol": round(worst[1], 3)}, "launches_by_kernel_family": fam}
+
+
+def launch_ranks(args) -> int:
+    """`bench.py --gpus N` started WITHOUT a launcher (WORLD_SIZE unset): start the N ranks ourselves, as a CHILD
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py <same arguments>`,
+    before this process has imported the package or touched a GPU (a process that has initialised the GPU must never
+    exec or be replaced; a plain child is safe).  The child's rank 0 prints the JSON line; it is passed through once,
+    after checking that it really reports N GPUs.  Returns the exit code."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC only on this pool (RCCL across processes)
+    env.setdefault("OMP_NUM_THREADS", "4")
+    child = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    line = None
+    for out in child.stdout:
+        if out.startswith("{") and '"n_gpus"' in out:
+            line = out.strip()
+        else:
+            sys.stderr.write(out)                          # anything else a rank printed: keep stdout to the one JSON line
+    rc = child.wait()
+    if rc != 0:
+        print(f"bench.py: the {args.gpus}-rank child run failed with exit code {rc}", file=sys.stderr)
+        return rc
+    if line is None:
+        print("bench.py: the ranks finished without printing a result line", file=sys.stderr)
+        return 1
+    got = json.loads(line).get("n_gpus")
+    if got != args.gpus:
+        print(f"bench.py: asked for --gpus {args.gpus} but the run reports n_gpus = {got}; refusing to print it", file=sys.stderr)
+        return 1
+    print(line, flush=True)
+    return 0
 
 
 def main():
     args = parse()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args))
     import rtmodt_amd  # noqa: F401
     pkg = sys.modules["rtmodt_amd"]
     sync = pkg.streams.NodeSync(backend=args.backend)    # RCCL; no process group when WORLD_SIZE == 1
     rank, local_rank, world = sync.rank, sync.local_rank, sync.world
-    if args.gpus != world and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the line would not describe the run")
+    if args.launch_check:
+        ranks = sync.sum_stats([1])[0]
+        sync.barrier()
+        if rank == 0:
+            print(json.dumps({"launch_check": True, "n_gpus": world, "ranks_joined": ranks, "backend": args.backend}), flush=True)
+        sync.close()
+        return
+    if not args.one_device:
+        ndev = pkg._ffi.device_count()
+        if local_rank >= ndev:
+            raise SystemExit(f"rank {rank}: --gpus {args.gpus} needs GPU {local_rank} but only {ndev} are visible (rehearsal on one card: --one-device --backend gloo)")
 
     from importlib import import_module
     core_cls = import_module(pkg.__name__ + ".tracking.tracker")._ByteTrackCore
@@ -435,7 +536,8 @@ def main():
     # ---- untimed self-check on one more batch of the SAME detector: NMS survivors, boxes, scores and classes of every image
     # must equal the oracle's non_max_suppression + scale_boxes on the engine's own pre-NMS tensor (the oracle is the checker) ----
     if not args.no_verify:
-        res["verified"] = verify_outputs(pkg, det, [pt for f in range(F) for pt in ptrs[f % R]], size, args.max_det)
+        res["verified"] = verify_outputs(pkg, det, [pt for f in range(F) for pt in ptrs[f % R]], size, args.max_det,
+                                         weights if weights is not None else pkg.weights.load(wpath)[0], args.model)
 
     # ---- per-kernel view (eager, HIP events around every launch) ----
     prof = det.profile(3)

@@ -126,6 +126,13 @@ def ptr(a: np.ndarray | None):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
 
 
+def device_count() -> int:
+    """GPUs visible to this process (``rtmodt_device_count``)."""
+    n = C.c_int(0)
+    check(lib().rtmodt_device_count(C.byref(n)))
+    return n.value
+
+
 def device_ordinal(device) -> int:
     """``"cuda:1"`` / ``"1"`` / ``1`` -> 1 (ROCm keeps the ``cuda`` spelling, detector.py:66)."""
     if isinstance(device, int):

@@ -11,8 +11,11 @@ so that ``pipeline.run`` takes either.  What is different, because the step afte
   ``ffmpeg -i rtsp://... -f rawvideo -pix_fmt bgr24 -`` writes), ``"synthetic"`` -- a generated ring; ``register_backend``
   adds others (a ``cv2.VideoCapture`` wrapper is four lines and listed in INTEGRATION.md);
 * decoded frames land directly in a PAGE-LOCKED ring (``pipeline.PinnedFrameRing``) when one is given: the detector's upload
-  of such a frame is one asynchronous DMA, and ``read(copy=False)`` hands out the slot itself instead of a copy.  The ring has
-  ``buffer_size + 2`` slots: the latest frame, the one a consumer may still be uploading, and the one being written.
+  of such a frame is one asynchronous DMA, and ``read(copy=False)`` hands out the slot itself instead of a copy -- as a
+  LEASE: the capture thread never writes into a leased slot, and the consumer gives it back with ``release(frame_id)`` once
+  the batch the frame went into has been fetched (``Detector.fetch``; the detector keeps up to three batches in flight and
+  may read page-locked frames in place).  The ring needs at least ``buffer_size + 2`` slots (the latest frame, one being
+  written, ``buffer_size`` leased); size it by the consumer's in-flight depth: ``slots = frames in flight + 2``.
 """
 from __future__ import annotations
 
@@ -126,6 +129,12 @@ class FrameReader:
             raise ValueError(f"unknown ingest backend {backend!r}; registered: {sorted(_BACKENDS)}")
         self._backend_kw = backend_kw
         self._ring = ring                              # pipeline.PinnedFrameRing or None
+        if ring is not None and ring.slots < self.buffer_size + 2:
+            raise ValueError(f"a ring of {ring.slots} slots cannot hold buffer_size={self.buffer_size} leased frames plus the latest "
+                             f"frame and the one being written: build it with >= {self.buffer_size + 2} slots")
+        self._leases: Dict[int, int] = {}              # ring slot -> outstanding leases
+        self._lease_slot: Dict[int, int] = {}          # frame id -> ring slot
+        self._latest_slot = -1
         self._cap = None
         self._latest: Optional[np.ndarray] = None
         self._slot = 0
@@ -147,13 +156,42 @@ class FrameReader:
         return self
 
     def read(self, copy: bool = True):
-        """``(ok, frame, frame_id)``, non-blocking; ``copy=False`` hands out the (page-locked) slot itself -- valid until
-        ``buffer_size + 1`` newer frames have arrived."""
+        """``(ok, frame, frame_id)``, non-blocking.  ``copy=False`` hands out the (page-locked) ring slot itself under a
+        lease: it is not rewritten until ``release(frame_id)``.  With every slot but the latest and the write slot on
+        lease the call raises -- release earlier frames (after their batch's ``fetch``) or build a larger ring."""
         with self._lock:
             if self._latest is None:
                 return False, None, self._frame_id
             self._served_id = self._frame_id
-            return True, (self._latest.copy() if copy else self._latest), self._frame_id
+            if copy:
+                return True, self._latest.copy(), self._frame_id
+            if self._ring is not None:                 # (without a ring every frame is a fresh array: nothing to protect)
+                slot = self._latest_slot
+                if slot not in self._leases and len(self._leases) >= self._ring.slots - 2:
+                    raise RuntimeError(f"all {self._ring.slots - 2} leasable ring slots are on lease: release(frame_id) the frames whose "
+                                       "batches have been fetched, or build the ring with more slots")
+                if self._frame_id not in self._lease_slot:
+                    self._leases[slot] = self._leases.get(slot, 0) + 1
+                    self._lease_slot[self._frame_id] = slot
+            return True, self._latest, self._frame_id
+
+    def release(self, frame_id: int) -> None:
+        """Give back the slot leased by ``read(copy=False)`` for ``frame_id`` (no-op for ids that hold no lease)."""
+        with self._lock:
+            slot = self._lease_slot.pop(frame_id, None)
+            if slot is None:
+                return
+            left = self._leases.get(slot, 0) - 1
+            if left > 0:
+                self._leases[slot] = left
+            else:
+                self._leases.pop(slot, None)
+
+    @property
+    def leased(self) -> int:
+        """Ring slots currently on lease."""
+        with self._lock:
+            return len(self._leases)
 
     def stop(self) -> None:
         self._stop.set()
@@ -186,7 +224,6 @@ class FrameReader:
 
     def _loop(self) -> None:
         failures = 0
-        n_slots = self.buffer_size + 2
         while not self._stop.is_set():
             if self._cap is None or not self._cap.opened:
                 if failures >= self.max_reconnects:
@@ -207,10 +244,18 @@ class FrameReader:
             if not self._cap.grab():
                 self._release()
                 continue
-            dst = None
+            dst, slot = None, -1
             if self._ring is not None:
-                self._slot = (self._slot + 1) % n_slots
-                dst = self._ring.frame(self._slot)
+                with self._lock:                         # next slot that is neither on lease nor the latest frame
+                    n = self._ring.slots
+                    slot = next((c for c in ((self._slot + k) % n for k in range(1, n + 1))
+                                 if c not in self._leases and c != self._latest_slot), -1)
+                if slot < 0:                             # cannot happen while leases <= slots - 2; never write over a lease
+                    self._cap.retrieve(None)
+                    self.dropped += 1
+                    continue
+                self._slot = slot
+                dst = self._ring.frame(slot)
             ok, frame = self._cap.retrieve(dst)
             if not ok or frame is None:
                 continue
@@ -218,6 +263,7 @@ class FrameReader:
                 if self._frame_id != self._served_id:
                     self.dropped += 1
                 self._latest = frame
+                self._latest_slot = slot
                 self._frame_id += 1
             failures = 0
 

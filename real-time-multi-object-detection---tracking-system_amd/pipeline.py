@@ -83,12 +83,15 @@ def run(source, detector, tracker, profiler: Optional[LatencyProfiler] = None, m
             profiler.record("nms", nms)
             profiler.record("inference", max(total_inf - pre - nms, 0.0))
         handoff = device_handoff and hasattr(tracker, "update_from_detector") and hasattr(detector, "model")
+        # the track list stays on the device only when the event stage can read it there; an engine with the reference's
+        # host API alone (`process(tracks, fid)`) must be handed the materialised list, trails included
+        events_on_device = handoff and event_engine is not None and hasattr(event_engine, "process_tracker")
         profiler.tick("tracking")
-        tracks = tracker.update_from_detector(detector, materialize=event_engine is None) if handoff else tracker.update(detections)
+        tracks = tracker.update_from_detector(detector, materialize=not events_on_device) if handoff else tracker.update(detections)
         profiler.tock("tracking")
         if event_engine is not None:                       # tools/run_pipeline.py:141-146
             profiler.tick("events")
-            if handoff and hasattr(event_engine, "process_tracker"):
+            if events_on_device:
                 n_events += len(event_engine.process_tracker(tracker, fid, class_names=getattr(detector.model, "names", None))[0])
             else:
                 n_events += len(event_engine.process(tracks, fid))

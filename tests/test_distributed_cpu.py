@@ -77,3 +77,27 @@ def test_shard_properties(pkg):
     s = pkg.streams.NodeSync(world=1, rank=0)
     assert s.max_time(1.5) == 1.5 and s.sum_stats([1, 2]) == [1, 2]
     s.barrier()
+
+
+def test_bench_starts_its_own_ranks_when_run_bare():
+    """the driver runs `python bench.py --gpus N` WITHOUT a launcher.  bench.py must then start the N
+    ranks itself (a child `torch.distributed.run`, before anything touches a GPU) and print ONE line that reports N --
+    never a 1-GPU measurement labelled N.  `--launch-check` stops after the rendez-vous, so this runs on CPUs (gloo)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--one-device", "--launch-check"],
+                         env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["ranks_joined"] == 2 and rec["launch_check"] is True
+    # under a launcher whose world disagrees with --gpus the run is refused instead of mislabelled
+    env2 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--launch-check"],
+                         env=env2, capture_output=True, text=True, timeout=120)
+    assert bad.returncode != 0 and "WORLD_SIZE=1" in bad.stderr

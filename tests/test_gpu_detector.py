@@ -230,23 +230,50 @@ def match_report(rx, rc, rk, d, thr):
     return rows
 
 
-@pytest.mark.parametrize("src_hw,seed", [((1080, 1920), 5), ((640, 640), 1234), ((640, 640), 1239)])
-def test_end_to_end_vs_fp32_oracle(pkg, wdir, src_hw, seed):
+_E2E = {}
+
+
+def e2e_detector(pkg, wdir, autotune):
+    """One detector per tuning mode for all the free-running cases (module lifetime; closed by the last case's fixture teardown)."""
+    if autotune not in _E2E:
+        det, wts = make_detector(pkg, wdir, "s", 640, classes=[0, 1, 2, 3, 5, 7, 17, 18], max_det=300, autotune=autotune)
+        _E2E[autotune] = (det, wts, [n for n, _, _ in det.profile(1)])
+    return _E2E[autotune]
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _close_e2e_detectors():
+    yield
+    for det, _, _ in _E2E.values():
+        det.close()
+    _E2E.clear()
+
+
+@pytest.mark.parametrize("autotune", [False, True], ids=["default-tiles", "autotuned"])
+@pytest.mark.parametrize("src_hw,seed", [((1080, 1920), 5), ((640, 640), 1234), ((640, 640), 1235), ((640, 640), 1237), ((640, 640), 1239)])
+def test_end_to_end_vs_fp32_oracle(pkg, wdir, src_hw, seed, autotune):
     """Whole pipeline, FREE-RUNNING fp16 engine vs all-fp32 oracle (no teacher forcing: the drift of 63 fp16 convs is in).
-    north_star: IoU >= 0.99 per box, identical NMS survivors.  What is asserted, and printed with -s:
+    north_star: IoU >= 0.99 per box, identical NMS survivors.  Two engine configurations: the default tiles (`autotune=False`:
+    the same launches on every box -- with `weights.synthetic`'s quantised calibration the whole case is box-independent)
+    and the autotuned one (what the bench runs; its picks are printed on failure).  Asserted, and printed with -s:
       (1) head logits: max and p99 |engine - oracle| over the three Detect maps (box and class logits separately);
-      (2) pre-NMS tensor: boxes within 1 % of their extent + 0.5 px, scores within 0.03;
+      (2) pre-NMS tensor: boxes within 1 % of their extent + 0.5 px, scores within 0.008;
       (3) NMS on the engine's own pre-NMS tensor: bit-exact (identical survivors given identical inputs);
-      (4) every oracle detection whose score clears the confidence threshold by more than the measured score drift is
-          reproduced with IoU >= 0.99 and the same class.  Oracle detections closer to the threshold than that may flip
-          (their score crosses 0.35 in one net and not the other) -- the only allowed kind of miss; they are counted."""
+      (4) EVERY decision NMS takes -- candidate membership, best class, pairwise IoU > 0.45, walk order -- is compared between
+          the two tensors (tests/nms_audit.py).  A decision may differ only where the ORACLE's margin is inside the drift
+          tolerance (score 0.005, IoU 0.008; measured drift 0.004 / 0.005): then the engine's survivors are exactly NMS of the
+          oracle's tensor with near-ties flipped, however far one flip cascades (round 2's one-hop explainer could not follow
+          a chain A kept -> B suppressed -> C kept and failed on the driver's box).  One decision outside the tolerance fails;
+      (5) per-box statistics: oracle detections reproduced with IoU >= 0.99 and the same class (>= 90 %)."""
+    import nms_audit as NA
     h, w = src_hw
-    classes = [0, 1, 2, 3, 5, 7, 17, 18]
-    det, wts = make_detector(pkg, wdir, "s", 640, classes=classes, max_det=300)
+    det, wts, launches = e2e_detector(pkg, wdir, autotune)
+    classes = det.classes
     frame = np.ascontiguousarray(pkg.synth.frames(1, h, w, seed=seed)[0])
     d = det.detect(frame)
     (rx, rc, rk), im = Y.detect(frame, wts, "s", (640, 640), 0.35, 0.45, classes, 300, return_intermediate=True)
     _, heads, pred = det.debug_fetch(0, want_input=False)
+    cfg = f"weights {pkg.weights.digest(wts)}; launches: " + " | ".join(launches)
     # (1) free-running head logits
     off, box_err, cls_err = 0, [], []
     for lvl, s_ in enumerate((80, 40, 20)):
@@ -256,60 +283,35 @@ def test_end_to_end_vs_fp32_oracle(pkg, wdir, src_hw, seed):
     box_err, cls_err = np.concatenate(box_err), np.concatenate(cls_err)
     stats = dict(box_max=float(box_err.max()), box_p99=float(np.percentile(box_err, 99)), cls_max=float(cls_err.max()), cls_p99=float(np.percentile(cls_err, 99)))
     print(f"free-running head logits {src_hw}: box max {stats['box_max']:.4f} p99 {stats['box_p99']:.4f}; cls max {stats['cls_max']:.4f} p99 {stats['cls_p99']:.4f}")
-    assert stats["box_p99"] < 0.05 and stats["cls_p99"] < 0.05 and stats["box_max"] < 0.5 and stats["cls_max"] < 0.5, stats
+    assert stats["box_p99"] < 0.05 and stats["cls_p99"] < 0.05 and stats["box_max"] < 0.5 and stats["cls_max"] < 0.5, (stats, cfg)
     # (2) pre-NMS tensors agree to fp16 tolerance
     cand = im["pred"][4:].max(0) > 0.2
     extent = np.maximum(im["pred"][2, cand], im["pred"][3, cand])             # box size in pixels (P5 boxes are ~480 px wide)
-    assert np.all(np.abs(pred[:4, cand] - im["pred"][:4, cand]) <= 0.01 * extent + 0.5)      # fp16 net vs fp32 net: 1 % of the box + half a pixel
+    assert np.all(np.abs(pred[:4, cand] - im["pred"][:4, cand]) <= 0.01 * extent + 0.5), cfg      # fp16 net vs fp32 net: 1 % of the box + half a pixel
     score_drift = float(np.abs(pred[4:] - im["pred"][4:]).max())
-    assert score_drift < 0.03
+    assert score_drift < 0.008, (score_drift, cfg)
     # (3) NMS on the engine's tensor is exact
-    dets, _ = Y.non_max_suppression(pred, 0.35, 0.45, classes, False, 300)
-    assert np.array_equal(d.xyxy.view(np.int32), Y.scale_boxes(dets[:, :4], 640, 640, h, w).view(np.int32))
-    # (4) per-box reproduction
-    margin = 0.35 + 2 * score_drift + 1e-3
+    dets_e, anch_e = Y.non_max_suppression(pred, 0.35, 0.45, classes, False, 300)
+    assert np.array_equal(d.xyxy.view(np.int32), Y.scale_boxes(dets_e[:, :4], 640, 640, h, w).view(np.int32)), cfg
+    assert np.array_equal(d.confidence.view(np.int32), dets_e[:, 4].view(np.int32)) and d.class_id.tolist() == dets_e[:, 5].astype(np.int32).tolist(), cfg
+    # (4) every NMS decision, engine tensor vs oracle tensor
+    res = NA.audit(pred, im["pred"], 0.35, 0.45, classes, score_tol=0.005, iou_tol=0.008)
+    only_e, only_o = NA.survivors_diff(anch_e, im["anchors"])
+    print(f"end to end {src_hw} seed {seed}: {len(rc)} oracle / {len(d)} engine detections; survivors only in the engine {only_e}, only in the oracle {only_o}")
+    print(NA.describe(res))
+    assert len(d) < 300 and len(rc) < 300                                   # (max_det never truncates here: survivor sets are order-free)
+    assert not res["hard"], f"NMS decisions differ beyond the fp16 drift tolerance -- the engine's pre-NMS tensor is wrong:\n{NA.describe(res, 40)}\n{cfg}"
+    assert res["iou_drift"] < 0.012, (res["iou_drift"], cfg)
+    if only_e or only_o:
+        assert res["near"], f"survivors differ although no NMS decision does\n{cfg}"
+    # (5) per-box reproduction
     rows = match_report(rx, rc, rk, d, 0.35)
-    clear = [r for r in rows if r[1] > margin]
-    near = [r for r in rows if r[1] <= margin]
-    bad = [r for r in clear if r[2] < 0.99]
-    frac_all = np.mean([r[2] >= 0.99 for r in rows]) if rows else 1.0
-    print(f"end to end {src_hw}: {len(rows)} oracle detections, {len(d)} engine detections, score drift {score_drift:.4f}; "
-          f"IoU >= 0.99 + same class: {sum(r[2] >= 0.99 for r in rows)}/{len(rows)} = {frac_all:.4f}; "
-          f"within {margin - 0.35:.4f} of the threshold: {len(near)} (missed {sum(r[2] < 0.99 for r in near)}); clear of it: {len(clear)} (missed {len(bad)}) {bad[:5]}")
-    assert len(clear) >= 5
-    # Any other miss must trace back to ONE decision inside NMS whose margin is smaller than the drift between the two nets --
-    # a pair of overlapping same-class candidates whose IoU sits at the 0.45 threshold, or whose scores are closer than the
-    # score drift (their order in the descending-score walk swaps).  For a missed oracle survivor (anchor a): take the same
-    # anchor in the ENGINE's pre-NMS tensor, find the engine survivor that suppresses it there, and show that this very
-    # pair is such a near-tie in the oracle's tensor.
-    dets_e, anch_e = Y.non_max_suppression(pred, 0.35, 0.45, classes, False, 300)       # == the engine's output (asserted above), with anchors
-
-    def box_of(t, an):
-        cx, cy, bw, bh = t[:4, an]
-        return np.array([[cx - bw / 2, cy - bh / 2, cx + bw / 2, cy + bh / 2]], np.float32)
-
-    flips = []
-    for i, sc, _, _ in bad:
-        an, k = int(im["anchors"][i]), int(rk[i])
-        se = float(pred[4 + k, an])
-        assert se > 0.35, f"oracle survivor {i}: engine score {se:.4f} of the same anchor is below the threshold although the oracle's {sc:.4f} clears it by more than the drift"
-        why = None
-        for c_an in anch_e[(dets_e[:, 5] == k)]:
-            c_an = int(c_an)
-            iou_e = float(iou_1to1(box_of(pred, an), box_of(pred, c_an))[0])
-            if c_an == an or iou_e <= 0.45 or pred[4 + k, c_an] < se:
-                continue
-            iou_o = float(iou_1to1(box_of(im["pred"], an), box_of(im["pred"], c_an))[0])
-            ds = abs(float(im["pred"][4 + k, c_an]) - sc)
-            if abs(iou_o - 0.45) < 0.02 or ds <= 2 * score_drift + 1e-3 or float(im["pred"][4 + k, c_an]) <= 0.35 + 2 * score_drift:
-                why = (i, round(sc, 4), c_an, round(iou_e, 4), round(iou_o, 4), round(ds, 4))
-        assert why is not None, f"oracle survivor {i} (anchor {an}, score {sc:.4f}) is missing from the engine's output and no near-tie NMS decision explains it"
-        flips.append(why)
-    print(f"  near-tie NMS decisions (allowed): (oracle det, score, suppressing anchor, IoU engine, IoU oracle, score gap) {flips}")
-    assert len(bad) <= 0.05 * len(clear), bad
-    assert frac_all >= 0.95, frac_all
+    hit = sum(r[2] >= 0.99 for r in rows)
+    frac_all = hit / len(rows) if rows else 1.0
+    print(f"  IoU >= 0.99 + same class: {hit}/{len(rows)} = {frac_all:.4f}; score drift {score_drift:.4f}")
+    assert len(rows) >= 5
+    assert frac_all >= 0.9, (frac_all, [r for r in rows if r[2] < 0.99][:8], cfg)
     assert np.all(d.xyxy[:, [0, 2]] >= 0) and np.all(d.xyxy[:, [0, 2]] <= w) and np.all(d.xyxy[:, [1, 3]] <= h)
-    det.close()
 
 
 def test_batch_equals_single_and_graph_equals_eager(pkg, wdir, monkeypatch):
@@ -1189,4 +1191,41 @@ def test_persistent_tile_kernel(pkg, wdir, monkeypatch, tile, size, batch, up_re
             tol = 2e-3 * np.abs(taps[n]).max() + 2e-3
             err = float(np.abs(taps[n] - gpu[n]).max())
             assert err <= tol, f"tile {tile} img {img} layer {n}: max err {err:.4g} > tol {tol:.4g}"
+    det.close()
+
+
+def test_converted_checkpoint_through_the_engine(pkg, wdir, tmp_path):
+    """SURVEY 8f rank 2 on the GPU (VERDICT r02 missing 1): an Ultralytics-shaped `.pt` (fake class paths, fp16 tensors,
+    non-trivial BatchNorm statistics) -> `weights.convert_pt` (restricted unpickler, BN fold, NHWC fp16) -> RTMODTW1 -> the HIP
+    engine, checked against torch running the checkpoint's own UNFOLDED Conv + BatchNorm + SiLU graph
+    (reference: src/detection/detector.py:82-90 -- `YOLO(path)` loads the .pt and runs it as is):
+      * every stored layer of the engine vs the oracle on the converted file, teacher-forced, usual layer tolerance;
+      * free-running head logits vs the unfolded torch model: p99 < 0.05, max < 0.5 (the e2e bars);
+      * decode + NMS: every decision on the engine's tensor vs the unfolded model's tensor (nms_audit), none hard."""
+    import torch
+    import nms_audit as NA
+    from fake_ultralytics import forward_heads, make_checkpoint
+    model, rtw, _ = make_checkpoint(pkg, tmp_path, "n", 320)
+    w, scale, nc, _ = pkg.weights.load(rtw)
+    det = pkg.Detector(rtw, input_size=(320, 320), max_det=300, warmup=False)
+    assert det.model.scale == "n" and det.model.nc == 80
+    frame = pkg.synth.frames(1, 320, 320, seed=77)[0]
+    d, heads, pred, worst = layer_check(pkg, det, w, frame, "n", 320)
+    print("worst layer vs the folded oracle", worst)
+    inp, _, _ = det.debug_fetch(0, want_heads=False, want_pred=False)
+    with torch.no_grad():
+        ref = [h[0].permute(1, 2, 0).numpy() for h in forward_heads(model, torch.from_numpy(np.ascontiguousarray(inp.astype(np.float32).transpose(2, 0, 1)))[None])]
+    off, errs = 0, []
+    for lvl, s_ in enumerate((40, 20, 10)):
+        g = heads[off:off + s_ * s_ * 144].reshape(s_, s_, 144).astype(np.float32); off += s_ * s_ * 144
+        errs.append(np.abs(g - ref[lvl]).ravel())
+    errs = np.concatenate(errs)
+    print(f"free-running engine on the converted file vs the unfolded torch model: head logits max {errs.max():.4f} p99 {np.percentile(errs, 99):.4f}")
+    assert np.percentile(errs, 99) < 0.05 and errs.max() < 0.5
+    pr = Y.decode(ref)
+    res = NA.audit(pred, pr, 0.35, 0.45, None, score_tol=0.005, iou_tol=0.008)
+    print(NA.describe(res))
+    assert res["n_candidates"] > 50 and not res["hard"], NA.describe(res, 40)
+    dets, anch = Y.non_max_suppression(pr, 0.35, 0.45, None, False, 300)
+    assert len(d) > 5 and abs(len(d) - len(dets)) <= max(3, len(dets) // 10)
     det.close()

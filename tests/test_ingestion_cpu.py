@@ -69,6 +69,47 @@ def test_latest_frame_only_and_ids():
     assert ok                                     # the last frame stays readable after stop, like the reference's
 
 
+def test_leased_slots_are_never_rewritten():
+    """`read(copy=False)` hands out a page-locked ring slot that the detector may still be uploading (or reading in
+    place) while a free-running source produces newer frames.  The slot is a lease: the capture thread skips it until
+    `release(frame_id)`; a ring too short for `buffer_size` is refused; running out of leasable slots raises instead of
+    tearing a frame."""
+    frames = pkg.synth.frames(7, 48, 64, seed=11)
+    with pytest.raises(ValueError):
+        ing.FrameReader("ring", backend="synthetic", resolution=(64, 48), frames=frames, ring=HostRing(2, 48, 64))
+    with pytest.raises(ValueError):
+        ing.FrameReader("ring", backend="synthetic", resolution=(64, 48), frames=frames, ring=HostRing(4, 48, 64), buffer_size=3)
+    ring = HostRing(5, 48, 64)                     # 3 leasable slots: a detector with three batches in flight
+    with ing.FrameReader("ring", backend="synthetic", resolution=(64, 48), frames=frames, fps=2000.0, ring=ring, buffer_size=3) as r:
+        held = []
+        for _ in range(3):
+            last = held[-1][0] if held else 0
+            assert wait_for(lambda: r.read()[2] > last)
+            ok, f, fid = r.read(copy=False)
+            assert ok
+            held.append((fid, f, f.copy()))
+        assert r.leased == 3
+        assert wait_for(lambda: r.read()[2] >= held[-1][0] + 40)      # 40 newer frames went through the two remaining slots
+        for fid, view, snap in held:
+            assert np.array_equal(view, snap) and np.array_equal(view, frames[(fid - 1) % 7]), fid      # untouched while on lease
+        newest = r.read()[2]
+        assert wait_for(lambda: r.read()[2] > newest)
+        with pytest.raises(RuntimeError):
+            while True:                               # a fourth lease (of a frame in an unleased slot) must be refused
+                ok, f, fid = r.read(copy=False)
+                if fid not in [h[0] for h in held]:
+                    break
+        r.release(held[0][0])
+        r.release(held[0][0])                         # idempotent
+        assert r.leased == 2
+        ok, f, fid = r.read(copy=False)               # ... and now it is granted
+        assert ok and r.leased == 3
+        for fid_, _, _ in held[1:]:
+            r.release(fid_)
+        r.release(fid)
+        assert r.leased == 0
+
+
 def test_read_before_first_frame():
     class Never:
         opened = True

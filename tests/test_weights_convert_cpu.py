@@ -4,7 +4,6 @@ saves it with torch.save (so the pickle names classes that do NOT exist when it 
 reads it with the restricted unpickler and checks (1) every tensor, (2) that BN folding +
 layout conversion reproduce the torch model's own forward pass through the oracle."""
 import sys
-import types
 
 import numpy as np
 import torch
@@ -13,88 +12,7 @@ import torch.nn as nn
 from oracle import yolo_oracle as Y
 
 
-def build_fake_ultralytics():
-    tasks = types.ModuleType("ultralytics.nn.tasks")
-    mods = types.ModuleType("ultralytics.nn.modules")
-
-    class Conv(nn.Module):
-        def __init__(self, c1, c2, k=1, s=1):
-            super().__init__()
-            self.conv = nn.Conv2d(c1, c2, k, s, k // 2, bias=False)
-            self.bn = nn.BatchNorm2d(c2, eps=1e-3)
-            self.act = nn.SiLU()
-
-        def forward(self, x):
-            return self.act(self.bn(self.conv(x)))
-
-    class Bottleneck(nn.Module):
-        def __init__(self, c, shortcut):
-            super().__init__()
-            self.cv1, self.cv2, self.add = Conv(c, c, 3), Conv(c, c, 3), shortcut
-
-        def forward(self, x):
-            y = self.cv2(self.cv1(x))
-            return x + y if self.add else y
-
-    class C2f(nn.Module):
-        def __init__(self, c1, c2, n, shortcut):
-            super().__init__()
-            self.c = c2 // 2
-            self.cv1, self.cv2 = Conv(c1, 2 * self.c, 1), Conv((2 + n) * self.c, c2, 1)
-            self.m = nn.ModuleList(Bottleneck(self.c, shortcut) for _ in range(n))
-
-        def forward(self, x):
-            y = list(self.cv1(x).chunk(2, 1))
-            y.extend(m(y[-1]) for m in self.m)
-            return self.cv2(torch.cat(y, 1))
-
-    class SPPF(nn.Module):
-        def __init__(self, c1, c2):
-            super().__init__()
-            self.cv1, self.cv2 = Conv(c1, c1 // 2, 1), Conv(c1 * 2, c2, 1)
-            self.m = nn.MaxPool2d(5, 1, 2)
-
-        def forward(self, x):
-            y = [self.cv1(x)]
-            y.extend(self.m(y[-1]) for _ in range(3))
-            return self.cv2(torch.cat(y, 1))
-
-    class Placeholder(nn.Module):        # Upsample / Concat slots (no parameters)
-        pass
-
-    class Detect(nn.Module):
-        def __init__(self, nc, ch, c2, c3):
-            super().__init__()
-            self.cv2 = nn.ModuleList(nn.Sequential(Conv(x, c2, 3), Conv(c2, c2, 3), nn.Conv2d(c2, 64, 1)) for x in ch)
-            self.cv3 = nn.ModuleList(nn.Sequential(Conv(x, c3, 3), Conv(c3, c3, 3), nn.Conv2d(c3, nc, 1)) for x in ch)
-
-    class DetectionModel(nn.Module):
-        def __init__(self, scale, nc):
-            super().__init__()
-            arch, head = Y.arch(scale, nc)
-            layers = []
-            for m in arch:
-                if m[0] == "conv":
-                    layers.append(Conv(m[2], m[3], m[4], m[5]))
-                elif m[0] == "c2f":
-                    layers.append(C2f(m[2], m[3], m[4], m[5]))
-                elif m[0] == "sppf":
-                    layers.append(SPPF(m[2], m[3]))
-                else:
-                    layers.append(Placeholder())
-            layers.append(Detect(nc, head["ch"], head["c2"], head["c3"]))
-            self.model = nn.Sequential(*layers)
-            self.names = {i: str(i) for i in range(nc)}
-
-    for c in (Conv, Bottleneck, C2f, SPPF, Placeholder, Detect):
-        c.__module__ = "ultralytics.nn.modules"
-        c.__qualname__ = c.__name__
-        setattr(mods, c.__name__, c)
-    DetectionModel.__module__ = "ultralytics.nn.tasks"
-    DetectionModel.__qualname__ = "DetectionModel"
-    tasks.DetectionModel = DetectionModel
-    return {"ultralytics": types.ModuleType("ultralytics"), "ultralytics.nn": types.ModuleType("ultralytics.nn"),
-            "ultralytics.nn.tasks": tasks, "ultralytics.nn.modules": mods}, DetectionModel
+from fake_ultralytics import build_fake_ultralytics, make_checkpoint
 
 
 def test_convert_pt_without_ultralytics(pkg, tmp_path):
@@ -146,3 +64,27 @@ def test_read_pt_rejects_non_checkpoints(pkg, tmp_path):
     p.write_bytes(b"not a zip")
     with pytest.raises(Exception):
         pkg.weights.read_pt(str(p))
+
+
+def test_converted_checkpoint_reproduces_the_unfolded_model_end_to_end(pkg, tmp_path):
+    """`.pt` -> restricted read -> BN fold -> NHWC fp16 -> RTMODTW1, then the WHOLE net: the oracle run on the converted file
+    against torch running the checkpoint's own unfolded Conv + BatchNorm + SiLU graph -- all three Detect maps, and the
+    detections after decode + NMS decision by decision (the only differences: folded weights are rounded to fp16 once more)."""
+    import nms_audit as NA
+    from fake_ultralytics import forward_heads
+    model, rtw, _ = make_checkpoint(pkg, tmp_path)
+    w, scale, nc, _ = pkg.weights.load(rtw)
+    frame = pkg.synth.frames(1, 320, 320, seed=77)[0]
+    x = Y.preprocess(frame, 320, 320)
+    with torch.no_grad():
+        ref = [h[0].permute(1, 2, 0).numpy() for h in forward_heads(model, torch.from_numpy(np.ascontiguousarray(x.transpose(2, 0, 1)))[None])]
+    got = Y.forward(x, w, scale)
+    for lvl in range(3):
+        e = np.abs(got[lvl] - ref[lvl])
+        assert np.isfinite(ref[lvl]).all() and ref[lvl][..., :64].std() > 0.5          # a live net, not one that decayed to its biases
+        assert np.percentile(e, 99) < 0.02 and e.max() < 0.1, (lvl, float(np.percentile(e, 99)), float(e.max()))
+    po, pr = Y.decode(got), Y.decode(ref)
+    n_cand = int((pr[4:].max(0) > 0.35).sum())
+    assert 10 < n_cand < 1500, n_cand
+    res = NA.audit(po, pr, 0.35, 0.45, None, score_tol=0.001, iou_tol=0.002)
+    assert not res["hard"], NA.describe(res)
