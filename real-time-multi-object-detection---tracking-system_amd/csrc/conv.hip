@@ -522,7 +522,8 @@ __device__ __forceinline__ void conv_mfma64_body(const ConvArgs &p, const int bx
     static_assert((LA + LBp) * (DEPTH > 1 ? DEPTH - 1 : 1) <= 63, "vmcnt is a 6-bit counter");
     constexpr int TAIL_BYTES = N2T > 0 ? tail_lds_bytes<BM, BN, N2T>() : 0;
     __shared__ __attribute__((aligned(1024))) unsigned char lds[NSTAGE * STAGE > TAIL_BYTES ? NSTAGE * STAGE : TAIL_BYTES];
-    static_assert(BM * (BN * 2 + 16) <= NSTAGE * STAGE, "the epilogue's fp16 tile must fit the stage buffers");
+    constexpr bool EPI_FITS = BM * (BN * 2 + 16) <= NSTAGE * STAGE;      // the epilogue's fp16 tile goes through the drained stage buffers when it fits them
+    static_assert(EPI_FITS || N2T == 0, "a fused tail needs the tile in LDS");
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -610,9 +611,11 @@ __device__ __forceinline__ void conv_mfma64_body(const ConvArgs &p, const int bx
         epilogue_tail<BM, BN, TM, TN, N2T>(p, acc, bv, lds, wm, wn, [&](int pm, long &o) { return tail_pixel_offset(p, m0 + pm, o); });
         return;
     }
-    if (p.epi16) {
-        epilogue_lds<BM, BN, TM, TN, NW * 64>(p, n0, acc, bv, lds, wm, wn, [&](int pm, long &o, long &rp, long &o2) { return pixel_offsets(p, m0 + pm, o, rp, o2); });
-        return;
+    if constexpr (EPI_FITS) {
+        if (p.epi16) {
+            epilogue_lds<BM, BN, TM, TN, NW * 64>(p, n0, acc, bv, lds, wm, wn, [&](int pm, long &o, long &rp, long &o2) { return pixel_offsets(p, m0 + pm, o, rp, o2); });
+            return;
+        }
     }
 #pragma unroll
     for (int t = 0; t < TM; ++t) {
@@ -1294,22 +1297,24 @@ const char *tile_name(int tile) {
                                             "tail:128x64", "tail:64x64", "tail:k64:128x128", "tail:k64:64x128",
                                             "k64:128x128s2/8w", "k64:128x128s3/8w", "k64:256x128s2/8w", "k64:128x64s3/8w", "k64:256x64s2/8w",
                                             "rows:128x64/8w", "rows:256x64/8w", "rows64:128x128/8w", "rows64:256x64/8w",
-                                            "ws:128x128", "ws:128x64", "pt:128x128s2", "pt:128x128s3", "pt:128x64s3", "pt:128x64s2"};
+                                            "ws:128x128", "ws:128x64", "pt:128x128s2", "pt:128x128s3", "pt:128x64s3", "pt:128x64s2",
+                                            "k64:256x128s3/8w", "k64:256x256s2/8w"};
     return tile >= 0 && tile < TILE_COUNT ? names[tile] : "?";
 }
 
 bool tile_needs_cin64(int tile) {
     return (tile >= TILE_K64_128x128_S2 && tile <= TILE_K64_128x128_S2W) || (tile >= TILE_ROWS_K64_128x64 && tile <= TILE_ROWS_K64_256x64) ||
            tile == TILE_TAIL_K64_128x128 || tile == TILE_TAIL_K64_64x128 || (tile >= TILE_K64_128x128_S2_W8 && tile <= TILE_K64_256x64_S2_W8) ||
-           tile == TILE_ROWS_K64_128x128_W8 || tile == TILE_ROWS_K64_256x64_W8 || tile_is_ws(tile) || tile_is_pt(tile);
+           tile == TILE_ROWS_K64_128x128_W8 || tile == TILE_ROWS_K64_256x64_W8 || tile_is_ws(tile) || tile_is_pt(tile) || tile_is_w8(tile);
 }
+bool tile_is_w8(int tile) { return (tile >= TILE_K64_128x128_S2_W8 && tile <= TILE_K64_256x64_S2_W8) || tile == TILE_K64_256x128_S3_W8 || tile == TILE_K64_256x256_S2_W8; }
 bool tile_is_ws(int tile) { return tile == TILE_WS_128x128 || tile == TILE_WS_128x64; }
 bool tile_is_pt(int tile) { return tile >= TILE_PT_128x128_S2 && tile <= TILE_PT_128x64_S2; }
 // resident weight slice (kp/64 x BN/8 KiB) + the pixel ring (3 x 16 KiB) within 156 KiB of LDS
 bool tile_ws_fits(int tile, int kp) { return tile_is_ws(tile) && (kp / 64) * (tile_shape(tile).bn / 8) + 3 * 16 <= 156; }
 bool tile_is_tail(int tile) { return tile >= TILE_TAIL_128x64 && tile <= TILE_TAIL_K64_64x128; }
 // the 64-deep tile kernels (conv_mfma64_body) know how to read channels [0, lo_c) from a half-resolution tensor
-bool tile_reads_lo(int tile) { return (tile >= TILE_K64_128x128_S2 && tile <= TILE_K64_128x128_S2W) || (tile >= TILE_K64_128x128_S2_W8 && tile <= TILE_K64_256x64_S2_W8) || tile_is_pt(tile); }
+bool tile_reads_lo(int tile) { return (tile >= TILE_K64_128x128_S2 && tile <= TILE_K64_128x128_S2W) || tile_is_w8(tile) || tile_is_pt(tile); }
 bool tile_is_rows(int tile) { return (tile >= TILE_ROWS_128x64 && tile <= TILE_ROWS_K64_256x64) || (tile >= TILE_ROWS_128x64_W8 && tile <= TILE_ROWS_K64_256x64_W8); }
 
 TileShape tile_shape(int tile) {
@@ -1354,6 +1359,8 @@ TileShape tile_shape(int tile) {
         case TILE_WS_128x64: return {128, 64};
         case TILE_PT_128x128_S2: case TILE_PT_128x128_S3: return {128, 128};
         case TILE_PT_128x64_S3: case TILE_PT_128x64_S2: return {128, 64};
+        case TILE_K64_256x128_S3_W8: return {256, 128};
+        case TILE_K64_256x256_S2_W8: return {256, 256};
     }
     return {0, 0};
 }
@@ -1566,6 +1573,8 @@ int launch_conv_group(const ConvLaunch *c, int n, int tile, hipStream_t s) {
     }
     for (int i = 0; i < n; ++i)
         RT_CHECK(!c[i].in_lo.base || tile_reads_lo(tile), RTMODT_E_INVALID, "launch_conv: tile %s cannot read a half-resolution source", tile_name(tile));
+    for (int i = 0; i < n; ++i)                            // weight rows and bias entries exist up to cout rounded up to 128
+        RT_CHECK(tile_shape(tile).bn <= 128 || c[i].cout % tile_shape(tile).bn == 0, RTMODT_E_INVALID, "launch_conv: tile %s needs cout %% %d == 0 (cout %d)", tile_name(tile), tile_shape(tile).bn, c[i].cout);
     if (tile_is_rows(tile)) {
         const int bk = tile_needs_cin64(tile) ? 64 : 32;
         for (int i = 0; i < n; ++i) {
@@ -1629,6 +1638,8 @@ int launch_conv_group(const ConvLaunch *c, int n, int tile, hipStream_t s) {
         case TILE_K64_256x128_S2_W8: RT_TRY((launch_k64_w8<256, 128, 4, 2, 2>(l, s))); break;
         case TILE_K64_128x64_S3_W8: RT_TRY((launch_k64_w8<128, 64, 4, 2, 3>(l, s))); break;
         case TILE_K64_256x64_S2_W8: RT_TRY((launch_k64_w8<256, 64, 8, 1, 2>(l, s))); break;
+        case TILE_K64_256x128_S3_W8: RT_TRY((launch_k64_w8<256, 128, 4, 2, 3>(l, s))); break;
+        case TILE_K64_256x256_S2_W8: RT_TRY((launch_k64_w8<256, 256, 4, 2, 2>(l, s))); break;
         case TILE_WS_128x128: RT_TRY(launch_ws<128>(l, s)); break;
         case TILE_WS_128x64: RT_TRY(launch_ws<64>(l, s)); break;
         case TILE_PT_128x128_S2: RT_TRY((launch_pt<128, 2>(l, s))); break;

@@ -413,7 +413,8 @@ static int make_conv(rtmodt_detector *d, WeightFile &wf, const std::vector<std::
         const int t = atoi(e);
         if (t >= 0 && t < TILE_COUNT && tile_needs_cin64(t) && !tile_is_rows(t) && !tile_is_tail(t) && c.cin % 64 == 0 && kp % 64 == 0 && !dst &&
             (!tile_is_ws(t) || (c.ks == 1 && c.stride == 1 && tile_ws_fits(t, kp) && ((long)d->B * out.H * out.W) % 128 == 0 && cout_eff % tile_shape(t).bn == 0 && !res && out.coff % 8 == 0 && out.C % 8 == 0)) &&
-            (!tile_is_pt(t) || (((long)d->B * out.H * out.W) % 128 == 0 && cout_eff % tile_shape(t).bn == 0 && out.coff % 8 == 0 && out.C % 8 == 0))) c.tile = t;
+            (!tile_is_pt(t) || (((long)d->B * out.H * out.W) % 128 == 0 && cout_eff % tile_shape(t).bn == 0 && out.coff % 8 == 0 && out.C % 8 == 0)) &&
+            (tile_shape(t).bn <= 128 || cout_eff % tile_shape(t).bn == 0)) c.tile = t;
     }
     if (const char *e = getenv("RTMODT_TILE_3X3S1")) {          // test hook: force a tap-reuse tile wherever it is legal
         int t = atoi(e);
@@ -886,7 +887,9 @@ static bool tile_legal(const ConvLaunch *c, int n, int t) {
     if (tile_needs_cin64(t) && !cin64) return false;
     if (tile_is_rows(t) && !rows_ok) return false;
     if (c[0].in_lo.base && !tile_reads_lo(t)) return false;
-    if (t >= TILE_K64_128x128_S2_W8 && t <= TILE_K64_256x64_S2_W8 && n != 1) return false;   // the 8-wave tiles have no group entry point
+    if (tile_is_w8(t) && n != 1) return false;   // the 8-wave tiles have no group entry point
+    for (int i = 0; i < n; ++i)                   // weights and bias are padded to 128 rows of cout: a wider tile must divide cout
+        if (tile_shape(t).bn > 128 && c[i].cout % tile_shape(t).bn != 0) return false;
     if (tile_is_pt(t) && (n != 1 || c[0].out2.base || ((long)c[0].B * c[0].out.H * c[0].out.W) % 128 != 0 ||
                           c[0].cout % tile_shape(t).bn != 0 || c[0].out.coff % 8 != 0 || c[0].out.C % 8 != 0)) return false;
     if (tile_is_ws(t) && (n != 1 || c[0].ks != 1 || c[0].stride != 1 || c[0].in_lo.base || c[0].res.base || c[0].out2.base || !tile_ws_fits(t, c[0].kp) ||
@@ -911,7 +914,7 @@ static int tile_lds_kib(int t) {
         case TILE_128x64_S5: case TILE_64x128_S5: stages = 5; break;
         case TILE_64x64_S6: case TILE_128x128_S6: stages = 6; break;
         case TILE_K64_128x128_S2: case TILE_K64_256x64_S2: case TILE_K64_256x128_S2: case TILE_K64_128x128_S2W: case TILE_K64_128x128_S2_W8:
-        case TILE_K64_256x128_S2_W8: case TILE_K64_256x64_S2_W8: stages = 2; break;
+        case TILE_K64_256x128_S2_W8: case TILE_K64_256x64_S2_W8: case TILE_K64_256x256_S2_W8: stages = 2; break;
         case TILE_K64_64x64_S4: stages = 4; break;
         default: break;
     }

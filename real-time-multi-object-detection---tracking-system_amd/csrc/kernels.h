@@ -52,13 +52,17 @@ enum ConvTile {
     TILE_ROWS_128x64_W8 = 38, TILE_ROWS_256x64_W8 = 39, TILE_ROWS_K64_128x128_W8 = 40, TILE_ROWS_K64_256x64_W8 = 41,   // tap-reuse kernel, 8 waves
     TILE_WS_128x128 = 42, TILE_WS_128x64 = 43,      // 1x1 convs, WEIGHT-STATIONARY: a persistent workgroup keeps its cout slice of the weights in LDS and streams pixel tiles
     TILE_PT_128x128_S2 = 44, TILE_PT_128x128_S3 = 45, TILE_PT_128x64_S3 = 46, TILE_PT_128x64_S2 = 47,   // PERSISTENT 64-deep tile kernel: a workgroup walks over pixel tiles, the ring keeps prefetching across tile boundaries
-    TILE_COUNT = 48
+    // BIG tiles, one workgroup per CU: fewer operand bytes per FLOP through the L2 -> LDS path (256x128: -25 %, 256x256: -50 % vs 128x128)
+    // AND more of them in flight (three 48-KiB stages / two 64-KiB stages of the 160 KiB); 8 waves, 64x64 / 64x128 outputs per wave
+    TILE_K64_256x128_S3_W8 = 48, TILE_K64_256x256_S2_W8 = 49,
+    TILE_COUNT = 50
 };
 const char *tile_name(int tile);
 bool tile_needs_cin64(int tile);
 bool tile_is_rows(int tile);      // 3x3 stride-1 only, bordered input
 bool tile_is_tail(int tile);      // runs ConvLaunch::tail_* as well; needs cout == the tile's BN
 bool tile_reads_lo(int tile);     // can serve ConvLaunch::in_lo
+bool tile_is_w8(int tile);        // 8-wave 64-deep tile kernel (conv_mfma64_w8): one conv per launch
 bool tile_is_pt(int tile);        // persistent 64-deep tile kernel: one conv per launch, cin % 64 == 0, full tiles, no second destination
 bool tile_is_ws(int tile);        // weight-stationary 1x1 kernel: ks == 1, stride 1, cin % 64 == 0, one problem per launch, weights slice + ring <= 156 KiB of LDS
 bool tile_ws_fits(int tile, int kp);

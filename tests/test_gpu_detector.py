@@ -722,7 +722,7 @@ def test_head_final_equals_separate_launches(pkg, wdir, monkeypatch, scale, size
         assert np.array_equal(res["off"][1][i][2].view(np.int32), res["on"][1][i][2].view(np.int32))         # pred
 
 
-@pytest.mark.parametrize("tile", [33, 34, 35, 36, 37])
+@pytest.mark.parametrize("tile", [33, 34, 35, 36, 37, 48, 49])      # 48, 49: the one-workgroup-per-CU big tiles (144 / 128 KiB of LDS)
 def test_eight_wave_tiles(pkg, wdir, monkeypatch, tile):
     """The 64-deep tile kernel with EIGHT waves per workgroup (the global->LDS path sustains ~5 B/clk per wave, so the
     big tiles issue their operands from twice as many waves): forced onto every single-launch conv with cin % 64 == 0,
