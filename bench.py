@@ -373,8 +373,9 @@ def main():
                 det.enqueue([fr for f in range(F) for fr in host_ring[(t * F + f) % R]])
             else:
                 det.enqueue([pt for f in range(F) for pt in ptrs[(t * F + f) % R]], height=size, width=size)
-            for f in range(F):                          # frame f of every stream, then frame f + 1: tracker.py:58-141 order
-                trk.update_from_detector(det, f * S, S)
+            # ONE tracker launch per step: stream s's workgroup walks over its F frames (slots f * S + s) in order -- tracker.py:58-141
+            # still sees every stream one frame at a time (tests: == F per-frame launches == the oracle)
+            trk.update_from_detector(det, 0, S, frames_per_stream=F)
 
         def step(t):
             """Steady state of the pipeline: submit batch t, then collect the oldest batch in flight (whose

@@ -171,6 +171,10 @@ int rtmodt_tracker_update_from_detector(rtmodt_tracker *trk, rtmodt_detector *de
  * a batch that holds several CONSECUTIVE frames of every stream (frame-major: image f * n_streams + s) is
  * tracked by calling this once per f, in order -- tracker.py:58-141 still sees each stream's frames one at a time. */
 int rtmodt_tracker_update_from_detector_frames(rtmodt_tracker *trk, rtmodt_detector *det, int first_frame, int n_frames);
+/* A frame-major batch (image f * n_streams + s, starting at first_frame) of n_frames consecutive frames of n_streams streams
+ * in ONE launch: stream s's workgroup walks over its n_frames detection slots in order, so every stream still sees
+ * tracker.py:58-141 one frame at a time; state after the call == n_frames calls of _update_from_detector_frames. */
+int rtmodt_tracker_update_from_detector_batch(rtmodt_tracker *trk, rtmodt_detector *det, int first_frame, int n_streams, int n_frames);
 /* List-order snapshot of a stream's state = the reference's _core._tracks + _core._next_id
  * (the parity surface).  Arrays sized max_tracks; any may be NULL. */
 int rtmodt_tracker_state(rtmodt_tracker *trk, int stream, int64_t *ids, float *xyxy, float *conf,

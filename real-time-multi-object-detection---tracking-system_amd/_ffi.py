@@ -95,6 +95,7 @@ def lib() -> C.CDLL:
         "rtmodt_tracker_update_batch": (C.c_int, [vp, vp, vp, vp, vp, vp]),
         "rtmodt_tracker_update_from_detector": (C.c_int, [vp, vp]),
         "rtmodt_tracker_update_from_detector_frames": (C.c_int, [vp, vp, C.c_int, C.c_int]),
+        "rtmodt_tracker_update_from_detector_batch": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int]),
         "rtmodt_tracker_state": (C.c_int, [vp, C.c_int, vp, vp, vp, vp, vp, vp, C.POINTER(i32), C.POINTER(i64)]),
         "rtmodt_tracker_reset": (C.c_int, [vp, C.c_int]),
         "rtmodt_tracker_enable_kalman": (C.c_int, [vp]),

@@ -217,6 +217,8 @@ struct TrackerArgs {
     int64_t *meta;             // device [n_streams][8]: {cur, n_tracks, err, n_active, next_id, 0, 0, 0}
     // detections: [n_streams][det_stride] boxes / conf / cls ; counts [n_streams]
     const float4 *det_box; const float *det_conf; const int32_t *det_cls; const int32_t *det_n; int det_stride;
+    // frames per launch: stream s consumes the detection slots s, s + frame_step, ..., in order, inside its workgroup
+    int n_frames = 1, frame_step = 0;
 };
 int launch_tracker_update(const TrackerArgs &a, hipStream_t s);
 int launch_iou_matrix(const float4 *a, int m, const float4 *b, int n, float *out, hipStream_t s);

@@ -388,9 +388,9 @@ __device__ __forceinline__ void assoc_lap(F val, int n_rows, int n_cols, double 
     __syncthreads();
 }
 
-__global__ __launch_bounds__(TRK_THREADS) void tracker_update(TrackerArgs a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int sidx = a.stream_base + blockIdx.x;
+// one frame of one stream (tracker.py:58-141); `didx` = which detection slot feeds it.  Every thread of the workgroup
+// returns together (all exits are on workgroup-uniform conditions).
+__device__ __forceinline__ void tracker_step(const TrackerArgs &a, const int sidx, const int didx, unsigned char *smem) {
     const int Mc = a.max_tracks, Nc = a.max_dets;
     // LDS carve
     float4 *tbox = (float4 *)smem;
@@ -427,7 +427,7 @@ __global__ __launch_bounds__(TRK_THREADS) void tracker_update(TrackerArgs a) {
     int32_t *c_tsu = cur ? st.tsu[1] : st.tsu[0];   int32_t *n_tsu = cur ? st.tsu[0] : st.tsu[1];
     float4 *c_kf = cur ? st.kf[1] : st.kf[0];       float4 *n_kf = cur ? st.kf[0] : st.kf[1];
     const bool kalman = a.kalman && c_kf != nullptr;
-    int n = a.det_n[sidx];                                // detections are indexed by absolute stream too
+    int n = a.det_n[didx];                                // detections are indexed by absolute stream too (+ the frame's slot offset)
     if (n > Nc) n = Nc;                                   // host rejects this; belt and braces
     const int tid = threadIdx.x;
 
@@ -445,9 +445,9 @@ __global__ __launch_bounds__(TRK_THREADS) void tracker_update(TrackerArgs a) {
         return;
     }
 
-    const float4 *gb = a.det_box + (size_t)sidx * a.det_stride;
-    const float *gc = a.det_conf + (size_t)sidx * a.det_stride;
-    const int32_t *gk = a.det_cls + (size_t)sidx * a.det_stride;
+    const float4 *gb = a.det_box + (size_t)didx * a.det_stride;
+    const float *gc = a.det_conf + (size_t)didx * a.det_stride;
+    const int32_t *gk = a.det_cls + (size_t)didx * a.det_stride;
     for (int i = tid; i < n; i += TRK_THREADS) { dbox[i] = gb[i]; dconf[i] = gc[i]; dcls[i] = gk[i]; }
     if (!kalman) for (int i = tid; i < M; i += TRK_THREADS) tbox[i] = c_box[i];
     __syncthreads();
@@ -584,6 +584,19 @@ __global__ __launch_bounds__(TRK_THREADS) void tracker_update(TrackerArgs a) {
         else if (lap_err) meta[2] = lap_err;
         meta[3] = active;
         meta[4] = next_id + nsp;
+    }
+}
+
+// One workgroup per stream.  A detector batch that holds n_frames CONSECUTIVE frames of every stream (slot f * frame_step + s)
+// is consumed in ONE launch: the workgroup walks its stream's frames in order -- tracker.py:58-141 still sees them one at a
+// time -- with a workgroup barrier (and its workgroup-scope fence) between frames: the state and meta words frame f wrote
+// are what frame f + 1 reads.  n_frames == 1 is the ordinary per-frame update.
+__global__ __launch_bounds__(TRK_THREADS) void tracker_update(TrackerArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int sidx = a.stream_base + blockIdx.x;
+    for (int f = 0; f < a.n_frames; ++f) {
+        tracker_step(a, sidx, sidx + f * a.frame_step, smem);
+        __syncthreads();
     }
 }
 

@@ -201,14 +201,15 @@ int rtmodt_tracker_update_batch(rtmodt_tracker *t, const float *xyxy, const floa
     return finish(t, 0, t->S, n_active_out);
 }
 
-static int update_from_detector_slice(rtmodt_tracker *t, rtmodt_detector *det, int first, int count) {
+static int update_from_detector_slice(rtmodt_tracker *t, rtmodt_detector *det, int first, int count, int frames = 1) {
     RT_CHECK(t && det, RTMODT_E_INVALID, "null argument");
     DetOutputs o;
     RT_TRY(detector_outputs(det, &o));
     if (count < 0) count = o.count - first;
     RT_CHECK(o.device == t->device, RTMODT_E_INVALID, "tracker on device %d, detector on device %d", t->device, o.device);
-    RT_CHECK(first >= 0 && count >= 1 && first + count <= o.count, RTMODT_E_INVALID, "frames [%d, %d) outside the detector's batch of %d", first,
-             first + count, o.count);
+    RT_CHECK(frames >= 1, RTMODT_E_INVALID, "n_frames %d", frames);
+    RT_CHECK(first >= 0 && count >= 1 && (long)first + (long)count * frames <= o.count, RTMODT_E_INVALID, "frames [%d, %ld) outside the detector's batch of %d", first,
+             (long)first + (long)count * frames, o.count);
     RT_CHECK(count <= t->S, RTMODT_E_INVALID, "%d frames > tracker streams %d", count, t->S);
     RT_CHECK(o.stride <= t->Nc, RTMODT_E_CAPACITY, "detector max_det %d > tracker max_dets %d", o.stride, t->Nc);
     RT_HIP(hipSetDevice(t->device));
@@ -216,6 +217,7 @@ static int update_from_detector_slice(rtmodt_tracker *t, rtmodt_detector *det, i
     a.n_streams = count;
     a.det_box = o.box + (size_t)first * o.stride; a.det_conf = o.conf + (size_t)first * o.stride; a.det_cls = o.cls + (size_t)first * o.stride;
     a.det_n = o.n + first; a.det_stride = o.stride;
+    a.n_frames = frames; a.frame_step = count;
     // (host-fed updates are synchronous -- finish() waits for them -- so the detector's stream needs no event from ours)
     RT_TRY(launch_tracker_update(a, o.stream));          // same HIP stream as the detector's NMS: ordered, no host sync
     RT_HIP(hipEventRecord(t->foreign_done, o.stream));
@@ -228,6 +230,11 @@ int rtmodt_tracker_update_from_detector(rtmodt_tracker *t, rtmodt_detector *det)
 int rtmodt_tracker_update_from_detector_frames(rtmodt_tracker *t, rtmodt_detector *det, int first_frame, int n_frames) {
     RT_CHECK(n_frames >= 1, RTMODT_E_INVALID, "n_frames %d", n_frames);
     return update_from_detector_slice(t, det, first_frame, n_frames);
+}
+
+int rtmodt_tracker_update_from_detector_batch(rtmodt_tracker *t, rtmodt_detector *det, int first_frame, int n_streams, int n_frames) {
+    RT_CHECK(n_streams >= 1 && n_frames >= 1, RTMODT_E_INVALID, "n_streams %d, n_frames %d", n_streams, n_frames);
+    return update_from_detector_slice(t, det, first_frame, n_streams, n_frames);
 }
 
 int rtmodt_tracker_state(rtmodt_tracker *t, int stream, int64_t *ids, float *xyxy, float *conf, int32_t *cls, int32_t *age,

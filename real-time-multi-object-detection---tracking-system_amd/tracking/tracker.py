@@ -86,10 +86,15 @@ class _ByteTrackCore:
                                                           _ffi.ptr(counts), _ffi.ptr(act)))
         return act
 
-    def update_from_detector(self, detector, first_frame: int = 0, n_frames: int = -1) -> None:
+    def update_from_detector(self, detector, first_frame: int = 0, n_frames: int = -1, frames_per_stream: int = 1) -> None:
         """Consume the detector's device-resident detections (stream i <- frame first_frame + i), no host hop.
-        A batch with F consecutive frames per stream (image f * n_streams + s) takes F calls, f ascending."""
-        if first_frame == 0 and n_frames < 0:
+        A batch with F consecutive frames per stream (image f * n_streams + s) takes F calls, f ascending -- or ONE call
+        with ``frames_per_stream=F`` (``n_frames`` = streams): each stream's workgroup then walks over its F frames in order
+        inside a single launch."""
+        if frames_per_stream > 1:
+            _ffi.check(_ffi.lib().rtmodt_tracker_update_from_detector_batch(self._h, detector.model.handle, int(first_frame),
+                                                                            int(self.n_streams if n_frames < 0 else n_frames), int(frames_per_stream)))
+        elif first_frame == 0 and n_frames < 0:
             _ffi.check(_ffi.lib().rtmodt_tracker_update_from_detector(self._h, detector.model.handle))
         else:
             _ffi.check(_ffi.lib().rtmodt_tracker_update_from_detector_frames(self._h, detector.model.handle, int(first_frame),

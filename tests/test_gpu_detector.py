@@ -612,11 +612,13 @@ def test_frame_batching_keeps_tracker_order(pkg, wdir, monkeypatch, F):
     big, _ = make_detector(pkg, wdir, "s", 320, batch=S * F, autotune=False, confidence=0.2)
     one, _ = make_detector(pkg, wdir, "s", 320, batch=S, autotune=False, confidence=0.2)
     core_b, core_1 = core_cls(n_streams=S, max_dets=128, max_tracks=512), core_cls(n_streams=S, max_dets=128, max_tracks=512)
+    core_x = core_cls(n_streams=S, max_dets=128, max_tracks=512)      # the same batch in ONE tracker launch (what bench.py issues)
     oracles = [T.TrackerOracle() for _ in range(S)]
     for t in range(steps):
         big.enqueue([buf.ptr + ((t * F + f) * S + s) * per for f in range(F) for s in range(S)], height=320, width=320)
         for f in range(F):
             core_b.update_from_detector(big, f * S, S)
+        core_x.update_from_detector(big, 0, S, frames_per_stream=F)
         got = big.fetch()
         assert len(got) == S * F
         for f in range(F):
@@ -630,9 +632,12 @@ def test_frame_batching_keeps_tracker_order(pkg, wdir, monkeypatch, F):
         for s in range(S):
             assert np.array_equal(T.state_digest(core_b.snapshot(s)), T.state_digest(core_1.snapshot(s))), (t, s)
             assert np.array_equal(T.state_digest(core_b.snapshot(s)), T.state_digest(oracles[s].snapshot())), (t, s)
+            assert np.array_equal(T.state_digest(core_x.snapshot(s)), T.state_digest(oracles[s].snapshot())), ("one launch", t, s)
     assert sum(len(core_b.snapshot(s)["ids"]) for s in range(S)) > 0
     with pytest.raises(pkg._ffi.RtmodtError):
         core_b.update_from_detector(big, S * F - 1, S)          # slice runs past the batch
+    with pytest.raises(pkg._ffi.RtmodtError):
+        core_x.update_from_detector(big, S, S, frames_per_stream=F)      # F frames from slot S on: past the batch
     buf.free(); big.close(); one.close()
 
 
@@ -956,8 +961,7 @@ def test_benchmarked_shape_parity(pkg, wdir):
 
     def submit(t):
         det.enqueue([buf.ptr + ((t * F + f) * S + s) * per for f in range(F) for s in range(S)], height=size, width=size)
-        for f in range(F):
-            core.update_from_detector(det, f * S, S)
+        core.update_from_detector(det, 0, S, frames_per_stream=F)          # one launch, the F frames of a stream in order inside its workgroup
 
     for t in range(steps):
         submit(t)
