@@ -61,6 +61,7 @@ struct ConvArgs {
     // tail's output is stored (the tile kernels with BN == cout, TAIL instantiations)
     const f16 *t_wt; const float *t_bias; f16 *t_out;
     int t_cout, t_kp, t_act, t_out_Hp, t_out_Wp, t_out_cs, t_out_pad;
+    int t_gap;                           // pair form: elements between the end of channel 63 and channel 64 of a tail output row (0 otherwise)
     int epi16;                           // epilogue through LDS with 16-byte NHWC stores (all channel offsets / strides % 8 == 0):
                                          // 1 = tile kernels, 2 = also the tap-reuse kernel
     int wthru;                           // output stores are WRITE-THROUGH (sc1): the tile leaves the XCD's L2 while the kernel still runs,
@@ -341,7 +342,7 @@ __device__ __forceinline__ void epilogue_tail(const ConvArgs &p, const floatx4 (
         if (n >= p.t_cout) continue;
         long opix;
         if (!pix(pm, opix)) continue;
-        store16(p.t_out, opix + n, *(const half8 *)(lds + pm * ROWB2 + k8 * 16), p.wthru);
+        store16(p.t_out, opix + n + (n >> 6) * p.t_gap, *(const half8 *)(lds + pm * ROWB2 + k8 * 16), p.wthru);
     }
 }
 
@@ -1513,11 +1514,11 @@ static int make_args(const ConvLaunch &c, ConvArgs &a) {
     a.bias = c.bias;
     a.out = c.out.base + c.out.coff;
     a.res = c.res.base ? c.res.base + c.res.coff : nullptr;
-    a.in_Hp = c.in.H + 2 * c.in.pad; a.in_Wp = c.in.W + 2 * c.in.pad; a.in_cs = c.in.C; a.in_org = c.in.pad - c.ks / 2;
+    a.in_Hp = c.in.H + 2 * c.in.pad; a.in_Wp = c.in.padded_w(); a.in_cs = c.in.C; a.in_org = c.in.pad - c.ks / 2;
     a.Ho = (c.in.H + 2 * (c.ks / 2) - c.ks) / c.stride + 1;
     a.Wo = (c.in.W + 2 * (c.ks / 2) - c.ks) / c.stride + 1;
     RT_CHECK(a.Ho == c.out.H && a.Wo == c.out.W, RTMODT_E_INVALID, "launch_conv: output %dx%d != %dx%d", c.out.H, c.out.W, a.Ho, a.Wo);
-    a.out_Hp = c.out.H + 2 * c.out.pad; a.out_Wp = c.out.W + 2 * c.out.pad; a.out_cs = c.out.C; a.out_pad = c.out.pad;
+    a.out_Hp = c.out.H + 2 * c.out.pad; a.out_Wp = c.out.padded_w(); a.out_cs = c.out.C; a.out_pad = c.out.pad;
     a.res_Hp = c.res.H + 2 * c.res.pad; a.res_Wp = c.res.W + 2 * c.res.pad; a.res_cs = c.res.C; a.res_pad = c.res.pad;
     if (a.res) {
         RT_CHECK(c.res.H == c.out.H && c.res.W == c.out.W && c.res.c == c.cout && c.res.coff % 4 == 0 && c.res.C % 4 == 0,
@@ -1548,7 +1549,10 @@ static int make_args(const ConvLaunch &c, ConvArgs &a) {
     a.kp = c.kp;
     a.t_wt = c.tail_wt; a.t_bias = c.tail_bias; a.t_out = c.tail_wt ? c.tail_out.base + c.tail_out.coff : nullptr;
     a.t_cout = c.tail_cout; a.t_kp = c.tail_kp; a.t_act = c.tail_act;
-    a.t_out_Hp = c.tail_out.H + 2 * c.tail_out.pad; a.t_out_Wp = c.tail_out.W + 2 * c.tail_out.pad; a.t_out_cs = c.tail_out.C; a.t_out_pad = c.tail_out.pad;
+    a.t_out_Hp = c.tail_out.H + 2 * c.tail_out.pad; a.t_out_Wp = c.tail_out.padded_w(); a.t_out_cs = c.tail_out.C; a.t_out_pad = c.tail_out.pad;
+    a.t_gap = c.tail_gap;
+    RT_CHECK(c.tail_gap == 0 || (c.tail_wt && c.tail_cout == 128 && c.tail_gap % 8 == 0), RTMODT_E_INVALID, "launch_conv: tail_gap needs a 128-wide tail");
+    RT_CHECK(!c.in.wp || (!c.res.base && !c.out2.base && !c.in_lo.base), RTMODT_E_INVALID, "launch_conv: a pixel-pair view takes no residual / second destination / half-resolution source");
     static const int wt_env = getenv("RTMODT_WT") ? atoi(getenv("RTMODT_WT")) : 0;
     a.wthru = wt_env;
     a.epi16 = c.out.coff % 8 == 0 && c.out.C % 8 == 0 && (!c.out2.base || (c.out2.coff % 8 == 0 && c.out2.C % 8 == 0)) &&

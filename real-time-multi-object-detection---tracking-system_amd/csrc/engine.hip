@@ -312,7 +312,7 @@ static int upload(rtmodt_detector *d, const void *src, size_t bytes, void **out)
 static Op sub_batch(const Op &op, int b0, int nb) {
     Op o = op;
     auto shift = [&](TensorView &v) {
-        if (v.c) v.base += (size_t)b0 * (v.H + 2 * v.pad) * (v.W + 2 * v.pad) * v.C;
+        if (v.c) v.base += (size_t)b0 * (v.H + 2 * v.pad) * v.padded_w() * v.C;
     };
     o.B = nb;
     if (o.kind == OP_CONV) { shift(o.conv.in); shift(o.conv.out); shift(o.conv.res); shift(o.conv.out2); shift(o.conv.tail_out); shift(o.conv.in_lo); o.conv.B = nb; }
@@ -603,6 +603,77 @@ static int build_graph(rtmodt_detector *d, WeightFile &wf) {
                 b.skip = a.tail_on;
             }
         }
+    // Layer "1" in PIXEL-PAIR form, OPT-IN (RTMODT_L1_PAIR=1).  YOLOv8s' layer 1 is a 3x3 / s2 conv, 32 -> 64 channels on
+    // the 320 x 320 stem output: K = 288 in 32-deep steps, the most byte-heavy GEMM of the net (23 KB through the global -> LDS path per
+    // MFLOP against 15.6 for a 128 x 128 x 64 tile).  Two horizontally adjacent OUTPUT pixels share three of their five input columns,
+    // and two adjacent INPUT pixels are 128 contiguous bytes in NHWC: seen as [B][322][161 pairs][64], the stem's tensor makes the same
+    // arithmetic an ordinary 3x3 / s2 conv with cin = 64 (a pixel pair), cout = 128 (two output pixels x 64 channels), K = 576 -- half
+    // the GEMM rows, every DMA piece a whole 128-byte line, and the 64-deep tile kernels (persistent tiles included) become legal.
+    // Output pair j of a row = padded columns 2j + 1, 2j + 2 of the NHWC output = one contiguous 128-channel "pixel" of the view based
+    // one pixel earlier.  The weight of (sub-pixel s, co) at tap (kh, pair pw, half t, ci) is w[co][kh][2 pw + t - 2 s][ci] where that
+    // kw exists and zero elsewhere.  The non-zero terms of every output meet in the same order and the same 32-wide groups as in the
+    // plain form: bit-identical results (test_layer1_pixel_pair_form).  The 1x1 tail (2.cv1) runs on the pair rows with a
+    // block-diagonal weight matrix.
+    // MEASURED (32 frames, profiles/r03): the pair conv alone 88 us on pt:128x128s2 against 102 us for the plain form's best tile --
+    // but its matrix work is doubled (4 of 9 pair-taps are half empty), and with 2.cv1 as its tail (only the 4-wave tail kernels
+    // exist) it takes 133 us against 111 us for the plain form with its tail: off by default.
+        const bool pair_off = !(getenv("RTMODT_L1_PAIR") && atoi(getenv("RTMODT_L1_PAIR")) != 0) || (getenv("RTMODT_STEM_L1") && atoi(getenv("RTMODT_STEM_L1")) != 0);
+        for (size_t i = 1; i < d->ops.size() && !pair_off; ++i) {
+            Op &o = d->ops[i];
+            ConvLaunch &c = o.conv;
+            if (o.kind != OP_CONV || o.name != "1" || c.ks != 3 || c.stride != 2 || c.cin != 32 || c.cout != 64 || c.act != 1 || c.res.base || c.out2.base || c.in_lo.base) continue;
+            if (c.in.pad != 1 || c.in.coff != 0 || c.in.C != 32 || c.in.W % 2 != 0 || c.out.pad != 1 || c.out.coff != 0 || c.out.C != 64 || c.out.W % 2 != 0 || c.in.W != 2 * c.out.W) continue;
+            if (c.tail_wt && (c.tail_cout != 64 || c.tail_out.pad != 1 || c.tail_out.coff != 0 || c.tail_out.C < 64 || c.tail_out.C % 8 != 0 || c.tail_kp != 64)) continue;
+            const WeightRec &r = wf.recs.at("1");
+            const int kp = 576;
+            std::vector<f16> w((size_t)128 * kp, (f16)0.0f);
+            std::vector<float> b(128, 0.f);
+            for (int s = 0; s < 2; ++s)
+                for (int co = 0; co < 64; ++co) {
+                    b[s * 64 + co] = r.b[co];
+                    for (int kh = 0; kh < 3; ++kh)
+                        for (int pw = 0; pw < 3; ++pw)
+                            for (int t = 0; t < 2; ++t) {
+                                const int kw = 2 * pw + t - 2 * s;
+                                if (kw < 0 || kw > 2) continue;
+                                memcpy(&w[(size_t)(s * 64 + co) * kp + ((kh * 3 + pw) * 2 + t) * 32], &r.w[((size_t)co * 9 + kh * 3 + kw) * 32], 32 * sizeof(f16));
+                            }
+                }
+            void *dw, *db;
+            RT_TRY(upload(d, w.data(), w.size() * sizeof(f16), &dw));
+            RT_TRY(upload(d, b.data(), b.size() * sizeof(float), &db));
+            c.wt = (const f16 *)dw; c.bias = (const float *)db;
+            c.cin = 64; c.cout = 128; c.kp = kp;
+            c.in.C = 64; c.in.c = 64; c.in.W /= 2; c.in.wp = c.in.W + 1;                 // 161 pairs per padded row, the first one = (border, pixel 0)
+            c.out.base -= 64; c.out.C = 128; c.out.c = 128; c.out.W /= 2; c.out.wp = c.out.W + 1;   // 80 pairs + one pair of border pixels per padded row
+            if (c.tail_wt) {
+                const WeightRec &r2 = wf.recs.at(d->ops[i + 1].name);
+                std::vector<f16> w2((size_t)128 * 128, (f16)0.0f);
+                std::vector<float> b2(128, 0.f);
+                for (int s = 0; s < 2; ++s)
+                    for (int co = 0; co < 64; ++co) {
+                        b2[s * 64 + co] = r2.b[co];
+                        memcpy(&w2[(size_t)(s * 64 + co) * 128 + s * 64], &r2.w[(size_t)co * 64], 64 * sizeof(f16));
+                    }
+                RT_TRY(upload(d, w2.data(), w2.size() * sizeof(f16), &dw));
+                RT_TRY(upload(d, b2.data(), b2.size() * sizeof(float), &db));
+                const int cs = c.tail_out.C;
+                c.tail_wt = (const f16 *)dw; c.tail_bias = (const float *)db; c.tail_cout = 128; c.tail_kp = 128;
+                c.tail_gap = cs - 64;
+                c.tail_out.base -= cs; c.tail_out.C = 2 * cs; c.tail_out.c = 128; c.tail_out.W /= 2; c.tail_out.wp = c.tail_out.W + 1;
+                o.tail_tile = TILE_TAIL_K64_128x128;
+                if (const char *e = getenv("RTMODT_TAIL")) { o.tail_on = atoi(e) != 0; d->ops[i + 1].skip = o.tail_on; }
+            }
+            c.tile = pick_tile(d->B * c.out.H * c.out.W, 128);
+            if (const char *e = getenv("RTMODT_TILE_K64")) {        // the 64-deep test hook applies to the pair form too (the pt tiles need full tiles)
+                const int t = atoi(e);
+                if (t >= 0 && t < TILE_COUNT && tile_needs_cin64(t) && !tile_is_rows(t) && !tile_is_tail(t) && !tile_is_ws(t) && tile_shape(t).bn <= 128 &&
+                    (!tile_is_pt(t) || ((long)d->B * c.out.H * c.out.W) % 128 == 0)) c.tile = t;
+            }
+            o.name = "1";                                            // (flops, layer_out["1"] and the profile's name keep describing the real conv)
+            break;
+        }
+    }
     for (size_t i = 1; i < d->ops.size(); ++i) {              // layers 0 + 1 (+ 2.cv1) in one launch: YOLOv8s' shapes only
         const Op &o = d->ops[i];
         if (o.kind == OP_CONV && o.name == "1" && d->ops[0].kind == OP_STEM && o.conv.ks == 3 && o.conv.stride == 2 && o.conv.cin == 32 && o.conv.cout == 64 &&
@@ -1938,8 +2009,9 @@ int rtmodt_detector_profile(rtmodt_detector *d, int iters, int max_entries, cons
         } else if (op.kind == OP_CONV && op.skip) {
             snprintf(buf, sizeof(buf), "%s [runs as the tail of the previous launch]", op.name.c_str());
         } else if (op.kind == OP_CONV) {
-            snprintf(buf, sizeof(buf), "%s [M=%d N=%d K=%d k%d s%d tile %s]", op.name.c_str(), PB * op.conv.out.H * op.conv.out.W,
-                     op.conv.cout, op.conv.ks * op.conv.ks * op.conv.cin, op.conv.ks, op.conv.stride, tile_name(op.tail_on ? op.tail_tile : op.conv.tile));
+            snprintf(buf, sizeof(buf), "%s [M=%d N=%d K=%d k%d s%d tile %s%s]", op.name.c_str(), PB * op.conv.out.H * op.conv.out.W,
+                     op.conv.cout, op.conv.ks * op.conv.ks * op.conv.cin, op.conv.ks, op.conv.stride, tile_name(op.tail_on ? op.tail_tile : op.conv.tile),
+                     op.conv.in.wp ? ", pixel pairs" : "");
         } else if (op.kind == OP_BNECK) {
             if (op.fused) snprintf(buf, sizeof(buf), "%s [fused bottleneck%s, c=%d, %dx%d]", op.name.c_str(), op.tail_on ? " + C2f.cv2 tail" : "", op.bneck.c, op.bneck.in.H, op.bneck.in.W);
             else snprintf(buf, sizeof(buf), "%s [two launches: %s, %s]", op.name.c_str(), tile_name(op.group[0].tile), tile_name(op.group[1].tile));

@@ -36,6 +36,8 @@ struct TensorView {
     int C = 0;             // channels of the underlying tensor (pixel stride)
     int pad = 0;           // border width (0 or 1)
     int coff = 0, c = 0;   // the slice
+    int wp = 0;            // padded row length in pixels when it is not W + 2 * pad (pixel-PAIR views of a tensor: engine.hip, layer 1)
+    int padded_w() const { return wp ? wp : W + 2 * pad; }
 };
 
 // Tile configurations of the implicit-GEMM kernel (conv.hip)
@@ -83,6 +85,9 @@ struct ConvLaunch {
     int tile = TILE_128x128;
     // optional fused tail: a 1x1 stride-1 conv over this conv's output, which is then never stored (TILE_TAIL_* only)
     TensorView tail_out; const f16 *tail_wt = nullptr; const float *tail_bias = nullptr; int tail_cout = 0, tail_kp = 0, tail_act = 1;
+    // pixel-pair form only: the tail's 128 output "channels" are two pixels x 64 channels, and the second pixel starts tail_gap elements
+    // after the end of the first (the destination is a 64-channel slice of a wider tensor)
+    int tail_gap = 0;
     int epilogue = 1;             // 0: 8-byte stores from the accumulator layout; 1: 16-byte stores through LDS in the tile kernels; 2: also in the tap-reuse kernel
 };
 

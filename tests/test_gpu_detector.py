@@ -1233,3 +1233,43 @@ def test_converted_checkpoint_through_the_engine(pkg, wdir, tmp_path):
     dets, anch = Y.non_max_suppression(pr, 0.35, 0.45, None, False, 300)
     assert len(d) > 5 and abs(len(d) - len(dets)) <= max(3, len(dets) // 10)
     det.close()
+
+
+@pytest.mark.parametrize("size,batch,tail", [(640, 2, "0"), (640, 2, "1"), (320, 3, "1"), (352, 1, "0")])
+def test_layer1_pixel_pair_form(pkg, wdir, monkeypatch, size, batch, tail):
+    """Layer "1" of YOLOv8s (3x3 / s2, 32 -> 64) as a conv over PIXEL PAIRS: cin 64 = two adjacent input pixels, cout 128 = two
+    adjacent output pixels, half the GEMM rows, weights with the missing taps zeroed; 2.cv1 as its tail runs block-diagonal on
+    the pair rows and lands in a 64-channel slice of the 96-channel concat tensor.  On / off (RTMODT_L1_PAIR) with the tuner
+    out of the way: the non-zero terms meet in the same order and the same 32-wide groups, so every stored layer must be
+    bit-identical between the two forms, and within tolerance of the oracle; 352 -> 88-pixel rows (44 pairs: partial tiles)."""
+    monkeypatch.setenv("RTMODT_TILE", "2")
+    monkeypatch.setenv("RTMODT_BNECK", "0")
+    monkeypatch.setenv("RTMODT_TAIL", tail)
+    frames = list(pkg.synth.frames(batch, size, size, seed=size + batch))
+    names = [c.name for c in pkg.weights.spec("s")]
+    outs = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("RTMODT_L1_PAIR", mode)
+        det, w = make_detector(pkg, wdir, "s", size, autotune=False, batch=batch, confidence=0.05)
+        dets = det.detect_batch(frames)
+        prof = [n for n, _, _ in det.profile(1)]
+        assert ("pixel pairs" in prof[1]) == (mode == "1"), prof[:3]
+        layers = []
+        for img in range(batch):
+            inp, _, _ = det.debug_fetch(img, want_heads=False, want_pred=False)
+            gpu = fetch_layers(pkg, det, names, img)
+            assert ("1" in gpu) == (tail == "0") and "2.cv1" in gpu
+            layers.append(gpu)
+            if mode == "1":
+                taps = {}
+                Y.forward(inp.astype(np.float32), w, "s", taps=taps, force=gpu)
+                for n in gpu:
+                    k = 4e-3 if n == "2.cv1" and tail == "1" else 2e-3
+                    assert float(np.abs(taps[n] - gpu[n]).max()) <= k * np.abs(taps[n]).max() + 2e-3, (img, n)
+        outs[mode] = (dets, layers)
+        det.close()
+    for img in range(batch):
+        for n in outs["0"][1][img]:
+            assert np.array_equal(outs["0"][1][img][n].view(np.uint16), outs["1"][1][img][n].view(np.uint16)), (img, n)
+        a, b = outs["0"][0][img], outs["1"][0][img]
+        assert np.array_equal(a.xyxy.view(np.int32), b.xyxy.view(np.int32)) and a.class_id.tolist() == b.class_id.tolist()
