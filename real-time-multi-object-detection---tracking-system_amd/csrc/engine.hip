@@ -617,6 +617,7 @@ static int build_graph(rtmodt_detector *d, WeightFile &wf) {
     // MEASURED (32 frames, profiles/r03): the pair conv alone 88 us on pt:128x128s2 against 102 us for the plain form's best tile --
     // but its matrix work is doubled (4 of 9 pair-taps are half empty), and with 2.cv1 as its tail (only the 4-wave tail kernels
     // exist) it takes 133 us against 111 us for the plain form with its tail: off by default.
+    {
         const bool pair_off = !(getenv("RTMODT_L1_PAIR") && atoi(getenv("RTMODT_L1_PAIR")) != 0) || (getenv("RTMODT_STEM_L1") && atoi(getenv("RTMODT_STEM_L1")) != 0);
         for (size_t i = 1; i < d->ops.size() && !pair_off; ++i) {
             Op &o = d->ops[i];
