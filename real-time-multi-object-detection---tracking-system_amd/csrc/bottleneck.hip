@@ -21,6 +21,7 @@
 #include <algorithm>
 
 #include "kernels.h"
+#include "tile_math.h"
 
 namespace rtmodt {
 
@@ -66,11 +67,15 @@ struct BneckGeom {
     static constexpr int SUB = CW / 32;                   // MFMA k-substeps per (tap, plane)
     static constexpr int NT = CH / 16;                    // cout tiles
     static constexpr int PW = TW + 4, PH = TH + 4;        // input patch
-    static constexpr int P_PIX = PW * PH, P_ROWS = (P_PIX + RPP - 1) / RPP * RPP;
+    static constexpr int P_PIX = PW * PH, P_ROWS = (P_PIX + 2 + RPP - 1) / RPP * RPP;   // + 2: conv1's junk columns read two rows past the patch (zero-filled)
     static constexpr int IW = TW + 2, IH = TH + 2;        // intermediate (halo 1)
     static constexpr int M1 = IW * IH, M1T = (M1 + 15) / 16, T_ROWS = M1T * 16;
+    // conv1's GEMM rows enumerate PATCH positions of the first IH patch rows (all PW columns, the two right-most are junk that is
+    // never stored): an m-tile is then 16 CONSECUTIVE rows of the patch image whatever the tap -- no jump where the halo-1 region
+    // wraps to its next row -- which is what the swizzle above needs; 11 % more rows, the same number of m-tiles per wave
+    static constexpr int M1P = PW * IH, M1PT = (M1P + 15) / 16;
     static constexpr int M2 = TW * TH, M2T = M2 / 16;
-    static constexpr int TM1 = (M1T + BN_WAVES - 1) / BN_WAVES, TM2 = (M2T + BN_WAVES - 1) / BN_WAVES;
+    static constexpr int TM1 = (M1PT + BN_WAVES - 1) / BN_WAVES, TM2 = (M2T + BN_WAVES - 1) / BN_WAVES;
     static constexpr int W_PIECES = CH / RPP;             // DMA pieces per (tap, plane) of weights
     static constexpr int W_STEP = CH * CB;                // bytes of one weight unit: (tap, plane)
     static constexpr bool ALLW = CH == 32;                // a conv's whole weight matrix (18 KiB) sits in ONE LDS buffer: no ring, no barrier in the k-loop
@@ -83,12 +88,12 @@ struct BneckGeom {
     static constexpr int LDS_TAIL = 152 * 1024;
 };
 
-// byte offset of 16-byte chunk c16 of row R inside a piece-structured, swizzled plane
+// LDS swizzle (tile_math.h: swz_slot / swz_src, checked exhaustively on the host by tests/test_tile_math_cpu.py): conflict-free
+// ds_read_b128 fragments from ANY start row.  Round 2's XOR by {0, 0, 3, 3}[R >> 2] / (R >> 1) & 7 was conflict-free only from
+// rows that are multiples of 16 (what conv.hip's tiles read), and took ~2 LDS cycles per 16-lane group instead of 1 on the
+// activation fragments of every tap here (38 % conflict cycles in the counters).
 template <int CB>
-__device__ __forceinline__ int plane_off(int R, int c16) {
-    if (CB == 128) return (R >> 3) * 1024 + (R & 7) * 128 + ((c16 ^ ((R >> 1) & 7)) << 4);
-    return (R >> 4) * 1024 + (R & 15) * 64 + ((c16 ^ (((R >> 3) & 1) * 3)) << 4);
-}
+__device__ __forceinline__ int plane_off(int R, int c16) { return swz_plane_off<CB>(R, c16); }
 
 // One conv of the pair as an implicit GEMM from an LDS image.  src: planes [NCH][rows][CB];
 // SW = row width of that image; my_pb[i] = LDS pixel index (tap 0,0) of this lane's row in the
@@ -110,7 +115,7 @@ __device__ __forceinline__ void gemm_from_lds(const unsigned char *src, unsigned
             const int un = idx / G::W_PIECES, pc = idx - un * G::W_PIECES;
             const int unit = step * UPS + un, tap = unit / NCH, plane = unit - tap * NCH;
             int row = pc * RPP + ld_row;
-            int c16 = CB == 128 ? (ld_slot ^ ((row >> 1) & 7)) : (ld_slot ^ (((row >> 3) & 1) * 3));
+            int c16 = swz_src<CB>(row, ld_slot);
             dma16(w + ((long)row * kp + tap * (NCH * G::CW) + plane * G::CW + c16 * 8), dst + un * G::W_STEP + pc * 1024);
         }
     };
@@ -156,7 +161,7 @@ __device__ __forceinline__ void allw_issue(unsigned char *wbuf, const f16 *w, in
         const int unit = idx / G::W_PIECES, pc = idx - unit * G::W_PIECES;
         const int tap = unit / NCH, plane = unit - tap * NCH;
         int row = pc * RPP + ld_row;
-        int c16 = CB == 128 ? (ld_slot ^ ((row >> 1) & 7)) : (ld_slot ^ (((row >> 3) & 1) * 3));
+        int c16 = swz_src<CB>(row, ld_slot);
         dma16(w + ((long)row * kp + tap * (NCH * G::CW) + plane * G::CW + c16 * 8), wbuf + unit * G::W_STEP + pc * 1024);
     }
 }
@@ -211,7 +216,7 @@ __global__ __launch_bounds__(BN_THREADS) void bottleneck_fused(BneckArgs p) {
             const int pix = pp * RPP + ld_row;
             const int py = pix / G::PW, px = pix - py * G::PW;
             const int gy = y0 - 2 + py, gx = x0 - 2 + px;
-            const int c16 = CB == 128 ? (ld_slot ^ ((pix >> 1) & 7)) : (ld_slot ^ (((pix >> 3) & 1) * 3));
+            const int c16 = swz_src<CB>(pix, ld_slot);
             const bool ok = pix < G::P_PIX && gy >= -1 && gy <= p.H && gx >= -1 && gx <= p.W;
             const f16 *srcp = ok ? p.in + (((long)(b * p.in_Hp + gy + 1) * p.in_Wp + gx + 1) * p.in_cs + plane * G::CW + c16 * 8) : p.zeros;
             dma16(srcp, patch + plane * (G::P_ROWS * CB) + pp * 1024);
@@ -225,11 +230,9 @@ __global__ __launch_bounds__(BN_THREADS) void bottleneck_fused(BneckArgs p) {
 #pragma unroll
         for (int i = 0; i < G::TM1; ++i) {
             int t = wave + BN_WAVES * i;
-            int m = t * 16 + r;
-            mrow[i] = t < G::M1T ? m : -1;
-            m = m < G::M1 ? m : G::M1 - 1;                      // padding rows of the last tile re-read a valid pixel
-            int iy = m / G::IW, ix = m - iy * G::IW;
-            pb[i] = iy * G::PW + ix;
+            int m = t * 16 + r;                                  // patch position (row-major over PW columns)
+            mrow[i] = t < G::M1PT ? m : -1;
+            pb[i] = m < G::M1P ? m : G::M1P - 1;                // padding rows of the last tile re-read a valid position
         }
         floatx4 acc[G::TM1][NT];
 #pragma unroll
@@ -252,9 +255,11 @@ __global__ __launch_bounds__(BN_THREADS) void bottleneck_fused(BneckArgs p) {
         // epilogue 1: SiLU -> fp16 -> tbuf; positions outside the image are conv2's zero padding
 #pragma unroll
         for (int i = 0; i < G::TM1; ++i) {
-            const int m = mrow[i];
-            if (m < 0 || m >= G::M1) continue;
-            const int iy = m / G::IW, ix = m - iy * G::IW;
+            const int mp = mrow[i];
+            if (mp < 0 || mp >= G::M1P) continue;
+            const int iy = mp / G::PW, ix = mp - iy * G::PW;
+            if (ix >= G::IW) continue;                           // the patch's two right-most columns: not part of the halo-1 region
+            const int m = iy * G::IW + ix;                      // row of the intermediate image
             const int gy = y0 - 1 + iy, gx = x0 - 1 + ix;
             const bool inside = gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
 #pragma unroll

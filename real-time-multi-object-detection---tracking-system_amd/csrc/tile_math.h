@@ -50,4 +50,18 @@ RT_HD PtRun pt_run(int g, int slice, int groups, int n_mt) {
     return r;
 }
 
+// LDS swizzle of the fused Bottleneck's activation images (bottleneck.hip): where the 16-byte chunk c of row R sits inside its
+// row, and back.  The MFMA fragment reads of its two convs start at ARBITRARY rows (pixel + tap offset), not at multiples of 16
+// like the tile kernels', so the map has to be conflict-free for any 16 consecutive rows under ds_read_b128's lane groups
+// ({0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, + 32: inside a group the k-chunk index q is 0 for r in [0, 4) u [12, 16) and 1 for
+// r in [4, 12), or the other way round):
+//   64-byte rows (c = 32; 4 rows per 256-byte bank row): slot = c ^ 2 * bit 2 of R        (an involution)
+//   128-byte rows (2 rows per bank row):                  slot = (c + 2 * (R >> 1)) mod 8  (a rotation; its inverse on the DMA source)
+template <int CB> RT_HD int swz_slot(int R, int c) { return CB == 128 ? ((c + 2 * (R >> 1)) & 7) : (c ^ (((R >> 2) & 1) << 1)); }
+template <int CB> RT_HD int swz_src(int R, int slot) { return CB == 128 ? ((slot - 2 * (R >> 1)) & 7) : (slot ^ (((R >> 2) & 1) << 1)); }
+// byte offset of 16-byte chunk c of row R inside a plane of 1-KiB DMA pieces (8 rows x 128 B or 16 rows x 64 B)
+template <int CB> RT_HD int swz_plane_off(int R, int c) {
+    return CB == 128 ? (R >> 3) * 1024 + (R & 7) * 128 + (swz_slot<CB>(R, c) << 4) : (R >> 4) * 1024 + (R & 15) * 64 + (swz_slot<CB>(R, c) << 4);
+}
+
 }  // namespace rtmodt

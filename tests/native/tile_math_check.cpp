@@ -49,6 +49,40 @@ static int check_xcd_tile() {
     return 0;
 }
 
+// the fused Bottleneck's LDS swizzle: a bijection per row, src the inverse of slot, and every ds_read_b128 lane group of an MFMA
+// fragment read (16 consecutive rows from ANY start row, k-chunk q per lane) lands in 16 distinct 16-byte bank slots
+template <int CB>
+static int check_swizzle_cb() {
+    const int NC = CB / 16;
+    for (int R = 0; R < 4096; ++R) {
+        int seen = 0;
+        for (int c = 0; c < NC; ++c) {
+            const int s = swz_slot<CB>(R, c);
+            if (s < 0 || s >= NC || (seen >> s & 1) || swz_src<CB>(R, s) != c) { printf("swizzle<%d>: row %d chunk %d -> slot %d\n", CB, R, c, s); return 1; }
+            seen |= 1 << s;
+        }
+    }
+    static const int groups[4][16] = {{0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27}, {4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31},
+                                      {32, 33, 34, 35, 44, 45, 46, 47, 52, 53, 54, 55, 56, 57, 58, 59}, {36, 37, 38, 39, 40, 41, 42, 43, 48, 49, 50, 51, 60, 61, 62, 63}};
+    for (int R0 = 0; R0 < 2048; ++R0)
+        for (int kk = 0; kk < NC / 4; ++kk)
+            for (auto &g : groups) {
+                int seen = 0;
+                for (int lane : g) {
+                    const int r = lane & 15, q = lane >> 4;
+                    const int slot = (swz_plane_off<CB>(R0 + r, kk * 4 + q) >> 4) & 15;      // 16-byte slot of the 256-byte bank row
+                    if (seen >> slot & 1) { printf("swizzle<%d>: bank conflict from row %d, k-substep %d, lane %d\n", CB, R0, kk, lane); return 1; }
+                    seen |= 1 << slot;
+                }
+            }
+    return 0;
+}
+static int check_swizzle() {
+    if (check_swizzle_cb<64>() || check_swizzle_cb<128>()) return 1;
+    printf("ok swizzle\n");
+    return 0;
+}
+
 static int check_pt_run() {
     long cfgs = 0;
     for (int n_mt = 1; n_mt <= 700; ++n_mt)
@@ -76,4 +110,4 @@ static int check_pt_run() {
     return 0;
 }
 
-int main() { return check_fastdiv() || check_xcd_tile() || check_pt_run(); }
+int main() { return check_fastdiv() || check_xcd_tile() || check_pt_run() || check_swizzle(); }
