@@ -57,11 +57,14 @@ enum ConvTile {
     // BIG tiles, one workgroup per CU: fewer operand bytes per FLOP through the L2 -> LDS path (256x128: -25 %, 256x256: -50 % vs 128x128)
     // AND more of them in flight (three 48-KiB stages / two 64-KiB stages of the 160 KiB); 8 waves, 64x64 / 64x128 outputs per wave
     TILE_K64_256x128_S3_W8 = 48, TILE_K64_256x256_S2_W8 = 49,
-    TILE_COUNT = 50
+    // PERSISTENT tap-reuse kernel (8 waves): a workgroup walks over the tiles of the (grouped) launch, the next tile's first operands in flight under this tile's last step and epilogue
+    TILE_ROWS_PT_256x64 = 50, TILE_ROWS_PT_128x64 = 51, TILE_ROWS_PT_K64_256x64 = 52,
+    TILE_COUNT = 53
 };
 const char *tile_name(int tile);
 bool tile_needs_cin64(int tile);
 bool tile_is_rows(int tile);      // 3x3 stride-1 only, bordered input
+bool tile_is_rows_pt(int tile);   // ... its persistent form (groups allowed)
 bool tile_is_tail(int tile);      // runs ConvLaunch::tail_* as well; needs cout == the tile's BN
 bool tile_reads_lo(int tile);     // can serve ConvLaunch::in_lo
 bool tile_is_w8(int tile);        // 8-wave 64-deep tile kernel (conv_mfma64_w8): one conv per launch

@@ -161,7 +161,7 @@ def test_forward_layers_other_scales(pkg, wdir, scale, size):
     det.close()
 
 
-@pytest.mark.parametrize("tile", [22, 23, 24, 25, 26, 27, 28, 38, 39, 40, 41])      # 38..41: the 8-wave variants
+@pytest.mark.parametrize("tile", [22, 23, 24, 25, 26, 27, 28, 38, 39, 40, 41, 50, 51, 52])      # 38..41: the 8-wave variants; 50..52: the persistent form
 def test_tap_reuse_conv_tiles(pkg, wdir, monkeypatch, tile):
     """conv3x3_rows (the 3x3/s1 tap-reuse kernel) in each of its tile shapes, forced onto every
     layer where it is legal; all layers are then checked one by one against the oracle."""
@@ -1272,4 +1272,45 @@ def test_layer1_pixel_pair_form(pkg, wdir, monkeypatch, size, batch, tail):
         for n in outs["0"][1][img]:
             assert np.array_equal(outs["0"][1][img][n].view(np.uint16), outs["1"][1][img][n].view(np.uint16)), (img, n)
         a, b = outs["0"][0][img], outs["1"][0][img]
+        assert np.array_equal(a.xyxy.view(np.int32), b.xyxy.view(np.int32)) and a.class_id.tolist() == b.class_id.tolist()
+
+
+@pytest.mark.parametrize("tile,size,batch,scale", [(50, 320, 32, "s"), (51, 320, 32, "s"), (52, 320, 16, "s"), (50, 288, 3, "s"), (50, 640, 4, "s"), (51, 320, 8, "m")])
+def test_persistent_tap_reuse_kernel(pkg, wdir, monkeypatch, tile, size, batch, scale):
+    """conv3x3_rows_stream (TILE_ROWS_PT_*): persistent workgroups walk over the tiles of a launch -- of ALL problems of a grouped
+    launch (Detect stage 0: three levels with K = 1152 / 2304 / 4608, stage 1: six convs) -- with the next tile's first strip and
+    weights in flight under the current tile's last super-step and epilogue.  Forced onto every 3x3 / stride-1 conv (Bottlenecks
+    with their shortcuts, Detect); batches large enough that a workgroup walks several tiles and crosses problem boundaries, and
+    288 x 288 (partial tiles, fewer tiles than workgroups).  All layers of the first and the last image against the oracle; the
+    same arithmetic and k order as the plain tap-reuse kernel: bit-identical to it."""
+    monkeypatch.setenv("RTMODT_BNECK", "0")
+    monkeypatch.setenv("RTMODT_TAIL", "0")
+    frames = list(pkg.synth.frames(batch, size, size, seed=23 + tile))
+    names = [c.name for c in pkg.weights.spec(scale)]
+    plain = {50: 39, 51: 38, 52: 41}[tile]                    # the same tile shape on the plain 8-wave tap-reuse kernel
+    outs = {}
+    for t in (plain, tile):
+        monkeypatch.setenv("RTMODT_TILE_3X3S1", str(t))
+        det, w = make_detector(pkg, wdir, scale, size, autotune=False, batch=batch, confidence=0.05)
+        used = [n for n, _, _ in det.profile(1) if "rows" in n]
+        assert len(used) >= 6 and (("-pt:" in " ".join(used)) == (t == tile)), used
+        dets = det.detect_batch(frames)
+        layers = {}
+        for img in sorted({0, batch - 1}):
+            inp, _, _ = det.debug_fetch(img, want_heads=False, want_pred=False)
+            gpu = fetch_layers(pkg, det, names, img)
+            layers[img] = gpu
+            if t == tile:
+                taps = {}
+                Y.forward(inp.astype(np.float32), w, scale, taps=taps, force=gpu)
+                for n in gpu:
+                    tol = 2e-3 * np.abs(taps[n]).max() + 2e-3
+                    err = float(np.abs(taps[n] - gpu[n]).max())
+                    assert err <= tol, f"tile {tile} img {img} layer {n}: max err {err:.4g} > tol {tol:.4g}"
+        outs[t] = (dets, layers)
+        det.close()
+    for img in outs[tile][1]:
+        for n in outs[tile][1][img]:
+            assert np.array_equal(outs[plain][1][img][n].view(np.uint16), outs[tile][1][img][n].view(np.uint16)), (img, n)
+    for a, b in zip(outs[plain][0], outs[tile][0]):
         assert np.array_equal(a.xyxy.view(np.int32), b.xyxy.view(np.int32)) and a.class_id.tolist() == b.class_id.tolist()
