@@ -447,11 +447,20 @@ def main():
             hw = HwmonSampler(dev) if rank == 0 else None
             if hw:
                 hw.start()
+            if rank == 0:
+                det.clock_sampling(True)                 # one wave behind every batch's NMS reads s_memtime against s_memrealtime (long window only)
             k = 0
             tl0 = pc()
             while pc() - tl0 < long_s or k * S * F < 1000:
                 step(t); t += 1; k += 1
             long_run = {"steps": k, "seconds": pc() - tl0, "power_clock": hw.stop() if hw else None}
+            if rank == 0:
+                drain_now = [det.fetch() for _ in range(depth - 1)]      # the sampler's launches sit behind these batches' NMS
+                del drain_now
+                ghz_mean, ghz_min, ghz_max, n_s = det.clock_read()
+                det.clock_sampling(False)
+                long_run["in_kernel_clock"] = {"ghz_mean": round(ghz_mean, 4), "ghz_min": round(ghz_min, 4), "ghz_max": round(ghz_max, 4), "samples": n_s}
+                fill()
         drain()                                          # the batches still in flight (outside the timed region)
         sync_all(det)
         if collective:
@@ -522,6 +531,14 @@ def main():
         lr = m["long"]
         res["timing"]["long_window"] = {"value": round(world * S * F * lr["steps"] / lr["seconds"], 1), "unit": "frames/s (rank 0's own clock)",
                                         "steps": lr["steps"], "seconds": round(lr["seconds"], 3), "power_clock": lr.get("power_clock")}
+        ikc = lr.get("in_kernel_clock")
+        if ikc and ikc["samples"] > 0 and ikc["ghz_mean"] > 0:
+            # informational: `peak` / `frac` stay priced at the data sheet's 2.4 GHz.  The shader clock the kernels actually ran at, read INSIDE
+            # the device (s_memtime ticks per 100-MHz s_memrealtime tick, one wave behind every batch's NMS during the long window): the chip
+            # lowers it under this load, and hwmon / DPM readings overstate it (MI355X_MICROARCH.md, DVFS give-back)
+            held = 2500.0 * ikc["ghz_mean"] / 2.4
+            res["roofline"]["in_kernel_clock"] = dict(ikc, peak_at_clock=round(held, 1), frac_at_clock=round(res["roofline"]["achieved"] / held, 4),
+                                                      source="s_memtime / s_memrealtime x 100 MHz, ~20 us samples on the post-processing stream during the long window")
         pcw = lr.get("power_clock")
         if pcw and isinstance(res.get("roofline"), dict) and res["roofline"].get("achieved"):
             # informational: `peak` / `frac` stay priced at 2.4 GHz; this is the same peak at the clock the chip held under its power limit

@@ -134,6 +134,12 @@ int rtmodt_detector_last_timing(rtmodt_detector *det, float *total_ms, float *fo
 /* The same batch split into the stages the reference's profiler names (latency_profiler.py:38):
  * preprocess = letterbox, inference = forward pass + decode, nms = NMS + rescale (device ms). */
 int rtmodt_detector_stage_times(rtmodt_detector *det, float *preprocess_ms, float *inference_ms, float *nms_ms);
+/* In-kernel shader clock (measurement aid, no reference counterpart): while enabled, one wave behind every batch's NMS reads the
+ * shader-cycle counter against the constant 100 MHz counter for ~20 us; _read waits for the post-processing stream and returns
+ * mean / min / max GHz over the samples since it was enabled (or read last).  The MFMA peak at THAT clock, not at the 2.4 GHz of
+ * the data sheet, is what the matrix cores could have delivered during the run. */
+int rtmodt_detector_clock_enable(rtmodt_detector *det, int on);
+int rtmodt_detector_clock_read(rtmodt_detector *det, double *ghz_mean, double *ghz_min, double *ghz_max, int32_t *n_samples);
 
 /* decode-free NMS on a caller-supplied pre-NMS tensor pred[(4+nc)*A] float32 (the layout
  * ultralytics' non_max_suppression receives): BASELINE config 2's

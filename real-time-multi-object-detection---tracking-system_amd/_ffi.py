@@ -85,6 +85,8 @@ def lib() -> C.CDLL:
                                               C.POINTER(i64), C.POINTER(i32)]),
         "rtmodt_detector_last_timing": (C.c_int, [vp, C.POINTER(f32), C.POINTER(f32)]),
         "rtmodt_detector_stage_times": (C.c_int, [vp, C.POINTER(f32), C.POINTER(f32), C.POINTER(f32)]),
+        "rtmodt_detector_clock_enable": (C.c_int, [vp, C.c_int]),
+        "rtmodt_detector_clock_read": (C.c_int, [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int32)]),
         "rtmodt_nms_pred": (C.c_int, [C.c_int, vp, C.c_int, C.c_int, f32, f32, vp, C.c_int, C.c_int, C.c_int,
                                       vp, vp, vp, vp, C.POINTER(i32)]),
         "rtmodt_preprocess": (C.c_int, [C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),

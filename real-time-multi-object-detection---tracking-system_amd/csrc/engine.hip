@@ -272,9 +272,27 @@ struct rtmodt_detector {
     int last_h = 0, last_w = 0;
     // profile storage
     std::vector<std::string> prof_names;
+    // in-kernel shader clock, sampled by one wave behind every batch's NMS while enabled (rtmodt_detector_clock_*)
+    bool clock_on = false;
+    unsigned long long *d_clock = nullptr;            // [CLOCK_SLOTS][4] = {s_memtime, s_memrealtime} at the start and the end of a sample
+    uint64_t clock_n = 0;
+    static constexpr int CLOCK_SLOTS = 4096;
 };
 
 namespace rtmodt {
+
+// one wave: {s_memtime, s_memrealtime} now and again `ticks` 100-MHz ticks later (bounded: at most 4096 sleeps of ~64 x 64 clk)
+__global__ void clock_sample_kernel(unsigned long long *out, unsigned ticks) {
+    if (threadIdx.x != 0) return;
+    unsigned long long t0, r0, t1, r1;
+    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0), "=s"(r0)::"memory");
+    t1 = t0; r1 = r0;
+    for (int i = 0; i < 4096 && r1 - r0 < ticks; ++i) {
+        __builtin_amdgcn_s_sleep(64);
+        asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1), "=s"(r1)::"memory");
+    }
+    out[0] = t0; out[1] = r0; out[2] = t1; out[3] = r1;
+}
 
 struct Builder {
     rtmodt_detector *d;
@@ -1538,6 +1556,7 @@ void rtmodt_detector_destroy(rtmodt_detector *d) {
     for (auto e : d->chain_fork) hipEventDestroy(e);
     for (auto e : d->chain_join) hipEventDestroy(e);
     if (d->post_stream) hipStreamDestroy(d->post_stream);
+    if (d->d_clock) hipFree(d->d_clock);
     if (d->copy_stream) hipStreamDestroy(d->copy_stream);
     for (auto st : d->aux_streams) if (st) hipStreamDestroy(st);
     for (auto st : d->pad_streams) hipStreamDestroy(st);
@@ -1802,6 +1821,11 @@ int rtmodt_detector_enqueue_batch(rtmodt_detector *d, const uint8_t *const *fram
     if (chained && !sl.joined) for (int c = 1; c < d->n_chains; ++c) RT_HIP(hipStreamWaitEvent(d->post_stream, sl.chain_done[c], 0));
     RT_TRY(run_nms(d, g, h, w, sl));
     RT_HIP(hipEventRecord(sl.ev2, d->post_stream));
+    if (d->clock_on) {                                    // one wave, ~20 us, behind the NMS of this batch (the forward pass of the next ones is running)
+        hipLaunchKernelGGL(clock_sample_kernel, dim3(1), dim3(64), 0, d->post_stream, d->d_clock + 4 * (d->clock_n % rtmodt_detector::CLOCK_SLOTS), 2000u);
+        RT_HIP(hipGetLastError());
+        d->clock_n += 1;
+    }
     // results travel to pinned host memory right behind the kernels; fetch() only waits for `done`
     const int md = d->cfg.max_det;
     RT_HIP(hipMemcpyAsync(sl.h_n, sl.o_n, n * sizeof(int32_t), hipMemcpyDeviceToHost, d->post_stream));
@@ -1815,6 +1839,47 @@ int rtmodt_detector_enqueue_batch(rtmodt_detector *d, const uint8_t *const *fram
     d->batch_no += 1;
     d->n_pending += 1;
     d->last_h = h; d->last_w = w;
+    return RTMODT_OK;
+}
+
+// ---- in-kernel shader clock ------------------------------------------------------------------------------------------
+// The chip lowers its shader clock under an MFMA-dense load, and the hwmon / DPM reading overstates what the kernels see
+// (measured with phase stamps: 1.70-1.76 GHz inside the tap-reuse kernel against 2.05-2.13 GHz from hwmon).  While enabled,
+// ONE wave launched on the post-processing stream behind every batch's NMS reads the shader-cycle counter (s_memtime) and the
+// constant 100 MHz counter (s_memrealtime) about 20 us apart -- while the other stages' forward kernels run on the rest of the
+// chip -- so that clock = d(memtime) / d(memrealtime) x 100 MHz is the clock those kernels ran at.  Bounded spin (s_sleep).
+int rtmodt_detector_clock_enable(rtmodt_detector *d, int on) {
+    RT_CHECK(d, RTMODT_E_INVALID, "null argument");
+    RT_HIP(hipSetDevice(d->device));
+    if (on && !d->d_clock) {
+        RT_HIP(hipMalloc((void **)&d->d_clock, sizeof(unsigned long long) * 4 * rtmodt_detector::CLOCK_SLOTS));
+        RT_HIP(hipMemset(d->d_clock, 0, sizeof(unsigned long long) * 4 * rtmodt_detector::CLOCK_SLOTS));
+    }
+    if (on && !d->clock_on) d->clock_n = 0;
+    d->clock_on = on != 0;
+    return RTMODT_OK;
+}
+
+int rtmodt_detector_clock_read(rtmodt_detector *d, double *ghz_mean, double *ghz_min, double *ghz_max, int32_t *n_samples) {
+    RT_CHECK(d && d->d_clock, RTMODT_E_INVALID, "clock sampling was never enabled");
+    RT_HIP(hipSetDevice(d->device));
+    RT_HIP(hipStreamSynchronize(d->post_stream));
+    const int n = (int)std::min<uint64_t>(d->clock_n, rtmodt_detector::CLOCK_SLOTS);
+    std::vector<unsigned long long> h((size_t)4 * std::max(n, 1));
+    if (n) RT_HIP(hipMemcpy(h.data(), d->d_clock, sizeof(unsigned long long) * 4 * n, hipMemcpyDeviceToHost));
+    double sum = 0, lo = 1e30, hi = 0;
+    int good = 0;
+    for (int i = 0; i < n; ++i) {
+        const unsigned long long t0 = h[4 * i], r0 = h[4 * i + 1], t1 = h[4 * i + 2], r1 = h[4 * i + 3];
+        if (r1 <= r0 || t1 <= t0) continue;
+        const double ghz = (double)(t1 - t0) / (double)(r1 - r0) * 0.1;
+        sum += ghz; lo = std::min(lo, ghz); hi = std::max(hi, ghz); ++good;
+    }
+    if (ghz_mean) *ghz_mean = good ? sum / good : 0.0;
+    if (ghz_min) *ghz_min = good ? lo : 0.0;
+    if (ghz_max) *ghz_max = good ? hi : 0.0;
+    if (n_samples) *n_samples = good;
+    d->clock_n = 0;
     return RTMODT_OK;
 }
 

@@ -13,9 +13,12 @@ extern __device__ unsigned long long *g_stamps;
     do {                                                                                                 \
         __builtin_amdgcn_sched_barrier(0);                                                               \
         if (threadIdx.x == 0) {                                                                          \
-            unsigned long long t_;                                                                       \
-            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                    \
-            g_stamps[(size_t)(blockIdx.x + blockIdx.y * gridDim.x) * 16 + (k)] = t_;                                                \
+            unsigned long long t_, r_;                                                                   \
+            asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_), "=s"(r_)::"memory");          \
+            unsigned long long *s_ = g_stamps + (size_t)(blockIdx.x + blockIdx.y * gridDim.x) * 16;       \
+            s_[(k)] = t_;                                                                                \
+            if ((k) == 0) { s_[13] = r_; s_[12] = t_; }      /* shader clock / 100 MHz real-time pair at the first ... */ \
+            s_[15] = r_; s_[14] = t_;                        /* ... and at the latest stamp: in-kernel clock = d(12,14) / d(13,15) x 100 MHz */ \
         }                                                                                                \
         __builtin_amdgcn_sched_barrier(0);                                                               \
     } while (0)

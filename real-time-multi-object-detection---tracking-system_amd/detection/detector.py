@@ -301,6 +301,16 @@ class Detector:
         _ffi.check(_ffi.lib().rtmodt_detector_stage_times(self.model.handle, C.byref(a), C.byref(b), C.byref(c)))
         return a.value, b.value, c.value
 
+    def clock_sampling(self, on: bool) -> None:
+        """Start / stop sampling the in-kernel shader clock (one wave behind every batch's NMS; include/rtmodt.h)."""
+        _ffi.check(_ffi.lib().rtmodt_detector_clock_enable(self.model.handle, int(bool(on))))
+
+    def clock_read(self):
+        """(mean, min, max) GHz and the sample count since sampling was enabled / last read."""
+        a, b, c, n = C.c_double(), C.c_double(), C.c_double(), C.c_int32()
+        _ffi.check(_ffi.lib().rtmodt_detector_clock_read(self.model.handle, C.byref(a), C.byref(b), C.byref(c), C.byref(n)))
+        return a.value, b.value, c.value, n.value
+
     def last_timing(self):
         a, b = C.c_float(), C.c_float()
         _ffi.check(_ffi.lib().rtmodt_detector_last_timing(self.model.handle, C.byref(a), C.byref(b)))

@@ -1314,3 +1314,23 @@ def test_persistent_tap_reuse_kernel(pkg, wdir, monkeypatch, tile, size, batch, 
             assert np.array_equal(outs[plain][1][img][n].view(np.uint16), outs[tile][1][img][n].view(np.uint16)), (img, n)
     for a, b in zip(outs[plain][0], outs[tile][0]):
         assert np.array_equal(a.xyxy.view(np.int32), b.xyxy.view(np.int32)) and a.class_id.tolist() == b.class_id.tolist()
+
+
+def test_in_kernel_clock_sampling(pkg, wdir):
+    """rtmodt_detector_clock_enable / _read: one wave behind every batch's NMS reads the shader-cycle counter against the constant
+    100 MHz counter; the clock must be a plausible gfx950 shader clock, one sample per batch, and sampling must not change results."""
+    det, _ = make_detector(pkg, wdir, "s", 320, batch=4, autotune=False)
+    frames = list(pkg.synth.frames(4, 320, 320, seed=3))
+    ref = det.detect_batch(frames)
+    det.clock_sampling(True)
+    for _ in range(6):
+        got = det.detect_batch(frames)
+    mean, lo, hi, n = det.clock_read()
+    assert n == 6 and 0.3 < lo <= mean <= hi < 2.6, (mean, lo, hi, n)
+    assert det.clock_read()[3] == 0                                   # read resets
+    det.clock_sampling(False)
+    det.detect_batch(frames)
+    assert det.clock_read()[3] == 0
+    for a, b in zip(ref, got):
+        assert np.array_equal(a.xyxy.view(np.int32), b.xyxy.view(np.int32)) and a.class_id.tolist() == b.class_id.tolist()
+    det.close()

@@ -232,6 +232,15 @@ static int run_conv3(int tile, int cin, int cout, int stride, int HWin, int B, i
         for (int g = 0; g < wgs; ++g) { const unsigned long long *s2 = &st[(size_t)g * 16]; if (s2[6] && s2[0]) d.push_back((double)(s2[6] - s2[0])); }
         std::sort(d.begin(), d.end());
         if (!d.empty()) printf("  workgroup life median %.0f clk, %d workgroups stamped\n", d[d.size() / 2], live);
+        {   // in-kernel shader clock: s_memtime ticks per s_memrealtime tick (100 MHz), per workgroup, median
+            std::vector<double> ghz;
+            for (int gidx = 0; gidx < wgs; ++gidx) {
+                const unsigned long long *s = &st[(size_t)gidx * 16];
+                if (s[15] > s[13] && s[14] > s[12]) ghz.push_back((double)(s[14] - s[12]) / (double)(s[15] - s[13]) * 0.1);
+            }
+            std::sort(ghz.begin(), ghz.end());
+            if (!ghz.empty()) printf("  in-kernel shader clock (s_memtime / s_memrealtime): median %.3f GHz (min %.3f, max %.3f)\n", ghz[ghz.size() / 2], ghz.front(), ghz.back());
+        }
     }
     hipFree(in); hipFree(out); hipFree(w); hipFree(wt); hipFree(bias); hipFree(d_st);
     return 0;
