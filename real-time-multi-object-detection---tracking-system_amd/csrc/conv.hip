@@ -511,7 +511,7 @@ __device__ __forceinline__ void conv_mfma_body(const ConvArgs &p, const int bx, 
 template <int BM, int BN, int WM, int WN, int NSTAGE, int N2T = 0>
 __device__ __forceinline__ void conv_mfma64_body(const ConvArgs &p, const int bx, const int by) {
     constexpr int NW = WM * WN;                             // waves per workgroup: the DMA path sustains ~5 B/clk PER WAVE (tools/probes/dma_probe),
-    static_assert(NW == 4 || NW == 8, "4 or 8 waves");      // so the big tiles run 8 waves to issue their operands twice as fast
+    static_assert(NW == 4 || NW == 8 || NW == 16, "4, 8 or 16 waves");      // so the big tiles run 8 (16) waves to issue their operands twice (four times) as fast
     static_assert(N2T == 0 || NW == 4, "the fused tail is written for 4 waves");
     static_assert(BM % 32 == 0 && BN % 32 == 0, "tile shape");
     constexpr int NA = BM / 8, NB = BN / 8, NP = NA + NB;   // pieces per k-step
@@ -1409,6 +1409,8 @@ __global__ __launch_bounds__(256) void conv_mfma64_tail(ConvArgs p) { conv_mfma6
 template <int BM, int BN, int WM, int WN, int NSTAGE>
 __global__ __launch_bounds__(512) void conv_mfma64_w8(ConvArgs p) { conv_mfma64_body<BM, BN, WM, WN, NSTAGE>(p, blockIdx.x, blockIdx.y); }
 template <int BM, int BN, int WM, int WN, int NSTAGE>
+__global__ __launch_bounds__(1024) void conv_mfma64_w16(ConvArgs p) { conv_mfma64_body<BM, BN, WM, WN, NSTAGE>(p, blockIdx.x, blockIdx.y); }
+template <int BM, int BN, int WM, int WN, int NSTAGE>
 __global__ __launch_bounds__(256) void conv_mfma64(ConvArgs p) { conv_mfma64_body<BM, BN, WM, WN, NSTAGE>(p, blockIdx.x, blockIdx.y); }
 template <int BM, int BN, int WM, int WN, int NSTAGE>
 __global__ __launch_bounds__(256) void conv_mfma64_grp(ConvGroupArgs g) {
@@ -1454,7 +1456,7 @@ const char *tile_name(int tile) {
                                             "k64:128x128s2/8w", "k64:128x128s3/8w", "k64:256x128s2/8w", "k64:128x64s3/8w", "k64:256x64s2/8w",
                                             "rows:128x64/8w", "rows:256x64/8w", "rows64:128x128/8w", "rows64:256x64/8w",
                                             "ws:128x128", "ws:128x64", "pt:128x128s2", "pt:128x128s3", "pt:128x64s3", "pt:128x64s2",
-                                            "k64:256x128s3/8w", "k64:256x256s2/8w", "rows-pt:256x64", "rows-pt:128x64", "rows64-pt:256x64"};
+                                            "k64:256x128s3/8w", "k64:256x256s2/8w", "rows-pt:256x64", "rows-pt:128x64", "rows64-pt:256x64", "k64:256x128s3/16w"};
     return tile >= 0 && tile < TILE_COUNT ? names[tile] : "?";
 }
 
@@ -1463,7 +1465,7 @@ bool tile_needs_cin64(int tile) {
            tile == TILE_TAIL_K64_128x128 || tile == TILE_TAIL_K64_64x128 || (tile >= TILE_K64_128x128_S2_W8 && tile <= TILE_K64_256x64_S2_W8) ||
            tile == TILE_ROWS_K64_128x128_W8 || tile == TILE_ROWS_K64_256x64_W8 || tile == TILE_ROWS_PT_K64_256x64 || tile_is_ws(tile) || tile_is_pt(tile) || tile_is_w8(tile);
 }
-bool tile_is_w8(int tile) { return (tile >= TILE_K64_128x128_S2_W8 && tile <= TILE_K64_256x64_S2_W8) || tile == TILE_K64_256x128_S3_W8 || tile == TILE_K64_256x256_S2_W8; }
+bool tile_is_w8(int tile) { return (tile >= TILE_K64_128x128_S2_W8 && tile <= TILE_K64_256x64_S2_W8) || tile == TILE_K64_256x128_S3_W8 || tile == TILE_K64_256x256_S2_W8 || tile == TILE_K64_256x128_S3_W16; }
 bool tile_is_ws(int tile) { return tile == TILE_WS_128x128 || tile == TILE_WS_128x64; }
 bool tile_is_pt(int tile) { return tile >= TILE_PT_128x128_S2 && tile <= TILE_PT_128x64_S2; }
 // resident weight slice (kp/64 x BN/8 KiB) + the pixel ring (3 x 16 KiB) within 156 KiB of LDS
@@ -1518,6 +1520,7 @@ TileShape tile_shape(int tile) {
         case TILE_PT_128x64_S3: case TILE_PT_128x64_S2: return {128, 64};
         case TILE_K64_256x128_S3_W8: return {256, 128};
         case TILE_K64_256x256_S2_W8: return {256, 256};
+        case TILE_K64_256x128_S3_W16: return {256, 128};
         case TILE_ROWS_PT_256x64: case TILE_ROWS_PT_K64_256x64: return {256, 64};
         case TILE_ROWS_PT_128x64: return {128, 64};
     }
@@ -1817,6 +1820,10 @@ int launch_conv_group(const ConvLaunch *c, int n, int tile, hipStream_t s) {
         case TILE_ROWS_PT_K64_256x64: launch_rows_pt<256, 64, 4, 2, true>(l, s); break;
         case TILE_K64_256x128_S3_W8: RT_TRY((launch_k64_w8<256, 128, 4, 2, 3>(l, s))); break;
         case TILE_K64_256x256_S2_W8: RT_TRY((launch_k64_w8<256, 256, 4, 2, 2>(l, s))); break;
+        case TILE_K64_256x128_S3_W16:
+            RT_CHECK(l.n == 1, RTMODT_E_INVALID, "launch_conv: the 16-wave tiles run single problems");
+            hipLaunchKernelGGL((conv_mfma64_w16<256, 128, 8, 2, 3>), l.grid(256, 128), dim3(1024), 0, s, l.a[0]);
+            break;
         case TILE_WS_128x128: RT_TRY(launch_ws<128>(l, s)); break;
         case TILE_WS_128x64: RT_TRY(launch_ws<64>(l, s)); break;
         case TILE_PT_128x128_S2: RT_TRY((launch_pt<128, 2>(l, s))); break;

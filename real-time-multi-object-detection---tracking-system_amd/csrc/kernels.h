@@ -62,7 +62,9 @@ enum ConvTile {
     TILE_K64_256x128_S3_W8 = 48, TILE_K64_256x256_S2_W8 = 49,
     // PERSISTENT tap-reuse kernel (8 waves): a workgroup walks over the tiles of the (grouped) launch, the next tile's first operands in flight under this tile's last step and epilogue
     TILE_ROWS_PT_256x64 = 50, TILE_ROWS_PT_128x64 = 51, TILE_ROWS_PT_K64_256x64 = 52,
-    TILE_COUNT = 53
+    // the big tiles with SIXTEEN waves (one 1024-thread workgroup per CU): the LDS-DMA path sustains ~5 B/clk per issuing wave
+    TILE_K64_256x128_S3_W16 = 53,
+    TILE_COUNT = 54
 };
 const char *tile_name(int tile);
 bool tile_needs_cin64(int tile);
