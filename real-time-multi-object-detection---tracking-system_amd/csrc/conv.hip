@@ -1055,9 +1055,10 @@ __global__ __launch_bounds__(512) void conv1x1_ws(ConvArgs p, int groups) {
 // cout % BN == 0), any kernel size / stride, no residual / second destination / half-resolution source.
 // Same MFMA order per output as conv_mfma64 (k ascending), same swizzled piece layout.
 // ---------------------------------------------------------------------------------------
-template <int BN, int NSTAGE>
-__global__ __launch_bounds__(512) void conv_mfma64_pt(ConvArgs p, int groups) {
-    constexpr int BM = 128, NW = 8, WM = 4, WN = 2;
+template <int BN, int NSTAGE, int BM = 128, int NW = 8>
+__global__ __launch_bounds__(NW * 64) void conv_mfma64_pt(ConvArgs p, int groups) {
+    constexpr int WM = NW / 2, WN = 2;                      // 8 waves on 128 x BN (two workgroups per CU) or 16 waves on 256 x BN (one, three stages)
+    static_assert(BM % (WM * 16) == 0 && (BM / 8) % NW == 0, "pixel tile must split over the waves");
     constexpr int NA = BM / 8, NB = BN / 8, LA = NA / NW, LBp = NB / NW, L = LA + LBp;
     constexpr int DEPTH = NSTAGE - 1;
     constexpr int STAGE = (NA + NB) * 1024;
@@ -1456,7 +1457,7 @@ const char *tile_name(int tile) {
                                             "k64:128x128s2/8w", "k64:128x128s3/8w", "k64:256x128s2/8w", "k64:128x64s3/8w", "k64:256x64s2/8w",
                                             "rows:128x64/8w", "rows:256x64/8w", "rows64:128x128/8w", "rows64:256x64/8w",
                                             "ws:128x128", "ws:128x64", "pt:128x128s2", "pt:128x128s3", "pt:128x64s3", "pt:128x64s2",
-                                            "k64:256x128s3/8w", "k64:256x256s2/8w", "rows-pt:256x64", "rows-pt:128x64", "rows64-pt:256x64", "k64:256x128s3/16w"};
+                                            "k64:256x128s3/8w", "k64:256x256s2/8w", "rows-pt:256x64", "rows-pt:128x64", "rows64-pt:256x64", "k64:256x128s3/16w", "pt:256x128s3/16w"};
     return tile >= 0 && tile < TILE_COUNT ? names[tile] : "?";
 }
 
@@ -1467,7 +1468,7 @@ bool tile_needs_cin64(int tile) {
 }
 bool tile_is_w8(int tile) { return (tile >= TILE_K64_128x128_S2_W8 && tile <= TILE_K64_256x64_S2_W8) || tile == TILE_K64_256x128_S3_W8 || tile == TILE_K64_256x256_S2_W8 || tile == TILE_K64_256x128_S3_W16; }
 bool tile_is_ws(int tile) { return tile == TILE_WS_128x128 || tile == TILE_WS_128x64; }
-bool tile_is_pt(int tile) { return tile >= TILE_PT_128x128_S2 && tile <= TILE_PT_128x64_S2; }
+bool tile_is_pt(int tile) { return (tile >= TILE_PT_128x128_S2 && tile <= TILE_PT_128x64_S2) || tile == TILE_PT_256x128_S3_W16; }
 // resident weight slice (kp/64 x BN/8 KiB) + the pixel ring (3 x 16 KiB) within 156 KiB of LDS
 bool tile_ws_fits(int tile, int kp) { return tile_is_ws(tile) && (kp / 64) * (tile_shape(tile).bn / 8) + 3 * 16 <= 156; }
 bool tile_is_tail(int tile) { return tile >= TILE_TAIL_128x64 && tile <= TILE_TAIL_K64_64x128; }
@@ -1520,7 +1521,7 @@ TileShape tile_shape(int tile) {
         case TILE_PT_128x64_S3: case TILE_PT_128x64_S2: return {128, 64};
         case TILE_K64_256x128_S3_W8: return {256, 128};
         case TILE_K64_256x256_S2_W8: return {256, 256};
-        case TILE_K64_256x128_S3_W16: return {256, 128};
+        case TILE_K64_256x128_S3_W16: case TILE_PT_256x128_S3_W16: return {256, 128};
         case TILE_ROWS_PT_256x64: case TILE_ROWS_PT_K64_256x64: return {256, 64};
         case TILE_ROWS_PT_128x64: return {128, 64};
     }
@@ -1633,15 +1634,15 @@ static int launch_ws(const LaunchPlan &l, hipStream_t s) {
     }
 }
 
-template <int BN, int NSTAGE>
+template <int BN, int NSTAGE, int BM = 128, int NW = 8>
 static int launch_pt(const LaunchPlan &l, hipStream_t s) {
     const ConvArgs &a = l.a[0];
-    RT_CHECK(l.n == 1 && !l.general && a.cin % 64 == 0 && a.kp % 64 == 0 && a.M % 128 == 0 && a.cout % BN == 0 && !a.out2 && a.epi16,
-             RTMODT_E_INVALID, "launch_conv: the persistent tile runs one conv with cin %% 64 == 0, full tiles (M %% 128 == 0, cout %% BN == 0), no second destination");
-    const int slices = a.cout / BN, n_mt = a.M / 128;
-    constexpr int per_cu = (160 * 1024) / (NSTAGE * (128 / 8 + BN / 8) * 1024);          // workgroups of this kernel that fit one CU's LDS
+    RT_CHECK(l.n == 1 && !l.general && a.cin % 64 == 0 && a.kp % 64 == 0 && a.M % BM == 0 && a.cout % BN == 0 && !a.out2 && a.epi16,
+             RTMODT_E_INVALID, "launch_conv: the persistent tile runs one conv with cin %% 64 == 0, full tiles (M %% %d == 0, cout %% BN == 0), no second destination", BM);
+    const int slices = a.cout / BN, n_mt = a.M / BM;
+    constexpr int per_cu = (160 * 1024) / (NSTAGE * (BM / 8 + BN / 8) * 1024);          // workgroups of this kernel that fit one CU's LDS
     const int groups = std::max(1, std::min(n_mt, per_cu * 256 / slices));
-    hipLaunchKernelGGL((conv_mfma64_pt<BN, NSTAGE>), dim3(groups, slices), dim3(512), 0, s, a, groups);
+    hipLaunchKernelGGL((conv_mfma64_pt<BN, NSTAGE, BM, NW>), dim3(groups, slices), dim3(NW * 64), 0, s, a, groups);
     return RTMODT_OK;
 }
 
@@ -1830,6 +1831,7 @@ int launch_conv_group(const ConvLaunch *c, int n, int tile, hipStream_t s) {
         case TILE_PT_128x128_S3: RT_TRY((launch_pt<128, 3>(l, s))); break;
         case TILE_PT_128x64_S3: RT_TRY((launch_pt<64, 3>(l, s))); break;
         case TILE_PT_128x64_S2: RT_TRY((launch_pt<64, 2>(l, s))); break;
+        case TILE_PT_256x128_S3_W16: RT_TRY((launch_pt<128, 3, 256, 16>(l, s))); break;
         case TILE_TAIL_128x64: hipLaunchKernelGGL((conv_mfma_tail<128, 64, 2, 2, 3, 4>), l.grid(128, 64), dim3(256), 0, s, a[0]); break;
         case TILE_TAIL_64x64: hipLaunchKernelGGL((conv_mfma_tail<64, 64, 2, 2, 3, 4>), l.grid(64, 64), dim3(256), 0, s, a[0]); break;
         case TILE_TAIL_K64_128x128: hipLaunchKernelGGL((conv_mfma64_tail<128, 128, 4, 1, 2, 8>), l.grid(128, 128), dim3(256), 0, s, a[0]); break;

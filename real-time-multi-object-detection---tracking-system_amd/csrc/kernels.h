@@ -64,7 +64,8 @@ enum ConvTile {
     TILE_ROWS_PT_256x64 = 50, TILE_ROWS_PT_128x64 = 51, TILE_ROWS_PT_K64_256x64 = 52,
     // the big tiles with SIXTEEN waves (one 1024-thread workgroup per CU): the LDS-DMA path sustains ~5 B/clk per issuing wave
     TILE_K64_256x128_S3_W16 = 53,
-    TILE_COUNT = 54
+    TILE_PT_256x128_S3_W16 = 54,                    // ... and the persistent tile kernel on that shape (cross-tile prefetch through a three-stage ring, one workgroup per CU)
+    TILE_COUNT = 55
 };
 const char *tile_name(int tile);
 bool tile_needs_cin64(int tile);

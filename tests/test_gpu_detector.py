@@ -1168,7 +1168,8 @@ def test_weight_stationary_1x1_tiles(pkg, wdir, monkeypatch, tile, size, batch):
 @pytest.mark.parametrize("tile,size,batch,up_read,scale", [(44, 320, 32, "0", "s"), (45, 320, 32, "1", "s"), (46, 320, 32, "1", "s"), (47, 320, 32, "0", "s"),
                                                                  (44, 640, 8, "1", "s"), (45, 288, 3, "0", "s"),
                                                                  (44, 64, 8, "1", "s"), (47, 64, 24, "0", "s"),      # 64 x 64: one to twelve pixel tiles per conv -- fewer workgroups than XCDs
-                                                                 (44, 320, 8, "1", "m"), (47, 320, 16, "1", "n")])   # other channel counts (m: 192 / 384 / 576, n: 64 / 128 / 256)
+                                                                 (44, 320, 8, "1", "m"), (47, 320, 16, "1", "n"),   # other channel counts (m: 192 / 384 / 576, n: 64 / 128 / 256)
+                                                                 (54, 320, 32, "1", "s"), (54, 640, 8, "0", "s"), (54, 320, 16, "1", "m")])          # 256 x 128, 16 waves, three stages
 def test_persistent_tile_kernel(pkg, wdir, monkeypatch, tile, size, batch, up_read, scale):
     """conv_mfma64_pt: a persistent workgroup walks over pixel tiles of one cout slice; the stage ring keeps prefetching
     across tile boundaries and the epilogue stores straight from the accumulators.  Forced onto every conv where it is legal
