@@ -1640,7 +1640,10 @@ static int launch_pt(const LaunchPlan &l, hipStream_t s) {
     RT_CHECK(l.n == 1 && !l.general && a.cin % 64 == 0 && a.kp % 64 == 0 && a.M % BM == 0 && a.cout % BN == 0 && !a.out2 && a.epi16,
              RTMODT_E_INVALID, "launch_conv: the persistent tile runs one conv with cin %% 64 == 0, full tiles (M %% %d == 0, cout %% BN == 0), no second destination", BM);
     const int slices = a.cout / BN, n_mt = a.M / BM;
-    constexpr int per_cu = (160 * 1024) / (NSTAGE * (BM / 8 + BN / 8) * 1024);          // workgroups of this kernel that fit one CU's LDS
+    constexpr int per_cu_lds = (160 * 1024) / (NSTAGE * (BM / 8 + BN / 8) * 1024);      // workgroups of this kernel that fit one CU's LDS
+    // experiment hook (RTMODT_PT_PER_CU=1): one persistent workgroup per CU leaves the CU's other slot to the launches of the other stages
+    static const int per_cu_env = getenv("RTMODT_PT_PER_CU") ? atoi(getenv("RTMODT_PT_PER_CU")) : 0;
+    const int per_cu = per_cu_env > 0 ? std::min(per_cu_env, per_cu_lds) : per_cu_lds;
     const int groups = std::max(1, std::min(n_mt, per_cu * 256 / slices));
     hipLaunchKernelGGL((conv_mfma64_pt<BN, NSTAGE, BM, NW>), dim3(groups, slices), dim3(NW * 64), 0, s, a, groups);
     return RTMODT_OK;
