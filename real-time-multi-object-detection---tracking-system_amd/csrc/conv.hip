@@ -51,7 +51,8 @@ struct ConvArgs {
     int res_Hp, res_Wp, res_cs, res_pad;
     int Ho, Wo, M;                       // M = B*Ho*Wo
     FastDiv d_howo, d_wo;                // m -> (image, row, column) of the output
-    FastDiv d_hwp, d_wp;                 // the same over the PADDED input grid (tap-reuse kernel)
+    FastDiv d_hwp, d_wp;                 // tap-reuse kernel: division by Ho * in_Wp (the positions of one image it enumerates) and by in_Wp
+    int last_pos;                        // tap-reuse kernel: index of the last padded position of the input tensor (B * in_Hp * in_Wp - 1)
     f16 *out2;                           // optional second destination: nearest-2x upsampled copy (neck concat slice)
     int out2_Hp, out2_Wp, out2_cs, out2_pad;
     int cin, cout, ks, stride, act, kp, K;
@@ -661,7 +662,11 @@ __device__ __forceinline__ void conv3x3_rows_body(const ConvArgs &p, const int b
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r = lane & 15, q = lane >> 4;
-    const int Mp = p.M;                            // = B * in_Hp * in_Wp (padded positions)
+    // The GEMM rows enumerate the padded positions of the image ROWS THAT HOLD OUTPUTS: m = (b * Ho + oy) * in_Wp + x, x in [0, in_Wp) -- the
+    // two junk columns per row are what tap reuse costs, the top and bottom border rows are simply not enumerated (round 3: -2.4 / -4.8 /
+    // -9.1 % GEMM rows at 80 / 40 / 20 pixels).  Output (oy, ox) reads padded input rows oy .. oy + 2, so position m sits at padded index
+    // pos(m) = m + 2 * in_Wp * b; pos(m + kw) == pos(m) + kw for every real output (x + 2 < in_Wp), which is all the strip reuse needs.
+    const int Mp = p.M;                            // = B * Ho * in_Wp
     int mt, nt;
     xcd_tile((Mp + BM - 1) / BM, (p.cout + BN - 1) / BN, bx, by, mt, nt);
     const int m0 = mt * BM, n0 = nt * BN;
@@ -686,13 +691,14 @@ __device__ __forceinline__ void conv3x3_rows_body(const ConvArgs &p, const int b
     // per-wave piece lists: strip pieces wave, wave+4, ...; weight pieces likewise over 3*NBT
     constexpr int LA = (NAS + NW - 1) / NW, LB = (3 * NBT + NW - 1) / NW;
     int a_off[LA], b_off[LB];
-    const int last_pix = Mp - 1;
+    const int last_pix = p.last_pos;
 #pragma unroll
     for (int i = 0; i < LA; ++i) {
         int R = (wave + NW * i) * RP + ld_row;                 // strip row
         int chunk = K64 ? (ld_slot ^ ((R >> 1) & 7)) : (ld_slot ^ swz16(R));
         // pixel index is clamped per tap row at issue time; keep row and chunk parts separate
-        a_off[i] = (m0 + R) | (chunk << 28);
+        const int mm = min(m0 + R, Mp - 1);
+        a_off[i] = (mm + 2 * p.in_Wp * fdiv(mm, p.d_hwp)) | (chunk << 28);
     }
 #pragma unroll
     for (int i = 0; i < LB; ++i) {
@@ -763,7 +769,7 @@ __device__ __forceinline__ void conv3x3_rows_body(const ConvArgs &p, const int b
 
     STAMP(5);
     // ---- epilogue: padded position -> (b, y, x); border rows/columns are junk ----
-    const int HW = p.in_Hp * p.in_Wp;
+    const int HW = p.Ho * p.in_Wp;
     if (p.epi16 > 1) {                                     // measured: the extra LDS round trip costs this MFMA-heavier kernel more than its stores do
         epilogue_lds<BM, BN, TM, TN, NW * 64>(p, n0, acc, bv, lds, wm, wn, [&](int pm, long &opix, long &rpix, long &opix2) {
             const int m = m0 + pm;
@@ -1295,7 +1301,8 @@ __global__ __launch_bounds__(512) void conv3x3_rows_stream(ConvGroupArgs g, int 
         for (int i = 0; i < LA; ++i) {
             const int R = (wave + NW * i) * RP + ld_row;
             const int chunk = K64 ? (ld_slot ^ ((R >> 1) & 7)) : (ld_slot ^ swz16(R));
-            t.a_off[i] = (t.m0 + R) | (chunk << 28);
+            const int mm = min(t.m0 + R, p.M - 1);             // position -> padded index: two border rows per image are not enumerated
+            t.a_off[i] = (mm + 2 * p.in_Wp * fdiv(mm, p.d_hwp)) | (chunk << 28);
         }
 #pragma unroll
         for (int i = 0; i < LB; ++i) {
@@ -1314,7 +1321,7 @@ __global__ __launch_bounds__(512) void conv3x3_rows_stream(ConvGroupArgs g, int 
     auto issue = [&](Tile &t, int stage) {                    // the super-step (t.kh, t.c0) of tile t -> ring stage
         const ConvArgs &p = g.p[t.z];
         unsigned char *sbase = lds + stage * STAGE;
-        const int row_shift = t.kh * p.in_Wp, last_pix = p.M - 1;
+        const int row_shift = t.kh * p.in_Wp, last_pix = p.last_pos;
 #pragma unroll
         for (int i = 0; i < LA; ++i) {
             if (wave + NW * i < NAS) {
@@ -1371,7 +1378,7 @@ __global__ __launch_bounds__(512) void conv3x3_rows_stream(ConvGroupArgs g, int 
             stage ^= 1;
         }
         // ---- epilogue: padded position -> (b, y, x); border rows / columns are junk (conv3x3_rows_body's direct-store path) ----
-        const int HW = p.in_Hp * p.in_Wp;
+        const int HW = p.Ho * p.in_Wp;
 #pragma unroll
         for (int t = 0; t < TM; ++t) {
             const int m = cur.m0 + (wm * TM + t) * 16 + r;
@@ -1720,7 +1727,8 @@ static int make_args(const ConvLaunch &c, ConvArgs &a) {
     }
     a.M = c.B * a.Ho * a.Wo;
     a.d_howo = make_fastdiv(a.Ho * a.Wo); a.d_wo = make_fastdiv(a.Wo);
-    a.d_hwp = make_fastdiv(a.in_Hp * a.in_Wp); a.d_wp = make_fastdiv(a.in_Wp);
+    a.d_hwp = make_fastdiv(a.in_Hp * a.in_Wp); a.d_wp = make_fastdiv(a.in_Wp);      // (d_hwp is re-made for the tap-reuse tiles: launch_conv_group)
+    a.last_pos = 0;
     a.cin = c.cin; a.cout = c.cout; a.ks = c.ks; a.stride = c.stride; a.act = c.act;
     a.K = c.ks * c.ks * c.cin;
     a.kp = c.kp;
@@ -1761,8 +1769,10 @@ int launch_conv_group(const ConvLaunch *c, int n, int tile, hipStream_t s) {
         for (int i = 0; i < n; ++i) {
             RT_CHECK(c[i].ks == 3 && c[i].stride == 1 && c[i].in.pad == 1 && c[i].cin % bk == 0, RTMODT_E_INVALID,
                      "launch_conv: tile %s needs a 3x3 stride-1 conv on a bordered input with cin %% %d == 0", tile_name(tile), bk);
-            a[i].M = c[i].B * a[i].in_Hp * a[i].in_Wp;       // the GEMM runs over padded positions
-            RT_CHECK((long)a[i].M * a[i].in_cs < (1L << 31) && a[i].M < (1 << 28), RTMODT_E_INVALID, "launch_conv: tensor exceeds 2^31 elements");
+            a[i].M = c[i].B * a[i].Ho * a[i].in_Wp;          // the GEMM runs over the padded positions of the rows that hold outputs
+            a[i].d_hwp = make_fastdiv(a[i].Ho * a[i].in_Wp);
+            a[i].last_pos = c[i].B * a[i].in_Hp * a[i].in_Wp - 1;
+            RT_CHECK((long)(a[i].last_pos + 1) * a[i].in_cs < (1L << 31) && a[i].last_pos + 1 < (1 << 28), RTMODT_E_INVALID, "launch_conv: tensor exceeds 2^31 elements");
         }
     }
     if (tile_is_tail(tile)) {
