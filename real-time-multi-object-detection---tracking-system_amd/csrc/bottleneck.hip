@@ -67,15 +67,15 @@ struct BneckGeom {
     static constexpr int SUB = CW / 32;                   // MFMA k-substeps per (tap, plane)
     static constexpr int NT = CH / 16;                    // cout tiles
     static constexpr int PW = TW + 4, PH = TH + 4;        // input patch
-    static constexpr int P_PIX = PW * PH, P_ROWS = (P_PIX + 2 + RPP - 1) / RPP * RPP;   // + 2: conv1's junk columns read two rows past the patch (zero-filled)
+    static constexpr int P_PIX = PW * PH, P_ROWS = (P_PIX + RPP - 1) / RPP * RPP;
     static constexpr int IW = TW + 2, IH = TH + 2;        // intermediate (halo 1)
     static constexpr int M1 = IW * IH, M1T = (M1 + 15) / 16, T_ROWS = M1T * 16;
-    // conv1's GEMM rows enumerate PATCH positions of the first IH patch rows (all PW columns, the two right-most are junk that is
-    // never stored): an m-tile is then 16 CONSECUTIVE rows of the patch image whatever the tap -- no jump where the halo-1 region
-    // wraps to its next row -- which is what the swizzle above needs; 11 % more rows, the same number of m-tiles per wave
-    static constexpr int M1P = PW * IH, M1PT = (M1P + 15) / 16;
+    // (conv1's m-tiles wrap inside the halo-1 region, IW = TW + 2 wide in a PW-wide patch image: one jump of 2 rows per wrapping tile, the
+    // only fragment reads left with a 2-way conflict -- 1.71 LDS cycles per group against 2.06 before; enumerating all PW columns instead
+    // makes every read conflict-free at the price of 11 % more conv1 rows (MFMA + SiLU work, i.e. energy) and was measured not to change
+    // the launch time either way: not kept)
     static constexpr int M2 = TW * TH, M2T = M2 / 16;
-    static constexpr int TM1 = (M1PT + BN_WAVES - 1) / BN_WAVES, TM2 = (M2T + BN_WAVES - 1) / BN_WAVES;
+    static constexpr int TM1 = (M1T + BN_WAVES - 1) / BN_WAVES, TM2 = (M2T + BN_WAVES - 1) / BN_WAVES;
     static constexpr int W_PIECES = CH / RPP;             // DMA pieces per (tap, plane) of weights
     static constexpr int W_STEP = CH * CB;                // bytes of one weight unit: (tap, plane)
     static constexpr bool ALLW = CH == 32;                // a conv's whole weight matrix (18 KiB) sits in ONE LDS buffer: no ring, no barrier in the k-loop
@@ -230,9 +230,11 @@ __global__ __launch_bounds__(BN_THREADS) void bottleneck_fused(BneckArgs p) {
 #pragma unroll
         for (int i = 0; i < G::TM1; ++i) {
             int t = wave + BN_WAVES * i;
-            int m = t * 16 + r;                                  // patch position (row-major over PW columns)
-            mrow[i] = t < G::M1PT ? m : -1;
-            pb[i] = m < G::M1P ? m : G::M1P - 1;                // padding rows of the last tile re-read a valid position
+            int m = t * 16 + r;
+            mrow[i] = t < G::M1T ? m : -1;
+            m = m < G::M1 ? m : G::M1 - 1;                      // padding rows of the last tile re-read a valid pixel
+            int iy = m / G::IW, ix = m - iy * G::IW;
+            pb[i] = iy * G::PW + ix;
         }
         floatx4 acc[G::TM1][NT];
 #pragma unroll
@@ -255,11 +257,9 @@ __global__ __launch_bounds__(BN_THREADS) void bottleneck_fused(BneckArgs p) {
         // epilogue 1: SiLU -> fp16 -> tbuf; positions outside the image are conv2's zero padding
 #pragma unroll
         for (int i = 0; i < G::TM1; ++i) {
-            const int mp = mrow[i];
-            if (mp < 0 || mp >= G::M1P) continue;
-            const int iy = mp / G::PW, ix = mp - iy * G::PW;
-            if (ix >= G::IW) continue;                           // the patch's two right-most columns: not part of the halo-1 region
-            const int m = iy * G::IW + ix;                      // row of the intermediate image
+            const int m = mrow[i];
+            if (m < 0 || m >= G::M1) continue;
+            const int iy = m / G::IW, ix = m - iy * G::IW;
             const int gy = y0 - 1 + iy, gx = x0 - 1 + ix;
             const bool inside = gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
 #pragma unroll
