@@ -51,7 +51,8 @@ struct ConvArgs {
     int res_Hp, res_Wp, res_cs, res_pad;
     int Ho, Wo, M;                       // M = B*Ho*Wo
     FastDiv d_howo, d_wo;                // m -> (image, row, column) of the output
-    FastDiv d_hwp, d_wp;                 // tap-reuse kernel: division by Ho * in_Wp (the positions of one image it enumerates) and by in_Wp
+    FastDiv d_hwp, d_wp;                 // tap-reuse kernel: division by Ho * rows_wq (the positions of one image it enumerates) and by rows_wq
+    int rows_wq;                         // tap-reuse kernel: positions enumerated per image row = in_Wp - 1 (the right border column is skipped)
     int last_pos;                        // tap-reuse kernel: index of the last padded position of the input tensor (B * in_Hp * in_Wp - 1)
     f16 *out2;                           // optional second destination: nearest-2x upsampled copy (neck concat slice)
     int out2_Hp, out2_Wp, out2_cs, out2_pad;
@@ -643,6 +644,14 @@ __device__ __forceinline__ void conv_mfma64_body(const ConvArgs &p, const int bx
 // Two LDS stages (a super-step is long enough to cover one DMA batch), vmcnt(0) + one barrier
 // per super-step.  Requires stride 1, input border 1, cin % BK == 0.
 // ---------------------------------------------------------------------------------------
+// tap-reuse kernels: enumerated position m -> index of that pixel in the padded input tensor (not clamped: positions past the last image map
+// past the tensor and are clamped to its last -- border, zero -- position where they are used)
+__device__ __forceinline__ int rows_pos(const ConvArgs &p, int m) {
+    const int b = fdiv(m, p.d_hwp), rem = m - b * (p.Ho * p.rows_wq);
+    const int oy = fdiv(rem, p.d_wp), x = rem - oy * p.rows_wq;
+    return (b * p.in_Hp + oy) * p.in_Wp + x;
+}
+
 template <int BM, int BN, int WM, int WN, bool K64>
 __device__ __forceinline__ void conv3x3_rows_body(const ConvArgs &p, const int bx, const int by) {
     constexpr int NW = WM * WN;                     // 4 or 8 waves per workgroup (8: the DMA pieces of a super-step are issued by twice as many waves)
@@ -662,11 +671,14 @@ __device__ __forceinline__ void conv3x3_rows_body(const ConvArgs &p, const int b
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r = lane & 15, q = lane >> 4;
-    // The GEMM rows enumerate the padded positions of the image ROWS THAT HOLD OUTPUTS: m = (b * Ho + oy) * in_Wp + x, x in [0, in_Wp) -- the
-    // two junk columns per row are what tap reuse costs, the top and bottom border rows are simply not enumerated (round 3: -2.4 / -4.8 /
-    // -9.1 % GEMM rows at 80 / 40 / 20 pixels).  Output (oy, ox) reads padded input rows oy .. oy + 2, so position m sits at padded index
-    // pos(m) = m + 2 * in_Wp * b; pos(m + kw) == pos(m) + kw for every real output (x + 2 < in_Wp), which is all the strip reuse needs.
-    const int Mp = p.M;                            // = B * Ho * in_Wp
+    // The GEMM rows enumerate padded positions m = (b * Ho + oy) * Wq + x with x in [0, Wq), Wq = in_Wp - 1: the image ROWS THAT HOLD
+    // OUTPUTS (the top and bottom border rows are not enumerated) and every column but the right border (round 3: -3.6 / -7.0 / -13.2 % GEMM
+    // rows at 80 / 40 / 20 pixels against all (H + 2) x (W + 2) positions).  Output (oy, ox) reads padded input (oy + kh, ox + kw), so
+    // position m sits at padded index pos(m) = (b * in_Hp + oy) * in_Wp + x, and the strip gives tap kw the row pos(m + kw): the same
+    // as pos(m) + kw inside a row; for the last real column (x = W - 1, kw = 2) it is the LEFT border pixel of the next enumerated row
+    // instead of the right border pixel of this one -- both are zeros of the tensor's border (past the last image: clamped to the tensor's
+    // last position, a border pixel too).  One junk column (x = W) per row is what tap reuse still costs.
+    const int Mp = p.M;                            // = B * Ho * Wq
     int mt, nt;
     xcd_tile((Mp + BM - 1) / BM, (p.cout + BN - 1) / BN, bx, by, mt, nt);
     const int m0 = mt * BM, n0 = nt * BN;
@@ -697,8 +709,7 @@ __device__ __forceinline__ void conv3x3_rows_body(const ConvArgs &p, const int b
         int R = (wave + NW * i) * RP + ld_row;                 // strip row
         int chunk = K64 ? (ld_slot ^ ((R >> 1) & 7)) : (ld_slot ^ swz16(R));
         // pixel index is clamped per tap row at issue time; keep row and chunk parts separate
-        const int mm = min(m0 + R, Mp - 1);
-        a_off[i] = (mm + 2 * p.in_Wp * fdiv(mm, p.d_hwp)) | (chunk << 28);
+        a_off[i] = rows_pos(p, m0 + R) | (chunk << 28);
     }
 #pragma unroll
     for (int i = 0; i < LB; ++i) {
@@ -769,13 +780,13 @@ __device__ __forceinline__ void conv3x3_rows_body(const ConvArgs &p, const int b
 
     STAMP(5);
     // ---- epilogue: padded position -> (b, y, x); border rows/columns are junk ----
-    const int HW = p.Ho * p.in_Wp;
+    const int HW = p.Ho * p.rows_wq;
     if (p.epi16 > 1) {                                     // measured: the extra LDS round trip costs this MFMA-heavier kernel more than its stores do
         epilogue_lds<BM, BN, TM, TN, NW * 64>(p, n0, acc, bv, lds, wm, wn, [&](int pm, long &opix, long &rpix, long &opix2) {
             const int m = m0 + pm;
             if (m >= Mp) return false;
             const int b = fdiv(m, p.d_hwp), rem = m - b * HW;
-            const int oy = fdiv(rem, p.d_wp), ox = rem - oy * p.in_Wp;
+            const int oy = fdiv(rem, p.d_wp), ox = rem - oy * p.rows_wq;
             if (oy >= p.Ho || ox >= p.Wo) return false;
             opix = ((long)(b * p.out_Hp + oy + p.out_pad) * p.out_Wp + ox + p.out_pad) * p.out_cs;
             rpix = p.res ? ((long)(b * p.res_Hp + oy + p.res_pad) * p.res_Wp + ox + p.res_pad) * p.res_cs : 0;
@@ -790,7 +801,7 @@ __device__ __forceinline__ void conv3x3_rows_body(const ConvArgs &p, const int b
         int m = m0 + (wm * TM + t) * 16 + r;
         if (m >= Mp) continue;
         int b = fdiv(m, p.d_hwp), rem = m - b * HW;
-        int oy = fdiv(rem, p.d_wp), ox = rem - oy * p.in_Wp;
+        int oy = fdiv(rem, p.d_wp), ox = rem - oy * p.rows_wq;
         if (oy >= p.Ho || ox >= p.Wo) continue;
         long opix = ((long)(b * p.out_Hp + oy + p.out_pad) * p.out_Wp + ox + p.out_pad) * p.out_cs;
         long rpix = p.res ? ((long)(b * p.res_Hp + oy + p.res_pad) * p.res_Wp + ox + p.res_pad) * p.res_cs : 0;
@@ -1301,8 +1312,7 @@ __global__ __launch_bounds__(512) void conv3x3_rows_stream(ConvGroupArgs g, int 
         for (int i = 0; i < LA; ++i) {
             const int R = (wave + NW * i) * RP + ld_row;
             const int chunk = K64 ? (ld_slot ^ ((R >> 1) & 7)) : (ld_slot ^ swz16(R));
-            const int mm = min(t.m0 + R, p.M - 1);             // position -> padded index: two border rows per image are not enumerated
-            t.a_off[i] = (mm + 2 * p.in_Wp * fdiv(mm, p.d_hwp)) | (chunk << 28);
+            t.a_off[i] = rows_pos(p, t.m0 + R) | (chunk << 28);
         }
 #pragma unroll
         for (int i = 0; i < LB; ++i) {
@@ -1378,13 +1388,13 @@ __global__ __launch_bounds__(512) void conv3x3_rows_stream(ConvGroupArgs g, int 
             stage ^= 1;
         }
         // ---- epilogue: padded position -> (b, y, x); border rows / columns are junk (conv3x3_rows_body's direct-store path) ----
-        const int HW = p.Ho * p.in_Wp;
+        const int HW = p.Ho * p.rows_wq;
 #pragma unroll
         for (int t = 0; t < TM; ++t) {
             const int m = cur.m0 + (wm * TM + t) * 16 + r;
             if (m >= p.M) continue;
             const int b = fdiv(m, p.d_hwp), rem = m - b * HW;
-            const int oy = fdiv(rem, p.d_wp), ox = rem - oy * p.in_Wp;
+            const int oy = fdiv(rem, p.d_wp), ox = rem - oy * p.rows_wq;
             if (oy >= p.Ho || ox >= p.Wo) continue;
             const long opix = ((long)(b * p.out_Hp + oy + p.out_pad) * p.out_Wp + ox + p.out_pad) * p.out_cs;
             const long rpix = p.res ? ((long)(b * p.res_Hp + oy + p.res_pad) * p.res_Wp + ox + p.res_pad) * p.res_cs : 0;
@@ -1728,7 +1738,7 @@ static int make_args(const ConvLaunch &c, ConvArgs &a) {
     a.M = c.B * a.Ho * a.Wo;
     a.d_howo = make_fastdiv(a.Ho * a.Wo); a.d_wo = make_fastdiv(a.Wo);
     a.d_hwp = make_fastdiv(a.in_Hp * a.in_Wp); a.d_wp = make_fastdiv(a.in_Wp);      // (d_hwp is re-made for the tap-reuse tiles: launch_conv_group)
-    a.last_pos = 0;
+    a.last_pos = 0; a.rows_wq = a.in_Wp;
     a.cin = c.cin; a.cout = c.cout; a.ks = c.ks; a.stride = c.stride; a.act = c.act;
     a.K = c.ks * c.ks * c.cin;
     a.kp = c.kp;
@@ -1769,8 +1779,9 @@ int launch_conv_group(const ConvLaunch *c, int n, int tile, hipStream_t s) {
         for (int i = 0; i < n; ++i) {
             RT_CHECK(c[i].ks == 3 && c[i].stride == 1 && c[i].in.pad == 1 && c[i].cin % bk == 0, RTMODT_E_INVALID,
                      "launch_conv: tile %s needs a 3x3 stride-1 conv on a bordered input with cin %% %d == 0", tile_name(tile), bk);
-            a[i].M = c[i].B * a[i].Ho * a[i].in_Wp;          // the GEMM runs over the padded positions of the rows that hold outputs
-            a[i].d_hwp = make_fastdiv(a[i].Ho * a[i].in_Wp);
+            a[i].rows_wq = a[i].in_Wp - 1;                   // the GEMM runs over the padded positions of the rows that hold outputs, right border column left out
+            a[i].M = c[i].B * a[i].Ho * a[i].rows_wq;
+            a[i].d_hwp = make_fastdiv(a[i].Ho * a[i].rows_wq); a[i].d_wp = make_fastdiv(a[i].rows_wq);
             a[i].last_pos = c[i].B * a[i].in_Hp * a[i].in_Wp - 1;
             RT_CHECK((long)(a[i].last_pos + 1) * a[i].in_cs < (1L << 31) && a[i].last_pos + 1 < (1 << 28), RTMODT_E_INVALID, "launch_conv: tensor exceeds 2^31 elements");
         }
