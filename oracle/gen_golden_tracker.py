@@ -165,11 +165,55 @@ def g3_lifecycle():
     return frames
 
 
+def g8_adversarial():
+    """Ties and degenerate inputs (round 3): duplicate detections (equal IoUs: first arg-max; two tracks wanting one detection: the
+    later row is NOT retried), confidences exactly AT track_thresh (>= is high) and one ulp below, zero-area and inverted boxes
+    (negative "areas" in the reference's IoU arithmetic), huge coordinates, frames with only low-confidence detections (pass 2
+    alone), empty frames between them, more tracks than detections and the other way round."""
+    rng = np.random.default_rng(808)
+    f32 = np.float32
+    thr = f32(0.5)
+    below = np.nextafter(thr, f32(0), dtype=f32)
+    base = rng.uniform(20, 500, size=(24, 2)).astype(f32)
+    wh = rng.uniform(20, 90, size=(24, 2)).astype(f32)
+    boxes = np.concatenate([base, base + wh], axis=1).astype(f32)
+    frames = []
+    for f in range(48):
+        b = boxes + rng.normal(0, 0.6, size=boxes.shape).astype(f32) * (f % 3 != 0)      # every third frame: exactly the same boxes again
+        c = rng.uniform(0.2, 0.95, size=24).astype(f32)
+        k = rng.integers(0, 5, size=24).astype(np.int32)
+        if f % 4 == 1:                                      # duplicates: detections 0..5 appear twice, bit-identical
+            b = np.concatenate([b, b[:6]]); c = np.concatenate([c, c[:6]]); k = np.concatenate([k, k[:6]])
+        if f % 5 == 2:                                      # confidences on the threshold and one ulp below
+            c[:8] = thr; c[8:16] = below
+        if f % 6 == 3:                                      # degenerate boxes: zero width, zero height, inverted, far away
+            b[0, 2] = b[0, 0]; b[1, 3] = b[1, 1]; b[2, [0, 2]] = b[2, [2, 0]]; b[3] = b[3] + f32(1.0e6)
+        if f % 7 == 4:                                      # only low-confidence detections: pass 2 alone
+            c[:] = rng.uniform(0.05, 0.49, size=len(c)).astype(f32)
+        if f in (9, 10, 30):                                # empty frames
+            b, c, k = b[:0], c[:0], k[:0]
+        if f % 8 == 5:                                      # far fewer detections than tracks
+            b, c, k = b[:3], c[:3], k[:3]
+        if f % 9 == 6:                                      # overlapping crowd: two tracks' best column is the same detection
+            b[4:10] = b[4] + rng.normal(0, 0.3, size=(6, 4)).astype(f32)
+        frames.append((b.astype(f32), c.astype(f32), k.astype(np.int32)))
+    return frames
+
+
 def main():
     ref = load_reference()
     os.makedirs(OUT, exist_ok=True)
     import rtmodt_amd  # noqa: F401  (alias for the dashed package directory)
     synth = sys.modules["rtmodt_amd"].synth
+
+    # G8 (round 3): ties and degenerate inputs
+    fr = g8_adversarial()
+    d = run_sequence(ref, fr, full_every=4)
+    d.update(pack_inputs(fr))
+    np.savez_compressed(os.path.join(OUT, "tracker_g8_adversarial.npz"), **d)
+    if "--only-g8" in sys.argv:
+        print("tracker_g8_adversarial.npz", os.path.getsize(os.path.join(OUT, "tracker_g8_adversarial.npz")), "tracks at the end:", int(d["n_tracks"][-1]))
+        return
 
     np.savez_compressed(os.path.join(OUT, "tracker_g1_iou.npz"), **g1_iou(ref))
     np.savez_compressed(os.path.join(OUT, "tracker_g2_assign.npz"), **g2_assign(ref))

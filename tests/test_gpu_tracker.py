@@ -54,6 +54,7 @@ def run_sequence(pkg, z, frames, **params):
     ("tracker_g3c_expiry.npz", {}),
     ("tracker_g3b_params.npz", {"bytetrack": {"track_thresh": 0.6, "track_buffer": 5, "match_thresh": 0.7, "mot20": False}}),
     ("tracker_g7_ragged.npz", {}),
+    ("tracker_g8_adversarial.npz", {}),      # ties, threshold-equal confidences, zero-area / inverted boxes (round 3)
 ])
 def test_fixture_sequences(pkg, name, params):
     z = np.load(os.path.join(GOLDEN, name))

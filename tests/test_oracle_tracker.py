@@ -105,6 +105,14 @@ def test_g7_ragged():
     check_sequence(z, unpack_frames(z))
 
 
+def test_g8_adversarial():
+    """Ties and degenerate inputs run through the reference itself (oracle/gen_golden_tracker.py:g8_adversarial): duplicate detections,
+    confidences exactly at / one ulp below track_thresh, zero-area and inverted boxes, huge coordinates, low-confidence-only and
+    empty frames, crowds whose tracks share a best column."""
+    z = load("tracker_g8_adversarial.npz")
+    check_sequence(z, unpack_frames(z))
+
+
 def test_parallel_greedy_equals_sequential_on_sequences(pkg):
     xy, cf, cl = pkg.synth.box_sequence(150, 640, 40, seed=3)
     a, b = T.TrackerOracle(), T.TrackerOracle(assign="greedy_parallel")

@@ -19,6 +19,7 @@ def test_c_iou_bit_exact():
     ("tracker_g3c_expiry.npz", {}),
     ("tracker_g3b_params.npz", dict(track_thresh=0.6, track_buffer=5, match_thresh=0.7)),
     ("tracker_g7_ragged.npz", {}),
+    ("tracker_g8_adversarial.npz", {}),
 ])
 def test_c_sequences(name, params):
     z = np.load(os.path.join(GOLDEN, name))
