@@ -643,7 +643,9 @@ static int build_graph(rtmodt_detector *d, WeightFile &wf) {
             if (o.kind != OP_CONV || o.name != "1" || c.ks != 3 || c.stride != 2 || c.cin != 32 || c.cout != 64 || c.act != 1 || c.res.base || c.out2.base || c.in_lo.base) continue;
             if (c.in.pad != 1 || c.in.coff != 0 || c.in.C != 32 || c.in.W % 2 != 0 || c.out.pad != 1 || c.out.coff != 0 || c.out.C != 64 || c.out.W % 2 != 0 || c.in.W != 2 * c.out.W) continue;
             if (c.tail_wt && (c.tail_cout != 64 || c.tail_out.pad != 1 || c.tail_out.coff != 0 || c.tail_out.C < 64 || c.tail_out.C % 8 != 0 || c.tail_kp != 64)) continue;
-            const WeightRec &r = wf.recs.at("1");
+            auto rit = wf.recs.find("1");
+            if (rit == wf.recs.end() || (c.tail_wt && wf.recs.find(d->ops[i + 1].name) == wf.recs.end())) continue;
+            const WeightRec &r = rit->second;
             const int kp = 576;
             std::vector<f16> w((size_t)128 * kp, (f16)0.0f);
             std::vector<float> b(128, 0.f);
@@ -666,7 +668,7 @@ static int build_graph(rtmodt_detector *d, WeightFile &wf) {
             c.in.C = 64; c.in.c = 64; c.in.W /= 2; c.in.wp = c.in.W + 1;                 // 161 pairs per padded row, the first one = (border, pixel 0)
             c.out.base -= 64; c.out.C = 128; c.out.c = 128; c.out.W /= 2; c.out.wp = c.out.W + 1;   // 80 pairs + one pair of border pixels per padded row
             if (c.tail_wt) {
-                const WeightRec &r2 = wf.recs.at(d->ops[i + 1].name);
+                const WeightRec &r2 = wf.recs.find(d->ops[i + 1].name)->second;
                 std::vector<f16> w2((size_t)128 * 128, (f16)0.0f);
                 std::vector<float> b2(128, 0.f);
                 for (int s = 0; s < 2; ++s)
