@@ -1611,7 +1611,13 @@ static int detector_create_impl(const rtmodt_det_cfg *cfg, rtmodt_detector *d) {
     RT_CHECK(d->nc >= 1 && d->nc <= 128, RTMODT_E_UNSUPPORTED, "nc %d (1..128 supported)", d->nc);
     RT_HIP(hipSetDevice(d->device));
     RT_HIP(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking));
-    RT_HIP(hipStreamCreateWithFlags(&d->post_stream, hipStreamNonBlocking));
+    if (const char *e = getenv("RTMODT_POST_PRIO")) {     // experiment hook: the post-processing stream (one workgroup per image / stream) at another priority
+        int lo = 0, hi = 0;
+        RT_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        RT_HIP(hipStreamCreateWithPriority(&d->post_stream, hipStreamNonBlocking, atoi(e) > 0 ? hi : lo));
+    } else {
+        RT_HIP(hipStreamCreateWithFlags(&d->post_stream, hipStreamNonBlocking));
+    }
     RT_HIP(hipStreamCreateWithFlags(&d->copy_stream, hipStreamNonBlocking));
     RT_HIP(hipMalloc((void **)&d->d_zeros, 256));
     RT_HIP(hipMemset(d->d_zeros, 0, 256));
