@@ -31,7 +31,7 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ float silu_b(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+__device__ __forceinline__ float silu_b(float x) { return silu(x); }
 
 __device__ __forceinline__ void dma16(const f16 *src, unsigned char *dst) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,

@@ -41,4 +41,21 @@ static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; 
 
 typedef _Float16 f16;
 
+// SiLU of every conv epilogue: x / (1 + e^-x) as v_mul, v_exp_f32, v_add, v_rcp_f32, v_mul (the two transcendentals issue at a
+// quarter of the VALU rate).  -DRTMODT_ABLATE_SILU2 (DIAGNOSTIC build) evaluates it TWICE, on x and on x + 1e-30, and returns a value within
+// an ulp of the right one: same data, same decisions, twice the activation work -- which prices the activation in time and in clock
+// (power) without changing what the MFMAs chew on: profiles/r03/README.md, ablations.
+#if defined(__HIPCC__)
+__device__ __forceinline__ float silu(float x) {
+    const float a = x * __builtin_amdgcn_rcpf(1.0f + __expf(-x));
+#if defined(RTMODT_ABLATE_SILU2)
+    const float y = x + 1e-30f;
+    const float b = y * __builtin_amdgcn_rcpf(1.0f + __expf(-y));
+    return a + (b - a);
+#else
+    return a;
+#endif
+}
+#endif
+
 }  // namespace rtmodt

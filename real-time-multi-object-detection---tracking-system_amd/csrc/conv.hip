@@ -70,9 +70,7 @@ struct ConvArgs {
                                          // instead of as one write-back of every dirty line at the kernel boundary
 };
 
-__device__ __forceinline__ float silu_f(float x) {
-    return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x));
-}
+__device__ __forceinline__ float silu_f(float x) { return silu(x); }
 
 // Output stores.  A plain store leaves the line dirty in the XCD's L2 and the whole output is written back at the kernel
 // boundary (B / ~6 TB/s with nothing else running); a write-through (sc1) store sends it on its way at once, under the

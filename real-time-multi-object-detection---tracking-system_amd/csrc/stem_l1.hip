@@ -32,7 +32,7 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ float silu_s(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+__device__ __forceinline__ float silu_s(float x) { return silu(x); }
 
 constexpr int SL_THREADS = 512, SL_WAVES = 8;
 constexpr int SL_TW = 80;                       // layer-1 output pixels per segment
