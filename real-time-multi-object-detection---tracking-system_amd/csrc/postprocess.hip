@@ -26,8 +26,9 @@ namespace rtmodt {
 
 #pragma clang fp contract(off)
 
-constexpr int PP_THREADS = 256;
-constexpr int PP_WAVES = PP_THREADS / 64;
+// nms_kernel's workgroup: 1024 threads (one image per workgroup; the rank sort and the suppression sweep are per-thread loops over the
+// candidates a thread owns, so their latency goes with candidates / threads -- profiles/r03/nms_phases/); 256 = rounds 1-2, kept as an A/B
+// and test hook (RTMODT_NMS_THREADS=256)
 constexpr int SORT_LDS_MAX = 4096;          // keys sorted in LDS (32 KiB); beyond: global rank sort
 constexpr int MAX_NMS = 30000;              // ultralytics max_nms
 constexpr float MAX_WH = 7680.0f;           // ultralytics max_wh (per-class coordinate offset)
@@ -344,38 +345,20 @@ __device__ __forceinline__ bool nms_overlaps(const float4 a, float area_a, const
     return (double)ovr > thr;                            // torchvision CPU kernel compares against the double threshold
 }
 
-__device__ __forceinline__ int pp_scan_flag(bool flag, int *wsum, int &total) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    unsigned long long m = __ballot(flag);
-    int within = __popcll(m & ((1ull << lane) - 1ull));
-    if (lane == 0) wsum[wave] = __popcll(m);
-    __syncthreads();
-    int off = 0, tot = 0;
-#pragma unroll
-    for (int w = 0; w < PP_WAVES; ++w) {
-        int v = wsum[w];
-        if (w < wave) off += v;
-        tot += v;
-    }
-    __syncthreads();
-    total = tot;
-    return off + within;
-}
-
 constexpr int SBOX_LDS_MAX = 2048;          // sorted boxes kept in LDS (32 KiB); beyond: global scratch
-constexpr int RANK_LDS_MAX = 2048;          // up to here: LDS rank sort (no barriers); above: bitonic network
+constexpr int RANK_LDS_MAX = 2048;          // the LDS rank sort's capacity (8 keys per thread x 256 threads); launch_nms picks the switch-over below it
 
 // Greedy suppression over boxes sorted by descending score, 64 sorted positions at a time
 // (exactly torchvision's result: a box is kept iff no earlier KEPT box overlaps it):
-//   A. the 64 x 64 overlap matrix of the block is formed by the whole workgroup (thread t:
-//      row t>>2, columns 16 (t&3) ..), rows land in LDS as 64-bit masks;
+//   A. the 64 x 64 overlap matrix of the block is formed by the whole workgroup (threads / 64 threads per row,
+//      4 or 16 columns each), rows land in LDS as 64-bit masks;
 //   B. every wave resolves the block serially but entirely in registers -- lane i holds row i,
-//      v_readlane with a scalar index walks the rows: no LDS traffic, no barrier, ~64 short steps;
+//      v_readlane with a scalar index fetches the row of each box as it is kept: no LDS traffic, no barrier, one short step per kept box;
 //   C. the boxes kept in this block are applied to all later positions: each thread owns the
-//      sorted positions t, t+256, ... (alive bits in two registers) and publishes removals
+//      sorted positions t, t + threads, ... (alive bits in two registers) and publishes removals
 //      with one LDS atomicOr each.
 // Two barriers per 64 candidates instead of one (or two) per kept box; stops at max_det keeps.
-template <bool LDSBOX>
+template <bool LDSBOX, int PP_THREADS>
 __device__ __forceinline__ int greedy_nms(const float4 *lbox, const float4 *gbox, int n, int max_det, double thr,
                                           unsigned long long *removed, unsigned long long *rowmask, int *sel) {
     const int tid = threadIdx.x, lane = tid & 63;
@@ -395,33 +378,36 @@ __device__ __forceinline__ int greedy_nms(const float4 *lbox, const float4 *gbox
         if (avail == 0ull) continue;                          // uniform: everybody reads the same word
         // ---- A: overlap rows of the block ----
         {
-            const int i = tid >> 2, j0 = (tid & 3) << 4;
+            constexpr int TPR = PP_THREADS / 64, CPT = 64 / TPR;       // threads per row, columns per thread
+            const int i = tid / TPR, j0 = (tid % TPR) * CPT;
             unsigned long long part = 0ull;
             if (i < cnt && ((avail >> i) & 1ull)) {
                 const float4 bi = box_at(base + i);
                 const float ai = (bi.z - bi.x) * (bi.w - bi.y);
 #pragma unroll 4
-                for (int jj = 0; jj < 16; ++jj) {
+                for (int jj = 0; jj < CPT; ++jj) {
                     const int j = j0 + jj;
                     if (j > i && j < cnt && ((avail >> j) & 1ull) && nms_overlaps(bi, ai, box_at(base + j), thr)) part |= 1ull << j;
                 }
             }
-            part |= __shfl_xor(part, 1);
-            part |= __shfl_xor(part, 2);
-            if ((tid & 3) == 0) rowmask[i] = part;
+#pragma unroll
+            for (int d = 1; d < TPR; d <<= 1) part |= __shfl_xor(part, d);
+            if (tid % TPR == 0) rowmask[i] = part;
         }
         __syncthreads();
-        // ---- B: serial resolve in registers (identical in every wave) ----
+        // ---- B: serial resolve in registers (identical in every wave): one step per KEPT box -- the lowest live position is kept
+        //         and takes its row out of the live set (rows only hold later positions)
         const unsigned long long mine = rowmask[lane];
         const unsigned lo = (unsigned)mine, hi = (unsigned)(mine >> 32);
-        unsigned long long live = avail, keepm = 0ull;
-        for (int i = 0; i < cnt; ++i) {
-            if ((live >> i) & 1ull) {
-                keepm |= 1ull << i;
-                unsigned long long row = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)hi, i) << 32) |
-                                         (unsigned)__builtin_amdgcn_readlane((int)lo, i);
-                live &= ~row;
-            }
+        unsigned long long live = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(avail >> 32)) << 32) |
+                                  (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)avail);
+        unsigned long long keepm = 0ull;
+        while (live) {
+            const int i = __builtin_ctzll(live);
+            keepm |= 1ull << i;
+            const unsigned long long row = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)hi, i) << 32) |
+                                           (unsigned)__builtin_amdgcn_readlane((int)lo, i);
+            live &= ~(row | (1ull << i));
         }
         int nk = __popcll(keepm);
         if (kept + nk > max_det) {                            // keep[:max_det]
@@ -459,7 +445,9 @@ __device__ __forceinline__ int greedy_nms(const float4 *lbox, const float4 *gbox
     return kept;
 }
 
-__global__ __launch_bounds__(PP_THREADS) void nms_kernel(NmsArgs a, int dbg_stop) {
+template <int PP_THREADS>
+__global__ __launch_bounds__(PP_THREADS) void nms_kernel(NmsArgs a, int dbg_stop, int rank_max) {
+    constexpr int PP_WAVES = PP_THREADS / 64;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned long long *skeys = (unsigned long long *)smem;                  // [SORT_LDS_MAX] sort keys, kept for the index part
     float4 *lbox = (float4 *)(skeys + SORT_LDS_MAX);                         // [SBOX_LDS_MAX] sorted, class-offset boxes
@@ -480,7 +468,7 @@ __global__ __launch_bounds__(PP_THREADS) void nms_kernel(NmsArgs a, int dbg_stop
     // ---- 1. compaction in anchor order: thread t owns the contiguous anchors [t*per, (t+1)*per) ----
     const int per = (A + PP_THREADS - 1) / PP_THREADS;
     const int lo = min(tid * per, A), hi = min(lo + per, A);
-    constexpr int REG_SCORES = 40;                           // 8400 anchors / 256 threads = 33
+    constexpr int REG_SCORES = PP_THREADS == 256 ? 40 : 12;   // 8400 anchors / 256 threads = 33, / 1024 = 9
     const bool in_regs = per <= REG_SCORES;                  // uniform
     float sc[REG_SCORES];
     int mine = 0;
@@ -546,7 +534,7 @@ __global__ __launch_bounds__(PP_THREADS) void nms_kernel(NmsArgs a, int dbg_stop
     if (dbg_stop == 2) return;
 
     // ---- 2. sort by (score desc, anchor asc); keys are unique ----
-    if (n <= RANK_LDS_MAX) {
+    if (n <= rank_max) {
         // LDS rank sort: each thread ranks its <= 8 keys against all n (16-byte broadcast reads, no barriers)
         const int npad = (n + 1) & ~1;
         if (tid == 0 && (n & 1)) skeys[n] = 0ull;
@@ -636,8 +624,8 @@ __global__ __launch_bounds__(PP_THREADS) void nms_kernel(NmsArgs a, int dbg_stop
 
     // ---- 3. greedy suppression ----
     const double thr = (double)a.iou;
-    const int kept = lds_box ? greedy_nms<true>(lbox, gsbox, n, a.max_det, thr, removed, rowmask, sel)
-                             : greedy_nms<false>(lbox, gsbox, n, a.max_det, thr, removed, rowmask, sel);
+    const int kept = lds_box ? greedy_nms<true, PP_THREADS>(lbox, gsbox, n, a.max_det, thr, removed, rowmask, sel)
+                             : greedy_nms<false, PP_THREADS>(lbox, gsbox, n, a.max_det, thr, removed, rowmask, sel);
     __syncthreads();
     if (dbg_stop == 5) return;
 
@@ -664,13 +652,21 @@ __global__ __launch_bounds__(PP_THREADS) void nms_kernel(NmsArgs a, int dbg_stop
 int launch_nms(const NmsArgs &a, hipStream_t s) {
     size_t smem = (size_t)SORT_LDS_MAX * 8 + (size_t)SBOX_LDS_MAX * 16 + (size_t)((MAX_NMS + 63) / 64) * 8 + 64 * 8 + (size_t)a.max_det * 4 + 16;
     RT_CHECK(smem <= 150 * 1024, RTMODT_E_INVALID, "nms: max_det %d too large", a.max_det);
-    static size_t attr_bytes = 0;                          // raise the dynamic-LDS limit once per size, not per launch
-    if (smem > attr_bytes) {
-        RT_HIP(hipFuncSetAttribute((const void *)nms_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        attr_bytes = smem;
-    }
     static const int dbg_stop = getenv("RTMODT_NMS_STOP") ? atoi(getenv("RTMODT_NMS_STOP")) : 0;   // timing-only builds of the phases
-    hipLaunchKernelGGL(nms_kernel, dim3(a.B), dim3(PP_THREADS), smem, s, a, dbg_stop);
+    const char *e = getenv("RTMODT_NMS_THREADS");                                                   // A/B and test hook (read per launch)
+    const bool wide = !(e && atoi(e) == 256);
+    const char *rm = getenv("RTMODT_NMS_RANK_MAX");
+    // LDS rank sort (no barriers, n^2 / threads 64-bit compares per thread) up to here, the bitonic network (log^2 n barrier steps) above:
+    // with 1024 threads they cross at ~500 candidates (profiles/r03/nms_phases/sort_crossover.txt: 1 000 candidates 25 vs 18 us,
+    // 2 000: 74 vs 24); the 256-thread form keeps round 2's 2 048
+    const int rank_max = rm ? min(atoi(rm), RANK_LDS_MAX) : (wide ? 512 : RANK_LDS_MAX);
+    static size_t attr_bytes[2] = {0, 0};                  // raise the dynamic-LDS limit once per size, not per launch
+    if (smem > attr_bytes[wide]) {
+        RT_HIP(hipFuncSetAttribute(wide ? (const void *)nms_kernel<1024> : (const void *)nms_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        attr_bytes[wide] = smem;
+    }
+    if (wide) hipLaunchKernelGGL(nms_kernel<1024>, dim3(a.B), dim3(1024), smem, s, a, dbg_stop, rank_max);
+    else hipLaunchKernelGGL(nms_kernel<256>, dim3(a.B), dim3(256), smem, s, a, dbg_stop, rank_max);
     RT_HIP(hipGetLastError());
     return RTMODT_OK;
 }

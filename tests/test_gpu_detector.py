@@ -55,7 +55,14 @@ def check_nms(pkg, pred, **kw):
     return an
 
 
-def test_nms_planted_clusters(pkg):
+@pytest.fixture(params=["1024", "256"], ids=["1024-threads", "256-threads"])
+def nms_threads(request, monkeypatch):
+    """nms_kernel's two workgroup sizes (1024 = the product's; 256 = rounds 1-2, an A/B hook): the env is read per launch"""
+    monkeypatch.setenv("RTMODT_NMS_THREADS", request.param)
+    return request.param
+
+
+def test_nms_planted_clusters(pkg, nms_threads):
     pred, truth = pkg.synth.planted_pred()
     an = check_nms(pkg, pred, max_det=300)
     assert sorted(an.tolist()) == sorted(truth.tolist())
@@ -66,7 +73,7 @@ def test_nms_planted_clusters(pkg):
 
 
 @pytest.mark.parametrize("n_anchors,frac", [(8400, 0.05), (8400, 0.6), (2100, 1.0), (33600, 0.3), (8400, 1.0), (33600, 1.0)])
-def test_nms_dense_random(pkg, n_anchors, frac):
+def test_nms_dense_random(pkg, nms_threads, n_anchors, frac):
     """Hundreds to ~10k candidates, heavy overlap, duplicated scores (stable order matters);
     the 33600-anchor case drives the > 8192-candidate global rank-sort path."""
     rng = np.random.default_rng(n_anchors + int(frac * 100))
@@ -81,7 +88,7 @@ def test_nms_dense_random(pkg, n_anchors, frac):
     check_nms(pkg, pred, max_det=100, agnostic=True)
 
 
-def test_nms_empty_and_single(pkg):
+def test_nms_empty_and_single(pkg, nms_threads):
     pred = np.zeros((84, 100), np.float32)
     xy, cf, ci, an = pkg._ffi.nms_pred(pred)
     assert len(an) == 0
