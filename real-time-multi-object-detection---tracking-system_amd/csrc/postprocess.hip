@@ -29,7 +29,8 @@ namespace rtmodt {
 // nms_kernel's workgroup: 1024 threads (one image per workgroup; the rank sort and the suppression sweep are per-thread loops over the
 // candidates a thread owns, so their latency goes with candidates / threads -- profiles/r03/nms_phases/); 256 = rounds 1-2, kept as an A/B
 // and test hook (RTMODT_NMS_THREADS=256)
-constexpr int SORT_LDS_MAX = 4096;          // keys sorted in LDS (32 KiB); beyond: global rank sort
+constexpr int SORT_LDS_MAX = 8192;          // keys sorted in LDS (64 KiB); beyond: rank sort tiled through LDS
+constexpr int SORT_TILE = 4096;             // chunk of that tiled rank sort
 constexpr int MAX_NMS = 30000;              // ultralytics max_nms
 constexpr float MAX_WH = 7680.0f;           // ultralytics max_wh (per-class coordinate offset)
 
@@ -348,8 +349,26 @@ __device__ __forceinline__ bool nms_overlaps(const float4 a, float area_a, const
 constexpr int SBOX_LDS_MAX = 2048;          // sorted boxes kept in LDS (32 KiB); beyond: global scratch
 constexpr int RANK_LDS_MAX = 2048;          // the LDS rank sort's capacity (8 keys per thread x 256 threads); launch_nms picks the switch-over below it
 
-// Greedy suppression over boxes sorted by descending score, 64 sorted positions at a time
+// k-th (0-based) set bit of w; k < popcount(w)
+__device__ __forceinline__ int kth_set_bit(unsigned long long w, int k) {
+    int b = 0;
+    unsigned x = (unsigned)w;
+    int c = __popc(x);
+    if (k >= c) { k -= c; b = 32; x = (unsigned)(w >> 32); }
+    c = __popc(x & 0xFFFFu); if (k >= c) { k -= c; b += 16; x >>= 16; }
+    c = __popc(x & 0xFFu);   if (k >= c) { k -= c; b += 8; x >>= 8; }
+    c = __popc(x & 0xFu);    if (k >= c) { k -= c; b += 4; x >>= 4; }
+    c = __popc(x & 0x3u);    if (k >= c) { k -= c; b += 2; x >>= 2; }
+    if (k >= (int)(x & 1u)) b += 1;
+    return b;
+}
+
+// Greedy suppression over boxes sorted by descending score, 64 STILL-ALIVE sorted positions at a time
 // (exactly torchvision's result: a box is kept iff no earlier KEPT box overlaps it):
+//   G. the block = the next (up to) 64 positions after the cursor that no kept box has removed yet, gathered from the removed
+//      bitmap by every wave for itself (one bitmap word per lane over a 4 096-position window, wave prefix sum of the
+//      popcounts, member s = the (s - prefix)-th clear bit of its word): in a dense scene a few kept boxes remove thousands of
+//      positions, and the blocks then step over them instead of walking them 64 at a time;
 //   A. the 64 x 64 overlap matrix of the block is formed by the whole workgroup (threads / 64 threads per row,
 //      4 or 16 columns each), rows land in LDS as 64-bit masks;
 //   B. every wave resolves the block serially but entirely in registers -- lane i holds row i,
@@ -357,10 +376,10 @@ constexpr int RANK_LDS_MAX = 2048;          // the LDS rank sort's capacity (8 k
 //   C. the boxes kept in this block are applied to all later positions: each thread owns the
 //      sorted positions t, t + threads, ... (alive bits in two registers) and publishes removals
 //      with one LDS atomicOr each.
-// Two barriers per 64 candidates instead of one (or two) per kept box; stops at max_det keeps.
+// Two barriers per block instead of one (or two) per kept box; stops at max_det keeps.
 template <bool LDSBOX, int PP_THREADS>
 __device__ __forceinline__ int greedy_nms(const float4 *lbox, const float4 *gbox, int n, int max_det, double thr,
-                                          unsigned long long *removed, unsigned long long *rowmask, int *sel) {
+                                          unsigned long long *removed, unsigned long long *rowmask, int *sel, int *members) {
     const int tid = threadIdx.x, lane = tid & 63;
     unsigned long long alive0 = 0ull, alive1 = 0ull;
     for (int k = 0; k < 64; ++k) {
@@ -368,26 +387,59 @@ __device__ __forceinline__ int greedy_nms(const float4 *lbox, const float4 *gbox
         if (tid + PP_THREADS * (64 + k) < n) alive1 |= 1ull << k;
     }
     auto box_at = [&](int j) -> float4 { return LDSBOX ? lbox[j] : gbox[j]; };
-    int kept = 0;
-    const int nblocks = (n + 63) >> 6;
-    for (int b = 0; b < nblocks && kept < max_det; ++b) {
-        const int base = b << 6;
-        const int cnt = min(64, n - base);
-        unsigned long long avail = ~removed[b];
-        if (cnt < 64) avail &= (1ull << cnt) - 1ull;
-        if (avail == 0ull) continue;                          // uniform: everybody reads the same word
+    int kept = 0, cursor = 0;
+    const int nwords = (n + 63) >> 6;
+    while (cursor < n && kept < max_det) {
+        // ---- G: the next <= 64 alive positions (identical in every wave) ----
+        const int cw = cursor >> 6;
+        unsigned long long al = 0ull;
+        {
+            const int w = cw + lane;
+            if (w < nwords) {
+                al = ~removed[w];
+                if (w == cw) al &= ~0ull << (cursor & 63);
+                const int valid = n - (w << 6);
+                if (valid < 64) al &= (1ull << valid) - 1ull;
+            }
+        }
+        const int pc = __popcll(al);
+        int incl = pc;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int o = __shfl_up(incl, d);
+            if (lane >= d) incl += o;
+        }
+        const int total = __builtin_amdgcn_readlane(incl, 63);
+        const int window_end = min(n, (cw + 64) << 6);
+        if (total == 0) { cursor = window_end; continue; }     // uniform; nothing was written
+        const int cnt = min(64, total);
+        int pos = 0;
+        {
+            int L = 0;                                         // the first lane whose inclusive count exceeds my slot
+#pragma unroll
+            for (int step = 32; step; step >>= 1) {
+                const int v = __shfl(incl, L + step - 1);
+                if (v <= lane) L += step;
+            }
+            L = min(L, 63);
+            const unsigned long long wL = ((unsigned long long)(unsigned)__shfl((int)(unsigned)(al >> 32), L) << 32) | (unsigned)__shfl((int)(unsigned)al, L);
+            const int eL = __shfl(incl - pc, L);
+            if (lane < cnt) pos = ((cw + L) << 6) + kth_set_bit(wL, lane - eL);
+        }
+        const int cursor_next = total > 64 ? __builtin_amdgcn_readlane(pos, 63) + 1 : window_end;
+        if (lane < cnt) members[lane] = pos;                   // every wave writes the same values; it reads back only its own
         // ---- A: overlap rows of the block ----
         {
             constexpr int TPR = PP_THREADS / 64, CPT = 64 / TPR;       // threads per row, columns per thread
             const int i = tid / TPR, j0 = (tid % TPR) * CPT;
             unsigned long long part = 0ull;
-            if (i < cnt && ((avail >> i) & 1ull)) {
-                const float4 bi = box_at(base + i);
+            if (i < cnt) {
+                const float4 bi = box_at(members[i]);
                 const float ai = (bi.z - bi.x) * (bi.w - bi.y);
 #pragma unroll 4
                 for (int jj = 0; jj < CPT; ++jj) {
                     const int j = j0 + jj;
-                    if (j > i && j < cnt && ((avail >> j) & 1ull) && nms_overlaps(bi, ai, box_at(base + j), thr)) part |= 1ull << j;
+                    if (j > i && j < cnt && nms_overlaps(bi, ai, box_at(members[j]), thr)) part |= 1ull << j;
                 }
             }
 #pragma unroll
@@ -395,12 +447,11 @@ __device__ __forceinline__ int greedy_nms(const float4 *lbox, const float4 *gbox
             if (tid % TPR == 0) rowmask[i] = part;
         }
         __syncthreads();
-        // ---- B: serial resolve in registers (identical in every wave): one step per KEPT box -- the lowest live position is kept
-        //         and takes its row out of the live set (rows only hold later positions)
+        // ---- B: serial resolve in registers (identical in every wave): one step per KEPT box -- the lowest live member is kept
+        //         and takes its row out of the live set (rows only hold later members)
         const unsigned long long mine = rowmask[lane];
         const unsigned lo = (unsigned)mine, hi = (unsigned)(mine >> 32);
-        unsigned long long live = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(avail >> 32)) << 32) |
-                                  (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)avail);
+        unsigned long long live = cnt == 64 ? ~0ull : (1ull << cnt) - 1ull;
         unsigned long long keepm = 0ull;
         while (live) {
             const int i = __builtin_ctzll(live);
@@ -415,18 +466,17 @@ __device__ __forceinline__ int greedy_nms(const float4 *lbox, const float4 *gbox
             while (drop--) keepm &= ~(1ull << (63 - __builtin_clzll(keepm)));
             nk = max_det - kept;
         }
-        if (tid < 64 && ((keepm >> tid) & 1ull)) sel[kept + __popcll(keepm & ((1ull << tid) - 1ull))] = base + tid;
+        if (tid < 64 && ((keepm >> tid) & 1ull)) sel[kept + __popcll(keepm & ((1ull << tid) - 1ull))] = pos;
         kept += nk;
         if (kept >= max_det) break;
         // ---- C: apply this block's kept boxes to every later position I own ----
-        const int first_later = base + 64;
-        {   // positions before the next block are settled: drop them from my pool
-            int kmin = first_later > tid ? (first_later - tid + PP_THREADS - 1) / PP_THREADS : 0;
+        {   // positions before the next block's cursor are settled: drop them from my pool
+            int kmin = cursor_next > tid ? (cursor_next - tid + PP_THREADS - 1) / PP_THREADS : 0;
             if (kmin >= 64) { alive0 = 0ull; int k1 = kmin - 64; alive1 = k1 >= 64 ? 0ull : alive1 & ~((1ull << k1) - 1ull); }
             else alive0 &= ~((1ull << kmin) - 1ull);
         }
         for (unsigned long long km = keepm; km; km &= km - 1) {
-            const int ci = base + __builtin_ctzll(km);
+            const int ci = members[__builtin_ctzll(km)];
             const float4 cb = box_at(ci);
             const float carea = (cb.z - cb.x) * (cb.w - cb.y);
             for (unsigned long long m = alive0; m; m &= m - 1) {
@@ -440,7 +490,8 @@ __device__ __forceinline__ int greedy_nms(const float4 *lbox, const float4 *gbox
                 if (nms_overlaps(cb, carea, box_at(j), thr)) { alive1 &= ~(1ull << k); atomicOr(&removed[j >> 6], 1ull << (j & 63)); }
             }
         }
-        __syncthreads();                                      // removals visible; rowmask reusable
+        __syncthreads();                                      // removals visible; rowmask and members reusable
+        cursor = cursor_next;
     }
     return kept;
 }
@@ -449,11 +500,16 @@ template <int PP_THREADS>
 __global__ __launch_bounds__(PP_THREADS) void nms_kernel(NmsArgs a, int dbg_stop, int rank_max) {
     constexpr int PP_WAVES = PP_THREADS / 64;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned long long *skeys = (unsigned long long *)smem;                  // [SORT_LDS_MAX] sort keys, kept for the index part
-    float4 *lbox = (float4 *)(skeys + SORT_LDS_MAX);                         // [SBOX_LDS_MAX] sorted, class-offset boxes
-    unsigned long long *removed = (unsigned long long *)(lbox + SBOX_LDS_MAX);   // [ceil(MAX_NMS/64)] removed-or-kept bitmap
+    // LDS: [0, 64 KiB) the sort keys; once sorted, their anchor halves are packed in place into lidx (the first 32 KiB) and the sorted,
+    // class-offset boxes take the second 32 KiB
+    unsigned long long *skeys = (unsigned long long *)smem;                  // [SORT_LDS_MAX] sort keys
+    int *lidx = (int *)smem;                                                 // [SORT_LDS_MAX] sorted position -> anchor (after the sort)
+    float4 *lbox = (float4 *)(smem + (size_t)SORT_LDS_MAX * 4);              // [SBOX_LDS_MAX] sorted, class-offset boxes
+    static_assert((size_t)SORT_LDS_MAX * 4 + (size_t)SBOX_LDS_MAX * 16 <= (size_t)SORT_LDS_MAX * 8, "boxes alias the upper half of the key area");
+    unsigned long long *removed = (unsigned long long *)(skeys + SORT_LDS_MAX);  // [ceil(MAX_NMS/64)] removed bitmap
     unsigned long long *rowmask = removed + (MAX_NMS + 63) / 64;              // [64] overlap rows of the block being resolved
-    int *sel = (int *)(rowmask + 64);                                         // [max_det]
+    int *members = (int *)(rowmask + 64);                                     // [64] sorted positions of the block being resolved
+    int *sel = members + 64;                                                  // [max_det]
     __shared__ int wsum[PP_WAVES + 1];
 
     const int b = blockIdx.x, tid = threadIdx.x;
@@ -581,8 +637,8 @@ __global__ __launch_bounds__(PP_THREADS) void nms_kernel(NmsArgs a, int dbg_stop
             }
         }
     } else {
-        // > 4096 candidates (a saturated head, a very low confidence threshold): rank sort with the keys TILED through LDS --
-        // every thread ranks 8 of its keys at a time against chunks of SORT_LDS_MAX keys read as 16-byte broadcasts, as the
+        // > 8192 candidates (a saturated head, a very low confidence threshold): rank sort with the keys TILED through LDS --
+        // every thread ranks 8 of its keys at a time against chunks of SORT_TILE keys read as 16-byte broadcasts, as the
         // LDS rank sort above does.  (The first version compared against global memory key by key: 10 ms for 8 400 candidates.)
         const ulonglong2 *k2 = (const ulonglong2 *)skeys;
         for (int base0 = 0; base0 < n; base0 += PP_THREADS * 8) {         // uniform trip count: barriers inside
@@ -590,8 +646,8 @@ __global__ __launch_bounds__(PP_THREADS) void nms_kernel(NmsArgs a, int dbg_stop
             int rk[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) { const int i = base0 + tid + PP_THREADS * e; mk[e] = i < n ? gkeys[i] : ~0ull; rk[e] = 0; }
-            for (int c0 = 0; c0 < n; c0 += SORT_LDS_MAX) {
-                const int cn = min(SORT_LDS_MAX, n - c0), cpad = (cn + 1) & ~1;
+            for (int c0 = 0; c0 < n; c0 += SORT_TILE) {
+                const int cn = min(SORT_TILE, n - c0), cpad = (cn + 1) & ~1;
                 __syncthreads();                                      // everyone is done with the previous chunk
                 for (int i = tid; i < cpad; i += PP_THREADS) skeys[i] = i < cn ? gkeys[c0 + i] : 0ull;   // 0 ranks below every key
                 __syncthreads();
@@ -610,9 +666,20 @@ __global__ __launch_bounds__(PP_THREADS) void nms_kernel(NmsArgs a, int dbg_stop
     }
     if (dbg_stop == 3) return;
     if (n > MAX_NMS) n = MAX_NMS;                          // top-max_nms by confidence (B.3 step 5)
-    const bool lds_box = n <= SBOX_LDS_MAX;
+    if (lds_sort) {
+        // keys -> anchors, in place: lidx[i] (bytes 4i..) lands on keys[i / 2]; round r reads its PP_THREADS keys, everybody
+        // meets, then writes -- the bytes it writes lie below every key a later round still has to read
+        for (int i0 = 0; i0 < n; i0 += PP_THREADS) {       // uniform trip count: a barrier inside
+            const int i = i0 + tid;
+            const unsigned long long key = i < n ? skeys[i] : 0ull;
+            __syncthreads();
+            if (i < n) lidx[i] = (int)(0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull));
+        }
+        __syncthreads();
+    }
+    const bool lds_box = lds_sort && n <= SBOX_LDS_MAX;
     for (int i = tid; i < n; i += PP_THREADS) {
-        int idx = lds_sort ? (int)(0xFFFFFFFFu - (unsigned)(skeys[i] & 0xFFFFFFFFull)) : sidx[i];
+        int idx = lds_sort ? lidx[i] : sidx[i];
         float4 bx = box[idx];
         float off = a.agnostic ? 0.0f : (float)cls[idx] * MAX_WH;
         float4 ob = make_float4(bx.x + off, bx.y + off, bx.z + off, bx.w + off);
@@ -624,15 +691,15 @@ __global__ __launch_bounds__(PP_THREADS) void nms_kernel(NmsArgs a, int dbg_stop
 
     // ---- 3. greedy suppression ----
     const double thr = (double)a.iou;
-    const int kept = lds_box ? greedy_nms<true, PP_THREADS>(lbox, gsbox, n, a.max_det, thr, removed, rowmask, sel)
-                             : greedy_nms<false, PP_THREADS>(lbox, gsbox, n, a.max_det, thr, removed, rowmask, sel);
+    const int kept = lds_box ? greedy_nms<true, PP_THREADS>(lbox, gsbox, n, a.max_det, thr, removed, rowmask, sel, members)
+                             : greedy_nms<false, PP_THREADS>(lbox, gsbox, n, a.max_det, thr, removed, rowmask, sel, members);
     __syncthreads();
     if (dbg_stop == 5) return;
 
     // ---- 4. outputs (+ scale_boxes / clip) ----
     for (int k = tid; k < kept; k += PP_THREADS) {
         int sp = sel[k];
-        int idx = lds_sort ? (int)(0xFFFFFFFFu - (unsigned)(skeys[sp] & 0xFFFFFFFFull)) : sidx[sp];
+        int idx = lds_sort ? lidx[sp] : sidx[sp];
         float4 bx = box[idx];
         if (a.rescale) {
             bx.x = (bx.x - a.pad_x) / a.gain; bx.z = (bx.z - a.pad_x) / a.gain;
@@ -650,7 +717,7 @@ __global__ __launch_bounds__(PP_THREADS) void nms_kernel(NmsArgs a, int dbg_stop
 }
 
 int launch_nms(const NmsArgs &a, hipStream_t s) {
-    size_t smem = (size_t)SORT_LDS_MAX * 8 + (size_t)SBOX_LDS_MAX * 16 + (size_t)((MAX_NMS + 63) / 64) * 8 + 64 * 8 + (size_t)a.max_det * 4 + 16;
+    size_t smem = (size_t)SORT_LDS_MAX * 8 + (size_t)((MAX_NMS + 63) / 64) * 8 + 64 * 8 + 64 * 4 + (size_t)a.max_det * 4 + 16;
     RT_CHECK(smem <= 150 * 1024, RTMODT_E_INVALID, "nms: max_det %d too large", a.max_det);
     static const int dbg_stop = getenv("RTMODT_NMS_STOP") ? atoi(getenv("RTMODT_NMS_STOP")) : 0;   // timing-only builds of the phases
     const char *e = getenv("RTMODT_NMS_THREADS");                                                   // A/B and test hook (read per launch)

@@ -21,7 +21,8 @@ if not os.path.exists(path):
     pkg.weights.save(path, pkg.weights.synthetic("s", input_size=size), "s")
 det = pkg.Detector(path, input_size=(size, size), warmup=False, batch=B, autotune=False, chains=1, max_det=100)
 core = import_module(pkg.__name__ + ".tracking.tracker")._ByteTrackCore(n_streams=S, max_dets=128, max_tracks=2048)
-frames = np.stack([pkg.synth.frames(F * steps, size, size, seed=1234 + s) for s in range(S)], 1).reshape(steps, F, S, size, size, 3)
+gen = pkg.synth.structured_frames if os.environ.get("KIND") == "structured" else pkg.synth.frames
+frames = np.stack([gen(F * steps, size, size, seed=1234 + s) for s in range(S)], 1).reshape(steps, F, S, size, size, 3)
 buf = pkg._ffi.DeviceBuffer(frames.nbytes)
 buf.upload(frames)
 per = size * size * 3
