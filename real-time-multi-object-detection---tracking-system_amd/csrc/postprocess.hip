@@ -349,6 +349,32 @@ __device__ __forceinline__ bool nms_overlaps(const float4 a, float area_a, const
 constexpr int SBOX_LDS_MAX = 2048;          // sorted boxes kept in LDS (32 KiB); beyond: global scratch
 constexpr int RANK_LDS_MAX = 2048;          // the LDS rank sort's capacity (8 keys per thread x 256 threads); launch_nms picks the switch-over below it
 
+// one barrier step of the bitonic network over G consecutive strides (s0 << (G - 1), ..., s0): 2^G keys per thread in registers
+template <int G, int PP_THREADS>
+__device__ __forceinline__ void bitonic_step(unsigned long long *keys, int P, int k, int s0, int ls) {
+    constexpr int E = 1 << G;
+    for (int t = threadIdx.x; t < (P >> G); t += PP_THREADS) {
+        const int i0 = ((t >> ls) << (ls + G)) | (t & (s0 - 1));           // G zero bits inserted at bit ls
+        const bool desc = (i0 & k) == 0;
+        unsigned long long v[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) v[e] = keys[i0 + e * s0];
+#pragma unroll
+        for (int h = E >> 1; h >= 1; h >>= 1) {
+#pragma unroll
+            for (int e = 0; e < E; ++e)
+                if ((e & h) == 0) {
+                    const unsigned long long x = v[e], y = v[e | h];
+                    const bool sw = desc ? (x < y) : (x > y);
+                    v[e] = sw ? y : x;
+                    v[e | h] = sw ? x : y;
+                }
+        }
+#pragma unroll
+        for (int e = 0; e < E; ++e) keys[i0 + e * s0] = v[e];
+    }
+}
+
 // k-th (0-based) set bit of w; k < popcount(w)
 __device__ __forceinline__ int kth_set_bit(unsigned long long w, int k) {
     int b = 0;
@@ -379,7 +405,7 @@ __device__ __forceinline__ int kth_set_bit(unsigned long long w, int k) {
 // Two barriers per block instead of one (or two) per kept box; stops at max_det keeps.
 template <bool LDSBOX, int PP_THREADS>
 __device__ __forceinline__ int greedy_nms(const float4 *lbox, const float4 *gbox, int n, int max_det, double thr,
-                                          unsigned long long *removed, unsigned long long *rowmask, int *sel, int *members) {
+                                          unsigned long long *removed, unsigned long long *rowmask, int *sel, int *members, float4 *mbox) {
     const int tid = threadIdx.x, lane = tid & 63;
     unsigned long long alive0 = 0ull, alive1 = 0ull;
     for (int k = 0; k < 64; ++k) {
@@ -387,6 +413,10 @@ __device__ __forceinline__ int greedy_nms(const float4 *lbox, const float4 *gbox
         if (tid + PP_THREADS * (64 + k) < n) alive1 |= 1ull << k;
     }
     auto box_at = [&](int j) -> float4 { return LDSBOX ? lbox[j] : gbox[j]; };
+    constexpr int OWN = 8;                                  // my first OWN positions' boxes stay in registers for sweep C
+    float4 own[OWN];
+#pragma unroll
+    for (int k = 0; k < OWN; ++k) own[k] = tid + PP_THREADS * k < n ? box_at(tid + PP_THREADS * k) : make_float4(0.f, 0.f, 0.f, 0.f);
     int kept = 0, cursor = 0;
     const int nwords = (n + 63) >> 6;
     while (cursor < n && kept < max_det) {
@@ -427,19 +457,19 @@ __device__ __forceinline__ int greedy_nms(const float4 *lbox, const float4 *gbox
             if (lane < cnt) pos = ((cw + L) << 6) + kth_set_bit(wL, lane - eL);
         }
         const int cursor_next = total > 64 ? __builtin_amdgcn_readlane(pos, 63) + 1 : window_end;
-        if (lane < cnt) members[lane] = pos;                   // every wave writes the same values; it reads back only its own
+        if (lane < cnt) { members[lane] = pos; mbox[lane] = box_at(pos); }      // every wave writes the same values; it reads back only its own
         // ---- A: overlap rows of the block ----
         {
             constexpr int TPR = PP_THREADS / 64, CPT = 64 / TPR;       // threads per row, columns per thread
             const int i = tid / TPR, j0 = (tid % TPR) * CPT;
             unsigned long long part = 0ull;
             if (i < cnt) {
-                const float4 bi = box_at(members[i]);
+                const float4 bi = mbox[i];
                 const float ai = (bi.z - bi.x) * (bi.w - bi.y);
 #pragma unroll 4
                 for (int jj = 0; jj < CPT; ++jj) {
                     const int j = j0 + jj;
-                    if (j > i && j < cnt && nms_overlaps(bi, ai, box_at(members[j]), thr)) part |= 1ull << j;
+                    if (j > i && j < cnt && nms_overlaps(bi, ai, mbox[j], thr)) part |= 1ull << j;
                 }
             }
 #pragma unroll
@@ -476,11 +506,17 @@ __device__ __forceinline__ int greedy_nms(const float4 *lbox, const float4 *gbox
             else alive0 &= ~((1ull << kmin) - 1ull);
         }
         for (unsigned long long km = keepm; km; km &= km - 1) {
-            const int ci = members[__builtin_ctzll(km)];
-            const float4 cb = box_at(ci);
+            const float4 cb = mbox[__builtin_ctzll(km)];
             const float carea = (cb.z - cb.x) * (cb.w - cb.y);
-            for (unsigned long long m = alive0; m; m &= m - 1) {
-                int k = __builtin_ctzll(m);
+#pragma unroll
+            for (int k = 0; k < OWN; ++k)                                        // boxes in registers: no memory in this chain
+                if (((alive0 >> k) & 1ull) && nms_overlaps(cb, carea, own[k], thr)) {
+                    alive0 &= ~(1ull << k);
+                    const int j = tid + PP_THREADS * k;
+                    atomicOr(&removed[j >> 6], 1ull << (j & 63));
+                }
+            for (unsigned long long m = alive0 >> OWN; m; m &= m - 1) {
+                int k = OWN + __builtin_ctzll(m);
                 int j = tid + PP_THREADS * k;
                 if (nms_overlaps(cb, carea, box_at(j), thr)) { alive0 &= ~(1ull << k); atomicOr(&removed[j >> 6], 1ull << (j & 63)); }
             }
@@ -490,7 +526,7 @@ __device__ __forceinline__ int greedy_nms(const float4 *lbox, const float4 *gbox
                 if (nms_overlaps(cb, carea, box_at(j), thr)) { alive1 &= ~(1ull << k); atomicOr(&removed[j >> 6], 1ull << (j & 63)); }
             }
         }
-        __syncthreads();                                      // removals visible; rowmask and members reusable
+        __syncthreads();                                      // removals visible; rowmask, members and mbox reusable
         cursor = cursor_next;
     }
     return kept;
@@ -508,7 +544,8 @@ __global__ __launch_bounds__(PP_THREADS) void nms_kernel(NmsArgs a, int dbg_stop
     static_assert((size_t)SORT_LDS_MAX * 4 + (size_t)SBOX_LDS_MAX * 16 <= (size_t)SORT_LDS_MAX * 8, "boxes alias the upper half of the key area");
     unsigned long long *removed = (unsigned long long *)(skeys + SORT_LDS_MAX);  // [ceil(MAX_NMS/64)] removed bitmap
     unsigned long long *rowmask = removed + (MAX_NMS + 63) / 64;              // [64] overlap rows of the block being resolved
-    int *members = (int *)(rowmask + 64);                                     // [64] sorted positions of the block being resolved
+    float4 *mbox = (float4 *)(rowmask + 64);                                  // [64] boxes of the block being resolved
+    int *members = (int *)(mbox + 64);                                        // [64] their sorted positions
     int *sel = members + 64;                                                  // [max_det]
     __shared__ int wsum[PP_WAVES + 1];
 
@@ -624,16 +661,19 @@ __global__ __launch_bounds__(PP_THREADS) void nms_kernel(NmsArgs a, int dbg_stop
         while (P < n) P <<= 1;
         for (int i = n + tid; i < P; i += PP_THREADS) skeys[i] = 0ull;
         __syncthreads();
+        // bitonic network, up to three consecutive strides (4s, 2s, s) per barrier: a thread takes the 8 keys i0 + e * s whose indices
+        // differ only in those three bits into registers, runs the three compare-exchange steps there and writes them back
+        // (8 192 keys: 35 barrier steps instead of 91, a third of the LDS traffic); the direction bit k lies above all three strides
         for (int k = 2; k <= P; k <<= 1) {
-            for (int j = k >> 1; j > 0; j >>= 1) {
-                for (int i = tid; i < (P >> 1); i += PP_THREADS) {
-                    int lo_i = ((i & ~(j - 1)) << 1) | (i & (j - 1));          // index with bit j cleared
-                    int hi_i = lo_i | j;
-                    unsigned long long x = skeys[lo_i], y = skeys[hi_i];
-                    bool desc = (lo_i & k) == 0;
-                    if (desc ? (x < y) : (x > y)) { skeys[lo_i] = y; skeys[hi_i] = x; }
-                }
+            int j = k >> 1;
+            while (j > 0) {
+                const int g = j >= 4 ? 3 : (j >= 2 ? 2 : 1);            // strides in this step
+                const int s0 = j >> (g - 1), ls = __builtin_ctz(s0);     // the smallest of them
+                if (g == 3) bitonic_step<3, PP_THREADS>(skeys, P, k, s0, ls);
+                else if (g == 2) bitonic_step<2, PP_THREADS>(skeys, P, k, s0, ls);
+                else bitonic_step<1, PP_THREADS>(skeys, P, k, s0, ls);
                 __syncthreads();
+                j >>= g;
             }
         }
     } else {
@@ -691,8 +731,8 @@ __global__ __launch_bounds__(PP_THREADS) void nms_kernel(NmsArgs a, int dbg_stop
 
     // ---- 3. greedy suppression ----
     const double thr = (double)a.iou;
-    const int kept = lds_box ? greedy_nms<true, PP_THREADS>(lbox, gsbox, n, a.max_det, thr, removed, rowmask, sel, members)
-                             : greedy_nms<false, PP_THREADS>(lbox, gsbox, n, a.max_det, thr, removed, rowmask, sel, members);
+    const int kept = lds_box ? greedy_nms<true, PP_THREADS>(lbox, gsbox, n, a.max_det, thr, removed, rowmask, sel, members, mbox)
+                             : greedy_nms<false, PP_THREADS>(lbox, gsbox, n, a.max_det, thr, removed, rowmask, sel, members, mbox);
     __syncthreads();
     if (dbg_stop == 5) return;
 
@@ -717,7 +757,7 @@ __global__ __launch_bounds__(PP_THREADS) void nms_kernel(NmsArgs a, int dbg_stop
 }
 
 int launch_nms(const NmsArgs &a, hipStream_t s) {
-    size_t smem = (size_t)SORT_LDS_MAX * 8 + (size_t)((MAX_NMS + 63) / 64) * 8 + 64 * 8 + 64 * 4 + (size_t)a.max_det * 4 + 16;
+    size_t smem = (size_t)SORT_LDS_MAX * 8 + (size_t)((MAX_NMS + 63) / 64) * 8 + 64 * 8 + 64 * 16 + 64 * 4 + (size_t)a.max_det * 4 + 16;
     RT_CHECK(smem <= 150 * 1024, RTMODT_E_INVALID, "nms: max_det %d too large", a.max_det);
     static const int dbg_stop = getenv("RTMODT_NMS_STOP") ? atoi(getenv("RTMODT_NMS_STOP")) : 0;   // timing-only builds of the phases
     const char *e = getenv("RTMODT_NMS_THREADS");                                                   // A/B and test hook (read per launch)
