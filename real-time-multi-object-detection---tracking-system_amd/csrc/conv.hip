@@ -66,11 +66,16 @@ struct ConvArgs {
     int t_gap;                           // pair form: elements between the end of channel 63 and channel 64 of a tail output row (0 otherwise)
     int epi16;                           // epilogue through LDS with 16-byte NHWC stores (all channel offsets / strides % 8 == 0):
                                          // 1 = tile kernels, 2 = also the tap-reuse kernel
+    int epi_prio;                        // experiment hook RTMODT_EPI_PRIO: 1 = a wave raises its issue priority for its epilogue, 2 = lowers it (main loops at 1)
     int wthru;                           // output stores are WRITE-THROUGH (sc1): the tile leaves the XCD's L2 while the kernel still runs,
                                          // instead of as one write-back of every dirty line at the kernel boundary
 };
 
 __device__ __forceinline__ float silu_f(float x) { return silu(x); }
+
+// RTMODT_EPI_PRIO (ConvArgs::epi_prio): wave issue priority around an epilogue
+__device__ __forceinline__ void prio_main(int mode) { if (mode == 2) __builtin_amdgcn_s_setprio(1); else if (mode == 1) __builtin_amdgcn_s_setprio(0); }
+__device__ __forceinline__ void prio_epilogue(int mode) { if (mode == 1) __builtin_amdgcn_s_setprio(1); else if (mode == 2) __builtin_amdgcn_s_setprio(0); }
 
 // Output stores.  A plain store leaves the line dirty in the XCD's L2 and the whole output is written back at the kernel
 // boundary (B / ~6 TB/s with nothing else running); a write-through (sc1) store sends it on its way at once, under the
@@ -221,6 +226,7 @@ __device__ __forceinline__ void epilogue_lds(const ConvArgs &p, const int n0, co
     const int lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
     __syncthreads();                                       // every wave is done reading the last stage
     STAMP(7);
+    prio_epilogue(p.epi_prio);
 #pragma unroll
     for (int t = 0; t < TM; ++t) {
         const int pm = (wm * TM + t) * 16 + r;
@@ -239,6 +245,7 @@ __device__ __forceinline__ void epilogue_lds(const ConvArgs &p, const int n0, co
         }
     }
     STAMP(8);
+    prio_main(p.epi_prio);
     __syncthreads();
     STAMP(9);
     constexpr int CPR = BN / 8;                            // 16-byte chunks per pixel
@@ -1024,6 +1031,7 @@ __global__ __launch_bounds__(512) void conv1x1_ws(ConvArgs p, int groups) {
         }
         if (++kt == nk) {                                   // the tile is complete: epilogue straight from the accumulators
             kt = 0;
+            prio_epilogue(p.epi_prio);
             const int m0 = (g + tile * groups) * BM;
             ++tile;
 #pragma unroll
@@ -1053,6 +1061,7 @@ __global__ __launch_bounds__(512) void conv1x1_ws(ConvArgs p, int groups) {
                 }
             }
             store_credit = DEPTH;
+            prio_main(p.epi_prio);
             if (tile == 1) STAMP(7);
         }
     }
@@ -1197,6 +1206,7 @@ __global__ __launch_bounds__(NW * 64) void conv_mfma64_pt(ConvArgs p, int groups
             const int m0 = tile_m0(tile);
             ++tile;
             if (tile == 1) STAMP(6);
+            prio_epilogue(p.epi_prio);
             if (p.res) {                                    // the residual loads have landed; the DMA pieces issued after them may stay in flight
                 if (issued) wait_vmcnt<L>(); else wait_vmcnt<0>();
             }
@@ -1231,6 +1241,7 @@ __global__ __launch_bounds__(NW * 64) void conv_mfma64_pt(ConvArgs p, int groups
                 }
             }
             store_credit = DEPTH;
+            prio_main(p.epi_prio);
             if (tile == 1) STAMP(7);
         }
     }
@@ -1748,6 +1759,8 @@ static int make_args(const ConvLaunch &c, ConvArgs &a) {
     RT_CHECK(!c.in.wp || (!c.res.base && !c.out2.base && !c.in_lo.base), RTMODT_E_INVALID, "launch_conv: a pixel-pair view takes no residual / second destination / half-resolution source");
     static const int wt_env = getenv("RTMODT_WT") ? atoi(getenv("RTMODT_WT")) : 0;
     a.wthru = wt_env;
+    static const int prio_env = getenv("RTMODT_EPI_PRIO") ? atoi(getenv("RTMODT_EPI_PRIO")) : 0;      // experiment hook
+    a.epi_prio = prio_env;
     a.epi16 = c.out.coff % 8 == 0 && c.out.C % 8 == 0 && (!c.out2.base || (c.out2.coff % 8 == 0 && c.out2.C % 8 == 0)) &&
               (!c.res.base || (c.res.coff % 4 == 0)) ? c.epilogue : 0;
     RT_CHECK(a.kp % 32 == 0 && a.kp >= a.K, RTMODT_E_INVALID, "launch_conv: kp %d for K %d", a.kp, a.K);
