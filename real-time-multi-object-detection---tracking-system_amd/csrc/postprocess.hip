@@ -32,6 +32,7 @@ namespace rtmodt {
 constexpr int SORT_LDS_MAX = 8192;          // keys sorted in LDS (64 KiB); beyond: rank sort tiled through LDS
 constexpr int SORT_TILE = 4096;             // chunk of that tiled rank sort
 constexpr int MAX_NMS = 30000;              // ultralytics max_nms
+constexpr int REMOVED_WORDS = ((MAX_NMS + 63) / 64 + 1) & ~1;   // 64-bit words of the removed bitmap, even: what follows it in LDS stays 16-byte aligned
 constexpr float MAX_WH = 7680.0f;           // ultralytics max_wh (per-class coordinate offset)
 
 // ---------------------------------------------------------------------------------------
@@ -542,8 +543,8 @@ __global__ __launch_bounds__(PP_THREADS) void nms_kernel(NmsArgs a, int dbg_stop
     int *lidx = (int *)smem;                                                 // [SORT_LDS_MAX] sorted position -> anchor (after the sort)
     float4 *lbox = (float4 *)(smem + (size_t)SORT_LDS_MAX * 4);              // [SBOX_LDS_MAX] sorted, class-offset boxes
     static_assert((size_t)SORT_LDS_MAX * 4 + (size_t)SBOX_LDS_MAX * 16 <= (size_t)SORT_LDS_MAX * 8, "boxes alias the upper half of the key area");
-    unsigned long long *removed = (unsigned long long *)(skeys + SORT_LDS_MAX);  // [ceil(MAX_NMS/64)] removed bitmap
-    unsigned long long *rowmask = removed + (MAX_NMS + 63) / 64;              // [64] overlap rows of the block being resolved
+    unsigned long long *removed = (unsigned long long *)(skeys + SORT_LDS_MAX);  // [REMOVED_WORDS] removed bitmap
+    unsigned long long *rowmask = removed + REMOVED_WORDS;                        // [64] overlap rows of the block being resolved
     float4 *mbox = (float4 *)(rowmask + 64);                                  // [64] boxes of the block being resolved
     int *members = (int *)(mbox + 64);                                        // [64] their sorted positions
     int *sel = members + 64;                                                  // [max_det]
@@ -757,7 +758,7 @@ __global__ __launch_bounds__(PP_THREADS) void nms_kernel(NmsArgs a, int dbg_stop
 }
 
 int launch_nms(const NmsArgs &a, hipStream_t s) {
-    size_t smem = (size_t)SORT_LDS_MAX * 8 + (size_t)((MAX_NMS + 63) / 64) * 8 + 64 * 8 + 64 * 16 + 64 * 4 + (size_t)a.max_det * 4 + 16;
+    size_t smem = (size_t)SORT_LDS_MAX * 8 + (size_t)REMOVED_WORDS * 8 + 64 * 8 + 64 * 16 + 64 * 4 + (size_t)a.max_det * 4 + 16;
     RT_CHECK(smem <= 150 * 1024, RTMODT_E_INVALID, "nms: max_det %d too large", a.max_det);
     static const int dbg_stop = getenv("RTMODT_NMS_STOP") ? atoi(getenv("RTMODT_NMS_STOP")) : 0;   // timing-only builds of the phases
     const char *e = getenv("RTMODT_NMS_THREADS");                                                   // A/B and test hook (read per launch)

@@ -96,6 +96,29 @@ def test_nms_empty_and_single(pkg, nms_threads):
     check_nms(pkg, pred)
 
 
+def test_nms_dense_scene_through_the_engine(pkg, wdir, nms_threads):
+    """A saturated head (the random-weight net on STRUCTURED frames: thousands of candidates per image, as a dense scene gives a
+    trained one) through the detector itself, 8 images per batch: the fetched detections must equal oracle NMS + scale_boxes on
+    the engine's own pre-NMS tensor bit for bit -- the 8 192-key LDS sort, the walk over still-alive positions and the
+    boxes-in-global-scratch path are what this input exercises (profiles/r03/nms_phases/)."""
+    size, B = 640, 8
+    det, _ = make_detector(pkg, wdir, "s", size, batch=B, autotune=False, max_det=100)
+    frames = list(pkg.synth.structured_frames(B, size, size, seed=1234))
+    got = det.detect_batch(frames)
+    cands = []
+    for i in range(B):
+        _, _, pred = det.debug_fetch(i, want_input=False, want_heads=False)
+        cands.append(int((pred[4:].max(0) > det.confidence).sum()))
+        dets, _ = Y.non_max_suppression(pred, det.confidence, det.iou, det.classes, det.agnostic_nms, 100)
+        ref = Y.scale_boxes(dets[:, :4], size, size, size, size) if len(dets) else np.empty((0, 4), np.float32)
+        d = got[i]
+        assert len(d) == len(dets), (i, cands[-1])
+        assert np.array_equal(d.xyxy.view(np.int32), ref.view(np.int32)), i
+        assert np.array_equal(d.confidence.view(np.int32), dets[:, 4].astype(np.float32).view(np.int32)), i
+        assert d.class_id.tolist() == dets[:, 5].astype(np.int32).tolist(), i
+    assert max(cands) > 2048, cands              # the input really is dense
+
+
 # ------------------------------------------------------------------ forward pass, layer by layer
 def fetch_layers(pkg, det, names, img=0):
     """Every fused conv's output as the engine stored it; the first conv of a Bottleneck that runs
