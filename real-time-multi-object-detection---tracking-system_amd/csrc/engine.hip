@@ -2029,21 +2029,24 @@ int rtmodt_detector_debug_layer(rtmodt_detector *d, const char *name, int img, u
     auto it = d->layer_out.find(name);
     RT_CHECK(it != d->layer_out.end(), RTMODT_E_INVALID, "no fused conv named %s", name);
     const TensorView &v = it->second;
+    // what is stored is decided by the ops that RUN: with sub-batch chains those were tuned on their own (autotune_tiles) and may fuse
+    // a launch the whole-batch ops keep apart -- the tensor between them would then hold the tuner's stale data
+    const std::vector<Op> &ops = d->n_chains > 1 ? d->chain_ops[0] : d->ops;
     if (d->head_final && strncmp(name, "22.cv", 5) == 0 && strlen(name) > 2 && strcmp(name + strlen(name) - 2, ".2") == 0) {
         RT_HIP(hipSetDevice(d->device));
         RT_HIP(hipDeviceSynchronize());
         if (d->newest >= 0) d->cur_dense = d->newest;
         RT_TRY(materialize_heads(d));                      // Detect's last convs live inside head_final
     }
-    if (d->sl1_on && d->l1_idx > 0 && (strcmp(name, "0") == 0 || (strcmp(name, "1") == 0 && d->ops[d->l1_idx].tail_on)))
+    if (d->sl1_on && d->l1_idx > 0 && (strcmp(name, "0") == 0 || (strcmp(name, "1") == 0 && ops[d->l1_idx].tail_on)))
         return fail(RTMODT_E_UNSUPPORTED, "%s is consumed in LDS by the next conv fused into its launch", name);
-    for (auto &op : d->ops)                               // a conv whose 1x1 tail runs in the same launch stores only the tail's output
+    for (auto &op : ops)                               // a conv whose 1x1 tail runs in the same launch stores only the tail's output
         if (op.kind == OP_CONV && op.tail_on && op.name == name)
             return fail(RTMODT_E_UNSUPPORTED, "%s is consumed in LDS by the 1x1 conv fused into its launch", name);
-    for (auto &op : d->ops)                               // ... and so does a fused Bottleneck whose C2f.cv2 runs as its tail
+    for (auto &op : ops)                               // ... and so does a fused Bottleneck whose C2f.cv2 runs as its tail
         if (op.kind == OP_BNECK && op.fused && op.tail_on && op.name == std::string(name).substr(0, std::string(name).rfind('.')) + " (cv1+cv2)")
             return fail(RTMODT_E_UNSUPPORTED, "%s is consumed in LDS by the 1x1 conv fused into its launch", name);
-    for (auto &op : d->ops)                               // the first conv of a fused Bottleneck never leaves the CU
+    for (auto &op : ops)                               // the first conv of a fused Bottleneck never leaves the CU
         if (op.kind == OP_BNECK && op.fused && op.name == std::string(name).substr(0, std::string(name).rfind('.')) + " (cv1+cv2)" &&
             std::string(name).size() > 4 && std::string(name).compare(std::string(name).size() - 4, 4, ".cv1") == 0)
             return fail(RTMODT_E_UNSUPPORTED, "%s is the LDS-resident intermediate of a fused Bottleneck launch", name);

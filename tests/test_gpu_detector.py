@@ -154,6 +154,17 @@ def layer_check(pkg, det, w, frame, scale, size):
     return d, heads, pred, worst
 
 
+def test_stored_layers_with_sub_batch_chains(pkg, wdir):
+    """Two sub-batch chains, autotuned: the chains' ops are tuned on their own (half-batch GEMMs) and may fuse launches the
+    whole-batch ops keep apart; which layers `debug_layer` reports as stored must follow the ops that RUN (round 3: it followed
+    the whole-batch ops, and bench.py's layer check then read the tuner's stale tensor behind a fused Bottleneck)."""
+    det, w = make_detector(pkg, wdir, "s", 320, batch=4, autotune=True, chains=2)
+    assert det.model.chains == 2
+    frame = pkg.synth.frames(1, 320, 320, seed=1234)[0]
+    _, _, _, worst = layer_check(pkg, det, w, frame, "s", 320)
+    print("worst layer", worst)
+
+
 def test_forward_layers_yolov8s_640(pkg, wdir):
     det, w = make_detector(pkg, wdir, "s", 640)
     frame = pkg.synth.frames(1, 640, 640, seed=1234)[0]
