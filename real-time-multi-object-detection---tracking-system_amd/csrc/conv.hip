@@ -515,7 +515,7 @@ __device__ __forceinline__ void conv_mfma_body(const ConvArgs &p, const int bx, 
 // one barrier per 64 of K.  Chunk c (0..7) of row r sits in slot c ^ ((r>>1)&7): conflict-free
 // ds_read_b128 for both k-substeps.
 // ---------------------------------------------------------------------------------------
-template <int BM, int BN, int WM, int WN, int NSTAGE, int N2T = 0>
+template <int BM, int BN, int WM, int WN, int NSTAGE, int N2T = 0, bool PF = false>
 __device__ __forceinline__ void conv_mfma64_body(const ConvArgs &p, const int bx, const int by) {
     constexpr int NW = WM * WN;                             // waves per workgroup: the DMA path sustains ~5 B/clk PER WAVE (tools/probes/dma_probe),
     static_assert(NW == 4 || NW == 8 || NW == 16, "4, 8 or 16 waves");      // so the big tiles run 8 (16) waves to issue their operands twice (four times) as fast
@@ -591,6 +591,7 @@ __device__ __forceinline__ void conv_mfma64_body(const ConvArgs &p, const int bx
     for (int i = 0; i < DEPTH; ++i)
         if (i < nk) issue(i, i);
     int rstage = 0, wstage = DEPTH % NSTAGE;
+    if constexpr (!PF) {
     for (int kt = 0; kt < nk; ++kt) {
         wait_steps<LA + LBp, DEPTH - 1>(min(DEPTH - 1, nk - 1 - kt));
         __builtin_amdgcn_s_barrier();
@@ -612,6 +613,81 @@ __device__ __forceinline__ void conv_mfma64_body(const ConvArgs &p, const int bx
 #pragma unroll
                 for (int u = 0; u < TN; ++u)
                     acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[u], fa[t], acc[t][u], 0, 0, 0);
+        }
+    }
+    } else {
+        // SOFTWARE-PIPELINED k-loop (the PF tiles; one or two waves per SIMD, so a wave has to hide its own latencies): two fragment
+        // sets.  While the MFMAs of sub-step 0 run, the fragments of sub-step 1 are on their way from LDS; the step's barrier sits
+        // BETWEEN the two MFMA blocks (stage kt + 1 landed, everybody done reading stage kt); behind it the fragments of the NEXT
+        // stage's sub-step 0 are requested and the DMA pieces of stage kt + 1 + DEPTH are issued one by one between the MFMAs of
+        // sub-step 1 (into the slot stage kt just left).  Same ring, same counted waits, same results as the plain loop.
+        constexpr int NPW = LA + LBp, NMF = TM * TN;
+        int p_kt = -1, p_stage = 0, p_tap = 0, p_c0 = 0;
+        bool p_lo = false;
+        auto begin_issue = [&](int kt, int stage) {
+            p_kt = kt; p_stage = stage; p_c0 = c0;
+            p_tap = (kh * p.in_Wp + kw) * p.in_cs + c0;
+            p_lo = p.in2 && c0 < p.split;
+            c0 += 64;
+            if (c0 >= p.cin) { c0 = 0; if (++kw == p.ks) { kw = 0; ++kh; } }
+        };
+        auto issue_piece = [&](int i) {
+            unsigned char *sb = lds + p_stage * STAGE;
+            if (i < LA) {
+                if (p_lo) glds16(p.in2 + (a_lo[i] + p_c0), sb + (wave + NW * i) * 1024);
+                else glds16(p.in + (a_off[i] + p_tap), sb + (wave + NW * i) * 1024);
+            } else {
+                glds16(p.wt + (b_off[i - LA] + p_kt * 64), sb + (NA + wave + NW * (i - LA)) * 1024);
+            }
+        };
+        auto load_frags = [&](const unsigned char *sb, int ro, half8 (&fa)[TM], half8 (&fb)[TN]) {
+#pragma unroll
+            for (int t = 0; t < TM; ++t) fa[t] = *(const half8 *)(sb + (wm * TM + t) * 2048 + ro);
+#pragma unroll
+            for (int u = 0; u < TN; ++u) fb[u] = *(const half8 *)(sb + NA * 1024 + (wn * TN + u) * 2048 + ro);
+        };
+        half8 fa0[TM], fb0[TN], fa1[TM], fb1[TN];
+        wait_steps<NPW, DEPTH - 1>(min(DEPTH - 1, nk - 1));
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (DEPTH < nk) issue(DEPTH, wstage);               // the ring's last free slot
+        load_frags(lds, rd_off0, fa0, fb0);
+        for (int kt = 0; kt < nk; ++kt) {
+            const unsigned char *sbase = lds + rstage * STAGE;
+            __builtin_amdgcn_s_waitcnt(0xC07F);             // lgkmcnt(0): set 0 (requested a whole MFMA block ago) is here -- said with the builtin so that the
+            load_frags(sbase, rd_off1, fa1, fb1);           // compiler's own wait in front of the MFMAs does not also cover the loads of set 1 issued now
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < TM; ++t)
+#pragma unroll
+                for (int u = 0; u < TN; ++u) acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb0[u], fa0[t], acc[t][u], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            const int nstage = rstage + 1 == NSTAGE ? 0 : rstage + 1;
+            p_kt = -1;
+            __builtin_amdgcn_s_waitcnt(0xC07F);                             // lgkmcnt(0): my reads of stage kt are complete (on both paths: set 1 is then
+            if (kt + 1 < nk) {                                              // known to be there and the MFMAs below do not wait for the next set 0)
+                wait_steps<NPW, DEPTH - 1>(min(DEPTH - 1, nk - 2 - kt));    // my pieces of stage kt + 1 have landed
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                if (kt + 1 + DEPTH < nk) begin_issue(kt + 1 + DEPTH, rstage);
+                load_frags(lds + nstage * STAGE, rd_off0, fa0, fb0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            int piece = 0;
+#pragma unroll
+            for (int t = 0; t < TM; ++t)
+#pragma unroll
+                for (int u = 0; u < TN; ++u) {
+                    acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb1[u], fa1[t], acc[t][u], 0, 0, 0);
+                    const int done = t * TN + u + 1;
+                    if (piece < NPW && (piece + 1) * NMF <= done * NPW) {
+                        if (p_kt >= 0) issue_piece(piece);
+                        ++piece;
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            __builtin_amdgcn_sched_barrier(0);
+            rstage = nstage;
         }
     }
 
@@ -1439,6 +1515,11 @@ template <int BM, int BN, int WM, int WN, int NSTAGE>
 __global__ __launch_bounds__(1024) void conv_mfma64_w16(ConvArgs p) { conv_mfma64_body<BM, BN, WM, WN, NSTAGE>(p, blockIdx.x, blockIdx.y); }
 template <int BM, int BN, int WM, int WN, int NSTAGE>
 __global__ __launch_bounds__(256) void conv_mfma64(ConvArgs p) { conv_mfma64_body<BM, BN, WM, WN, NSTAGE>(p, blockIdx.x, blockIdx.y); }
+// software-pipelined k-loop (PF tiles): 4 waves, two workgroups per CU; 8 waves, one
+template <int BM, int BN, int WM, int WN, int NSTAGE>
+__global__ __launch_bounds__(256, 2) void conv_mfma64_pf(ConvArgs p) { conv_mfma64_body<BM, BN, WM, WN, NSTAGE, 0, true>(p, blockIdx.x, blockIdx.y); }
+template <int BM, int BN, int WM, int WN, int NSTAGE>
+__global__ __launch_bounds__(512, 2) void conv_mfma64_pf_w8(ConvArgs p) { conv_mfma64_body<BM, BN, WM, WN, NSTAGE, 0, true>(p, blockIdx.x, blockIdx.y); }
 template <int BM, int BN, int WM, int WN, int NSTAGE>
 __global__ __launch_bounds__(256) void conv_mfma64_grp(ConvGroupArgs g) {
     int bx, by;
@@ -1483,23 +1564,24 @@ const char *tile_name(int tile) {
                                             "k64:128x128s2/8w", "k64:128x128s3/8w", "k64:256x128s2/8w", "k64:128x64s3/8w", "k64:256x64s2/8w",
                                             "rows:128x64/8w", "rows:256x64/8w", "rows64:128x128/8w", "rows64:256x64/8w",
                                             "ws:128x128", "ws:128x64", "pt:128x128s2", "pt:128x128s3", "pt:128x64s3", "pt:128x64s2",
-                                            "k64:256x128s3/8w", "k64:256x256s2/8w", "rows-pt:256x64", "rows-pt:128x64", "rows64-pt:256x64", "k64:256x128s3/16w", "pt:256x128s3/16w"};
+                                            "k64:256x128s3/8w", "k64:256x256s2/8w", "rows-pt:256x64", "rows-pt:128x64", "rows64-pt:256x64", "k64:256x128s3/16w", "pt:256x128s3/16w", "k64pf:128x128s2", "k64pf:256x128s3/8w"};
     return tile >= 0 && tile < TILE_COUNT ? names[tile] : "?";
 }
 
 bool tile_needs_cin64(int tile) {
     return (tile >= TILE_K64_128x128_S2 && tile <= TILE_K64_128x128_S2W) || (tile >= TILE_ROWS_K64_128x64 && tile <= TILE_ROWS_K64_256x64) ||
            tile == TILE_TAIL_K64_128x128 || tile == TILE_TAIL_K64_64x128 || (tile >= TILE_K64_128x128_S2_W8 && tile <= TILE_K64_256x64_S2_W8) ||
-           tile == TILE_ROWS_K64_128x128_W8 || tile == TILE_ROWS_K64_256x64_W8 || tile == TILE_ROWS_PT_K64_256x64 || tile_is_ws(tile) || tile_is_pt(tile) || tile_is_w8(tile);
+           tile == TILE_ROWS_K64_128x128_W8 || tile == TILE_ROWS_K64_256x64_W8 || tile == TILE_ROWS_PT_K64_256x64 || tile_is_ws(tile) || tile_is_pt(tile) || tile_is_w8(tile) || tile_is_pf(tile);
 }
 bool tile_is_w8(int tile) { return (tile >= TILE_K64_128x128_S2_W8 && tile <= TILE_K64_256x64_S2_W8) || tile == TILE_K64_256x128_S3_W8 || tile == TILE_K64_256x256_S2_W8 || tile == TILE_K64_256x128_S3_W16; }
 bool tile_is_ws(int tile) { return tile == TILE_WS_128x128 || tile == TILE_WS_128x64; }
+bool tile_is_pf(int tile) { return tile == TILE_K64_PF_128x128_S2 || tile == TILE_K64_PF_256x128_S3_W8; }
 bool tile_is_pt(int tile) { return (tile >= TILE_PT_128x128_S2 && tile <= TILE_PT_128x64_S2) || tile == TILE_PT_256x128_S3_W16; }
 // resident weight slice (kp/64 x BN/8 KiB) + the pixel ring (3 x 16 KiB) within 156 KiB of LDS
 bool tile_ws_fits(int tile, int kp) { return tile_is_ws(tile) && (kp / 64) * (tile_shape(tile).bn / 8) + 3 * 16 <= 156; }
 bool tile_is_tail(int tile) { return tile >= TILE_TAIL_128x64 && tile <= TILE_TAIL_K64_64x128; }
 // the 64-deep tile kernels (conv_mfma64_body) know how to read channels [0, lo_c) from a half-resolution tensor
-bool tile_reads_lo(int tile) { return (tile >= TILE_K64_128x128_S2 && tile <= TILE_K64_128x128_S2W) || tile_is_w8(tile) || tile_is_pt(tile); }
+bool tile_reads_lo(int tile) { return (tile >= TILE_K64_128x128_S2 && tile <= TILE_K64_128x128_S2W) || tile_is_w8(tile) || tile_is_pt(tile) || tile_is_pf(tile); }
 bool tile_is_rows(int tile) { return (tile >= TILE_ROWS_128x64 && tile <= TILE_ROWS_K64_256x64) || (tile >= TILE_ROWS_128x64_W8 && tile <= TILE_ROWS_K64_256x64_W8) || tile_is_rows_pt(tile); }
 bool tile_is_rows_pt(int tile) { return tile >= TILE_ROWS_PT_256x64 && tile <= TILE_ROWS_PT_K64_256x64; }
 
@@ -1546,6 +1628,8 @@ TileShape tile_shape(int tile) {
         case TILE_PT_128x128_S2: case TILE_PT_128x128_S3: return {128, 128};
         case TILE_PT_128x64_S3: case TILE_PT_128x64_S2: return {128, 64};
         case TILE_K64_256x128_S3_W8: return {256, 128};
+        case TILE_K64_PF_128x128_S2: return {128, 128};
+        case TILE_K64_PF_256x128_S3_W8: return {256, 128};
         case TILE_K64_256x256_S2_W8: return {256, 256};
         case TILE_K64_256x128_S3_W16: case TILE_PT_256x128_S3_W16: return {256, 128};
         case TILE_ROWS_PT_256x64: case TILE_ROWS_PT_K64_256x64: return {256, 64};
@@ -1623,6 +1707,14 @@ template <int BM, int BN, int WM, int WN, int NSTAGE>
 static int launch_k64_w8(const LaunchPlan &l, hipStream_t s) {
     RT_CHECK(l.n == 1, RTMODT_E_INVALID, "launch_conv: the 8-wave tiles run single problems");
     hipLaunchKernelGGL((conv_mfma64_w8<BM, BN, WM, WN, NSTAGE>), l.grid(BM, BN), dim3(512), 0, s, l.a[0]);
+    return RTMODT_OK;
+}
+
+template <int BM, int BN, int WM, int WN, int NSTAGE, int NT>
+static int launch_k64_pf(const LaunchPlan &l, hipStream_t s) {
+    RT_CHECK(l.n == 1, RTMODT_E_INVALID, "launch_conv: the software-pipelined tiles run single problems");
+    if constexpr (NT == 256) hipLaunchKernelGGL((conv_mfma64_pf<BM, BN, WM, WN, NSTAGE>), l.grid(BM, BN), dim3(256), 0, s, l.a[0]);
+    else hipLaunchKernelGGL((conv_mfma64_pf_w8<BM, BN, WM, WN, NSTAGE>), l.grid(BM, BN), dim3(512), 0, s, l.a[0]);
     return RTMODT_OK;
 }
 
@@ -1855,6 +1947,8 @@ int launch_conv_group(const ConvLaunch *c, int n, int tile, hipStream_t s) {
         case TILE_ROWS_PT_128x64: launch_rows_pt<128, 64, 4, 2, false>(l, s); break;
         case TILE_ROWS_PT_K64_256x64: launch_rows_pt<256, 64, 4, 2, true>(l, s); break;
         case TILE_K64_256x128_S3_W8: RT_TRY((launch_k64_w8<256, 128, 4, 2, 3>(l, s))); break;
+        case TILE_K64_PF_128x128_S2: RT_TRY((launch_k64_pf<128, 128, 2, 2, 2, 256>(l, s))); break;
+        case TILE_K64_PF_256x128_S3_W8: RT_TRY((launch_k64_pf<256, 128, 4, 2, 3, 512>(l, s))); break;
         case TILE_K64_256x256_S2_W8: RT_TRY((launch_k64_w8<256, 256, 4, 2, 2>(l, s))); break;
         case TILE_K64_256x128_S3_W16:
             RT_CHECK(l.n == 1, RTMODT_E_INVALID, "launch_conv: the 16-wave tiles run single problems");

@@ -979,7 +979,7 @@ static bool tile_legal(const ConvLaunch *c, int n, int t) {
     if (tile_needs_cin64(t) && !cin64) return false;
     if (tile_is_rows(t) && !rows_ok) return false;
     if (c[0].in_lo.base && !tile_reads_lo(t)) return false;
-    if (tile_is_w8(t) && n != 1) return false;   // the 8-wave tiles have no group entry point
+    if ((tile_is_w8(t) || tile_is_pf(t)) && n != 1) return false;   // the 8-wave and the software-pipelined tiles have no group entry point
     for (int i = 0; i < n; ++i)                   // weights and bias are padded to 128 rows of cout: a wider tile must divide cout
         if (tile_shape(t).bn > 128 && c[i].cout % tile_shape(t).bn != 0) return false;
     if (tile_is_pt(t) && (n != 1 || c[0].out2.base || ((long)c[0].B * c[0].out.H * c[0].out.W) % tile_shape(t).bm != 0 ||
@@ -1006,7 +1006,7 @@ static int tile_lds_kib(int t) {
         case TILE_128x64_S5: case TILE_64x128_S5: stages = 5; break;
         case TILE_64x64_S6: case TILE_128x128_S6: stages = 6; break;
         case TILE_K64_128x128_S2: case TILE_K64_256x64_S2: case TILE_K64_256x128_S2: case TILE_K64_128x128_S2W: case TILE_K64_128x128_S2_W8:
-        case TILE_K64_256x128_S2_W8: case TILE_K64_256x64_S2_W8: case TILE_K64_256x256_S2_W8: stages = 2; break;
+        case TILE_K64_256x128_S2_W8: case TILE_K64_256x64_S2_W8: case TILE_K64_256x256_S2_W8: case TILE_K64_PF_128x128_S2: stages = 2; break;
         case TILE_K64_64x64_S4: stages = 4; break;
         default: break;
     }
@@ -1033,6 +1033,10 @@ static int tune_conv(rtmodt_detector *d, hipEvent_t e0, hipEvent_t e1, const std
         // frames/s, profiles/r03/w16/bench_ab.txt).  Tested, available through RTMODT_TUNE_BIG=1 and the test hooks, out of the tuner by default.
         static const bool tune_big = getenv("RTMODT_TUNE_BIG") != nullptr;
         if (!tune_big && (t == TILE_K64_256x128_S3_W8 || t == TILE_K64_256x256_S2_W8 || t == TILE_K64_256x128_S3_W16 || t == TILE_PT_256x128_S3_W16)) continue;
+        // the software-pipelined k-loop (TILE_K64_PF_*) ties with the plain loop on every shape tried (profiles/r03/pf/): what a k-step waits for is not
+        // the wave's own LDS-read or DMA-issue latency.  Tested, available through RTMODT_TUNE_PF=1 and the test hooks, out of the tuner by default.
+        static const bool tune_pf = getenv("RTMODT_TUNE_PF") != nullptr;
+        if (!tune_pf && tile_is_pf(t)) continue;
         // A/B hook: RTMODT_TUNE_SKIP="48,49,53" keeps the listed tile ids out of the tuner (same-box comparisons of a tile family)
         static const std::string skip = getenv("RTMODT_TUNE_SKIP") ? std::string(",") + getenv("RTMODT_TUNE_SKIP") + "," : std::string();
         if (!skip.empty() && skip.find("," + std::to_string(t) + ",") != std::string::npos) continue;

@@ -65,11 +65,15 @@ enum ConvTile {
     // the big tiles with SIXTEEN waves (one 1024-thread workgroup per CU): the LDS-DMA path sustains ~5 B/clk per issuing wave
     TILE_K64_256x128_S3_W16 = 53,
     TILE_PT_256x128_S3_W16 = 54,                    // ... and the persistent tile kernel on that shape (cross-tile prefetch through a three-stage ring, one workgroup per CU)
-    TILE_COUNT = 55
+    // 64-deep tile kernel with a SOFTWARE-PIPELINED k-loop (two fragment sets, the barrier between the two MFMA blocks of a step, DMA pieces issued between MFMAs):
+    // 4 waves x 64x64 outputs, two workgroups per CU; 8 waves on 256x128 with three stages, one workgroup per CU
+    TILE_K64_PF_128x128_S2 = 55, TILE_K64_PF_256x128_S3_W8 = 56,
+    TILE_COUNT = 57
 };
 const char *tile_name(int tile);
 bool tile_needs_cin64(int tile);
 bool tile_is_rows(int tile);      // 3x3 stride-1 only, bordered input
+bool tile_is_pf(int tile);        // software-pipelined 64-deep tile kernel (single problems)
 bool tile_is_rows_pt(int tile);   // ... its persistent form (groups allowed)
 bool tile_is_tail(int tile);      // runs ConvLaunch::tail_* as well; needs cout == the tile's BN
 bool tile_reads_lo(int tile);     // can serve ConvLaunch::in_lo

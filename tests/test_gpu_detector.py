@@ -768,7 +768,7 @@ def test_head_final_equals_separate_launches(pkg, wdir, monkeypatch, scale, size
         assert np.array_equal(res["off"][1][i][2].view(np.int32), res["on"][1][i][2].view(np.int32))         # pred
 
 
-@pytest.mark.parametrize("tile", [33, 34, 35, 36, 37, 48, 49, 53])      # 48, 49: the one-workgroup-per-CU big tiles (144 / 128 KiB of LDS); 53: 256x128 with 16 waves
+@pytest.mark.parametrize("tile", [33, 34, 35, 36, 37, 48, 49, 53, 55, 56])      # 48, 49: the one-workgroup-per-CU big tiles (144 / 128 KiB of LDS); 53: 256x128 with 16 waves; 55, 56: the software-pipelined k-loop (4 waves 128x128, 8 waves 256x128)
 def test_eight_wave_tiles(pkg, wdir, monkeypatch, tile):
     """The 64-deep tile kernel with EIGHT waves per workgroup (the global->LDS path sustains ~5 B/clk per wave, so the
     big tiles issue their operands from twice as many waves): forced onto every single-launch conv with cin % 64 == 0,
@@ -779,7 +779,7 @@ def test_eight_wave_tiles(pkg, wdir, monkeypatch, tile):
     for epi in ("1", "0"):
         monkeypatch.setenv("RTMODT_EPI16", epi)
         det, w = make_detector(pkg, wdir, "s", 320, autotune=False, batch=2)
-        used = [n for n, _, _ in det.profile(1) if "/8w" in n or "/16w" in n]
+        used = [n for n, _, _ in det.profile(1) if "/8w" in n or "/16w" in n or "k64pf:" in n]
         assert len(used) >= 15, used
         frames = list(pkg.synth.frames(2, 320, 320, seed=91))
         det.detect_batch(frames)

@@ -356,6 +356,17 @@ int main(int argc, char **argv) {
                 if (run_conv1x1(t, sh[0], sh[1], sh[2], 32)) return 1;
         return 0;
     }
+    if (argc > 1 && !strcmp(argv[1], "pf")) {                                     // the software-pipelined k-loop against the plain tile kernels
+        const int shapes[][3] = {{256, 256, 40}, {512, 256, 40}, {384, 128, 80}, {768, 256, 40}};
+        for (auto &sh : shapes)
+            for (int t : {TILE_K64_128x128_S2, TILE_K64_PF_128x128_S2, TILE_K64_128x128_S2_W8, TILE_PT_128x128_S2, TILE_K64_256x128_S3_W8, TILE_K64_PF_256x128_S3_W8})
+                if (run_conv1x1(t, sh[0], sh[1], sh[2], 32)) return 1;
+        for (int t : {TILE_K64_128x128_S2, TILE_K64_PF_128x128_S2, TILE_K64_128x128_S2_W8, TILE_PT_128x128_S2, TILE_K64_256x128_S3_W8, TILE_K64_PF_256x128_S3_W8, TILE_ROWS_K64_256x64_W8}) {
+            if (run_conv3(t, 128, 128, 1, 40, 32, 0)) return 1;                  // 6.m / 12.m / 18.m
+            if (run_conv3(t, 128, 256, 2, 80, 32, 0)) return 1;                  // layer 5
+        }
+        return 0;
+    }
     if (argc > 1 && !strcmp(argv[1], "ws")) {
         if (run_conv1x1(TILE_WS_128x128, 256, 128, 80, 32)) return 1;          // 4.cv2 at 32 frames
         if (run_conv1x1(TILE_128x64, 256, 128, 80, 32)) return 1;
