@@ -420,11 +420,8 @@ int launch_one(const BneckArgs &a0, int H, int W, int B, hipStream_t s) {
     static_assert(LDS <= G::LDS_TAIL, "LDS budget");
     BneckArgs a = a0;
     a.tiles_x = cdiv(W, TW); a.tiles_y = cdiv(H, TH);
-    static size_t attr = 0;
-    if ((size_t)LDS > attr) {
-        RT_HIP(hipFuncSetAttribute((const void *)bottleneck_fused<CH, TH, TW, N2T>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-        attr = LDS;
-    }
+    static DynLdsSeen seen;
+    RT_TRY(raise_dynamic_lds((const void *)bottleneck_fused<CH, TH, TW, N2T>, (size_t)LDS, seen));
     hipLaunchKernelGGL((bottleneck_fused<CH, TH, TW, N2T>), dim3(a.tiles_x * a.tiles_y * B), dim3(BN_THREADS), LDS, s, a);
     RT_HIP(hipGetLastError());
     return RTMODT_OK;

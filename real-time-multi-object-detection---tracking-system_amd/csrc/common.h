@@ -41,6 +41,20 @@ static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; 
 
 typedef _Float16 f16;
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a PER-DEVICE attribute of a kernel: raise it once per (device, size), on the device that is
+// current (a process that builds detectors on two devices must not skip the second because the first already raised it).  `seen` = the
+// caller's static per-kernel table.
+struct DynLdsSeen { size_t bytes[64] = {}; };
+static inline int raise_dynamic_lds(const void *kernel, size_t smem, DynLdsSeen &seen) {
+    int dev = 0;
+    RT_HIP(hipGetDevice(&dev));
+    const bool tracked = dev >= 0 && dev < 64;
+    if (tracked && smem <= seen.bytes[dev]) return RTMODT_OK;
+    RT_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    if (tracked) seen.bytes[dev] = smem;
+    return RTMODT_OK;
+}
+
 // SiLU of every conv epilogue: x / (1 + e^-x) as v_mul, v_exp_f32, v_add, v_rcp_f32, v_mul (the two transcendentals issue at a
 // quarter of the VALU rate).  -DRTMODT_ABLATE_SILU2 (DIAGNOSTIC build) evaluates it TWICE, on x and on x + 1e-30, and returns a value within
 // an ulp of the right one: same data, same decisions, twice the activation work -- which prices the activation in time and in clock

@@ -2321,11 +2321,8 @@ int launch_sppf_pool(const TensorView &y, const TensorView &p1, const TensorView
     size_t smem = (size_t)y.H * y.W * 16 * 4;
     RT_CHECK(smem <= 150 * 1024, RTMODT_E_UNSUPPORTED, "launch_sppf_pool: %dx%d tile exceeds LDS", y.H, y.W);
     int chunks = y.c / 8;
-    static size_t attr_bytes = 0;                      // raised once, outside graph capture (engine runs an eager pass first)
-    if (smem > attr_bytes) {
-        RT_HIP(hipFuncSetAttribute((const void *)sppf_pool, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        attr_bytes = smem;
-    }
+    static DynLdsSeen seen;                            // raised once per device, outside graph capture (engine runs an eager pass first)
+    RT_TRY(raise_dynamic_lds((const void *)sppf_pool, smem, seen));
     hipLaunchKernelGGL(sppf_pool, dim3(B * chunks), dim3(512), smem, s,      // 20x20 pixels at P5: one pass of 512 threads per phase
                        y.base + y.coff, y.H + 2 * y.pad, y.W + 2 * y.pad, y.C,
                        y.pad, y.H, y.W, p1.base + p1.coff, p2.base + p2.coff, p3.base + p3.coff, y.C, chunks);

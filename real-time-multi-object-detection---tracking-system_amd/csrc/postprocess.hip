@@ -768,11 +768,8 @@ int launch_nms(const NmsArgs &a, hipStream_t s) {
     // with 1024 threads they cross at ~500 candidates (profiles/r03/nms_phases/sort_crossover.txt: 1 000 candidates 25 vs 18 us,
     // 2 000: 74 vs 24); the 256-thread form keeps round 2's 2 048
     const int rank_max = rm ? min(atoi(rm), RANK_LDS_MAX) : (wide ? 512 : RANK_LDS_MAX);
-    static size_t attr_bytes[2] = {0, 0};                  // raise the dynamic-LDS limit once per size, not per launch
-    if (smem > attr_bytes[wide]) {
-        RT_HIP(hipFuncSetAttribute(wide ? (const void *)nms_kernel<1024> : (const void *)nms_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        attr_bytes[wide] = smem;
-    }
+    static DynLdsSeen seen[2];                             // raise the dynamic-LDS limit once per device and size, not per launch
+    RT_TRY(raise_dynamic_lds(wide ? (const void *)nms_kernel<1024> : (const void *)nms_kernel<256>, smem, seen[wide]));
     if (wide) hipLaunchKernelGGL(nms_kernel<1024>, dim3(a.B), dim3(1024), smem, s, a, dbg_stop, rank_max);
     else hipLaunchKernelGGL(nms_kernel<256>, dim3(a.B), dim3(256), smem, s, a, dbg_stop, rank_max);
     RT_HIP(hipGetLastError());

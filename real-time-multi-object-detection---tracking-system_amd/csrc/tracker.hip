@@ -608,13 +608,8 @@ int launch_tracker_update(const TrackerArgs &a, hipStream_t s) {
     size_t smem = tracker_smem_bytes(a.max_tracks, a.max_dets) + (a.assign_mode == RTMODT_ASSIGN_LAPJV ? lap_smem_bytes(a.max_dets) + 8 : 0);
     RT_CHECK(smem <= 150 * 1024, RTMODT_E_INVALID, "tracker: max_tracks %d / max_dets %d need %zu B of LDS (> 160 KiB)", a.max_tracks,
              a.max_dets, smem);
-    static size_t attr_bytes[64] = {};                     // the attribute is per device
-    int dev = 0;
-    RT_HIP(hipGetDevice(&dev));
-    if (dev >= 0 && dev < 64 && smem > attr_bytes[dev]) {
-        RT_HIP(hipFuncSetAttribute((const void *)tracker_update, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        attr_bytes[dev] = smem;
-    }
+    static DynLdsSeen seen;                                // the attribute is per device
+    RT_TRY(raise_dynamic_lds((const void *)tracker_update, smem, seen));
     hipLaunchKernelGGL(tracker_update, dim3(a.n_streams), dim3(TRK_THREADS), smem, s, a);
     RT_HIP(hipGetLastError());
     return RTMODT_OK;
@@ -702,11 +697,8 @@ int launch_assign_lapjv(const float *iou, int m, int n, double cost_limit, int32
                         hipStream_t s) {
     size_t smem = (size_t)(2 * m + n + TRK_WAVES + 1) * 4 + 8 + lap_smem_bytes(n);
     RT_CHECK(smem <= 150 * 1024, RTMODT_E_INVALID, "assign_lapjv: %d x %d needs %zu B of LDS", m, n, smem);
-    static size_t attr_bytes = 0;
-    if (smem > attr_bytes) {
-        RT_HIP(hipFuncSetAttribute((const void *)assign_lapjv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        attr_bytes = smem;
-    }
+    static DynLdsSeen seen;
+    RT_TRY(raise_dynamic_lds((const void *)assign_lapjv_kernel, smem, seen));
     hipLaunchKernelGGL(assign_lapjv_kernel, dim3(1), dim3(TRK_THREADS), smem, s, iou, m, n, cost_limit, row_to_col, col_used, err);
     RT_HIP(hipGetLastError());
     return RTMODT_OK;

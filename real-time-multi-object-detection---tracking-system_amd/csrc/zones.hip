@@ -347,11 +347,8 @@ ZoneArgs make_args(rtmodt_zones *z, double now, int64_t frame_id) {
 int launch(rtmodt_zones *z, const ZoneArgs &a, int n_streams, hipStream_t s) {
     size_t smem = (size_t)z->cap * 8 + ((size_t)z->cap + 2) * 4 + (size_t)std::max(z->n_pts, 1) * 8 + (ZN_WAVES + 1) * 4 + 32;
     RT_CHECK(smem <= 150 * 1024, RTMODT_E_INVALID, "zones: capacity %d needs %zu B of LDS", z->cap, smem);
-    static size_t attr_bytes = 0;
-    if (smem > attr_bytes) {
-        RT_HIP(hipFuncSetAttribute((const void *)zones_update, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        attr_bytes = smem;
-    }
+    static DynLdsSeen seen;
+    RT_TRY(raise_dynamic_lds((const void *)zones_update, smem, seen));
     hipLaunchKernelGGL(zones_update, dim3(n_streams), dim3(ZN_THREADS), smem, s, a);
     RT_HIP(hipGetLastError());
     return RTMODT_OK;
