@@ -591,11 +591,13 @@ __device__ __forceinline__ void conv_mfma64_body(const ConvArgs &p, const int bx
     for (int i = 0; i < DEPTH; ++i)
         if (i < nk) issue(i, i);
     int rstage = 0, wstage = DEPTH % NSTAGE;
+    STAMP(0);
     if constexpr (!PF) {
     for (int kt = 0; kt < nk; ++kt) {
         wait_steps<LA + LBp, DEPTH - 1>(min(DEPTH - 1, nk - 1 - kt));
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+        if (kt < 5) STAMP(1 + kt);
         if (kt + DEPTH < nk) issue(kt + DEPTH, wstage);
         const unsigned char *sbase = lds + rstage * STAGE;
         rstage = rstage + 1 == NSTAGE ? 0 : rstage + 1;
@@ -653,6 +655,7 @@ __device__ __forceinline__ void conv_mfma64_body(const ConvArgs &p, const int bx
         if (DEPTH < nk) issue(DEPTH, wstage);               // the ring's last free slot
         load_frags(lds, rd_off0, fa0, fb0);
         for (int kt = 0; kt < nk; ++kt) {
+            if (kt < 5) STAMP(1 + kt);
             const unsigned char *sbase = lds + rstage * STAGE;
             __builtin_amdgcn_s_waitcnt(0xC07F);             // lgkmcnt(0): set 0 (requested a whole MFMA block ago) is here -- said with the builtin so that the
             load_frags(sbase, rd_off1, fa1, fb1);           // compiler's own wait in front of the MFMAs does not also cover the loads of set 1 issued now
@@ -691,6 +694,7 @@ __device__ __forceinline__ void conv_mfma64_body(const ConvArgs &p, const int bx
         }
     }
 
+    STAMP(6);
     if constexpr (N2T > 0) {
         epilogue_tail<BM, BN, TM, TN, N2T>(p, acc, bv, lds, wm, wn, [&](int pm, long &o) { return tail_pixel_offset(p, m0 + pm, o); });
         return;

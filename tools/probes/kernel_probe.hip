@@ -121,6 +121,19 @@ static int run_conv1x1(int tile, int cin, int cout, int HW, int B) {
             printf("  %-40s median %8.0f clk\n", nm[k - 1], d[d.size() / 2]);
         }
     }
+    if (tile_needs_cin64(tile) && !tile_is_ws(tile) && !tile_is_pt(tile) && !tile_is_rows(tile)) {      // conv_mfma64_body: 0 = loop entry, 1..5 = k-steps 0..4 (after the barrier), 6 = loop exit, 9 = end
+        std::vector<unsigned long long> st((size_t)wgs * 16);
+        CK(hipMemcpy(st.data(), d_st, st.size() * 8, hipMemcpyDeviceToHost));
+        const char *nm[] = {"prologue -> step 0 ready", "step 0", "step 1", "step 2", "step 3", "rest of the k-loop", "epilogue: everybody out of the loop", "epilogue: bias + SiLU + LDS staging", "epilogue: barrier"};
+        const int idx[] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9};
+        for (int k = 1; k < 10; ++k) {
+            std::vector<double> d;
+            for (int g = 0; g < 256; ++g) { const unsigned long long *s = &st[(size_t)g * 16]; if (s[idx[k]] && s[idx[k - 1]]) d.push_back((double)(s[idx[k]] - s[idx[k - 1]])); }
+            if (d.empty()) continue;
+            std::sort(d.begin(), d.end());
+            printf("  %-40s median %8.0f clk\n", nm[k - 1], d[d.size() / 2]);
+        }
+    }
     hipFree(in); hipFree(out); hipFree(w); hipFree(bias); hipFree(d_st);
     return 0;
 }
@@ -354,6 +367,12 @@ int main(int argc, char **argv) {
         for (auto &sh : shapes)
             for (int t : {TILE_K64_128x128_S2_W8, TILE_PT_128x128_S2, TILE_PT_128x128_S3, TILE_PT_128x64_S3})
                 if (run_conv1x1(t, sh[0], sh[1], sh[2], 32)) return 1;
+        return 0;
+    }
+    if (argc > 1 && !strcmp(argv[1], "ksteps")) {                                 // k-step time of the 64-deep tile kernels by tile shape (stamped build)
+        for (int t : {TILE_K64_128x128_S2, TILE_K64_PF_128x128_S2, TILE_K64_128x128_S2_W8, TILE_K64_128x128_S3_W8, TILE_K64_256x128_S2_W8, TILE_K64_256x128_S3_W8, TILE_K64_PF_256x128_S3_W8,
+                      TILE_K64_256x256_S2_W8, TILE_K64_128x64_S3_W8, TILE_K64_64x64_S3, TILE_K64_64x64_S4})
+            if (run_conv1x1(t, 768, 256, 40, 32)) return 1;
         return 0;
     }
     if (argc > 1 && !strcmp(argv[1], "pf")) {                                     // the software-pipelined k-loop against the plain tile kernels
