@@ -594,11 +594,13 @@ __device__ __forceinline__ void conv_mfma64_body(const ConvArgs &p, const int bx
     STAMP(0);
     if constexpr (!PF) {
     for (int kt = 0; kt < nk; ++kt) {
+        if (kt == 2) STAMP(10);
         wait_steps<LA + LBp, DEPTH - 1>(min(DEPTH - 1, nk - 1 - kt));
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         if (kt < 5) STAMP(1 + kt);
         if (kt + DEPTH < nk) issue(kt + DEPTH, wstage);
+        if (kt == 2) STAMP(11);
         const unsigned char *sbase = lds + rstage * STAGE;
         rstage = rstage + 1 == NSTAGE ? 0 : rstage + 1;
         wstage = wstage + 1 == NSTAGE ? 0 : wstage + 1;
@@ -624,6 +626,7 @@ __device__ __forceinline__ void conv_mfma64_body(const ConvArgs &p, const int bx
         // stage's sub-step 0 are requested and the DMA pieces of stage kt + 1 + DEPTH are issued one by one between the MFMAs of
         // sub-step 1 (into the slot stage kt just left).  Same ring, same counted waits, same results as the plain loop.
         constexpr int NPW = LA + LBp, NMF = TM * TN;
+        constexpr bool PF_INTERLEAVE = false;               // true: one DMA piece between every NMF / NPW MFMAs of set 1 (measured: the step gets LONGER, profiles/r03/pf)
         int p_kt = -1, p_stage = 0, p_tap = 0, p_c0 = 0;
         bool p_lo = false;
         auto begin_issue = [&](int kt, int stage) {
@@ -674,6 +677,10 @@ __device__ __forceinline__ void conv_mfma64_body(const ConvArgs &p, const int bx
                 asm volatile("" ::: "memory");
                 if (kt + 1 + DEPTH < nk) begin_issue(kt + 1 + DEPTH, rstage);
                 load_frags(lds + nstage * STAGE, rd_off0, fa0, fb0);
+                if (!PF_INTERLEAVE && p_kt >= 0) {
+#pragma unroll
+                    for (int i = 0; i < NPW; ++i) issue_piece(i);              // the step's DMA pieces in one block, as the plain loop issues them
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
             int piece = 0;
@@ -683,7 +690,7 @@ __device__ __forceinline__ void conv_mfma64_body(const ConvArgs &p, const int bx
                 for (int u = 0; u < TN; ++u) {
                     acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb1[u], fa1[t], acc[t][u], 0, 0, 0);
                     const int done = t * TN + u + 1;
-                    if (piece < NPW && (piece + 1) * NMF <= done * NPW) {
+                    if (PF_INTERLEAVE && piece < NPW && (piece + 1) * NMF <= done * NPW) {
                         if (p_kt >= 0) issue_piece(piece);
                         ++piece;
                         __builtin_amdgcn_sched_barrier(0);

@@ -133,6 +133,16 @@ static int run_conv1x1(int tile, int cin, int cout, int HW, int B) {
             std::sort(d.begin(), d.end());
             printf("  %-40s median %8.0f clk\n", nm[k - 1], d[d.size() / 2]);
         }
+        // inside step 2 (plain loop): 10 = top of the iteration, 3 = behind its barrier, 11 = behind its DMA issue, 4 = behind the next barrier
+        const int pa[][2] = {{10, 3}, {3, 11}, {11, 4}};
+        const char *pn[] = {"step 2: wait for the stage + barrier", "step 2: issue of the DMA pieces", "step 2: fragment reads + MFMAs + next wait"};
+        for (int k = 0; k < 3; ++k) {
+            std::vector<double> d;
+            for (int g = 0; g < 256; ++g) { const unsigned long long *s = &st[(size_t)g * 16]; if (s[pa[k][0]] && s[pa[k][1]]) d.push_back((double)(s[pa[k][1]] - s[pa[k][0]])); }
+            if (d.empty()) continue;
+            std::sort(d.begin(), d.end());
+            printf("  %-40s median %8.0f clk\n", pn[k], d[d.size() / 2]);
+        }
     }
     hipFree(in); hipFree(out); hipFree(w); hipFree(bias); hipFree(d_st);
     return 0;
