@@ -18,6 +18,7 @@
 // compared against all later live boxes by the whole workgroup (bitmap in LDS), and the
 // loop stops after max_det keeps -- O(max_det * n) instead of the n^2 mask.
 #include "kernels.h"
+#include "tile_math.h"
 
 #include <climits>
 #include <type_traits>
@@ -355,7 +356,7 @@ template <int G, int PP_THREADS>
 __device__ __forceinline__ void bitonic_step(unsigned long long *keys, int P, int k, int s0, int ls) {
     constexpr int E = 1 << G;
     for (int t = threadIdx.x; t < (P >> G); t += PP_THREADS) {
-        const int i0 = ((t >> ls) << (ls + G)) | (t & (s0 - 1));           // G zero bits inserted at bit ls
+        const int i0 = bitonic_i0(t, ls, G, s0);                            // G zero bits inserted at bit ls (tile_math.h)
         const bool desc = (i0 & k) == 0;
         unsigned long long v[E];
 #pragma unroll
@@ -374,20 +375,6 @@ __device__ __forceinline__ void bitonic_step(unsigned long long *keys, int P, in
 #pragma unroll
         for (int e = 0; e < E; ++e) keys[i0 + e * s0] = v[e];
     }
-}
-
-// k-th (0-based) set bit of w; k < popcount(w)
-__device__ __forceinline__ int kth_set_bit(unsigned long long w, int k) {
-    int b = 0;
-    unsigned x = (unsigned)w;
-    int c = __popc(x);
-    if (k >= c) { k -= c; b = 32; x = (unsigned)(w >> 32); }
-    c = __popc(x & 0xFFFFu); if (k >= c) { k -= c; b += 16; x >>= 16; }
-    c = __popc(x & 0xFFu);   if (k >= c) { k -= c; b += 8; x >>= 8; }
-    c = __popc(x & 0xFu);    if (k >= c) { k -= c; b += 4; x >>= 4; }
-    c = __popc(x & 0x3u);    if (k >= c) { k -= c; b += 2; x >>= 2; }
-    if (k >= (int)(x & 1u)) b += 1;
-    return b;
 }
 
 // Greedy suppression over boxes sorted by descending score, 64 STILL-ALIVE sorted positions at a time
@@ -668,7 +655,7 @@ __global__ __launch_bounds__(PP_THREADS) void nms_kernel(NmsArgs a, int dbg_stop
         for (int k = 2; k <= P; k <<= 1) {
             int j = k >> 1;
             while (j > 0) {
-                const int g = j >= 4 ? 3 : (j >= 2 ? 2 : 1);            // strides in this step
+                const int g = bitonic_group(j);                         // strides in this step (tile_math.h)
                 const int s0 = j >> (g - 1), ls = __builtin_ctz(s0);     // the smallest of them
                 if (g == 3) bitonic_step<3, PP_THREADS>(skeys, P, k, s0, ls);
                 else if (g == 2) bitonic_step<2, PP_THREADS>(skeys, P, k, s0, ls);

@@ -64,4 +64,48 @@ template <int CB> RT_HD int swz_plane_off(int R, int c) {
     return CB == 128 ? (R >> 3) * 1024 + (R & 7) * 128 + (swz_slot<CB>(R, c) << 4) : (R >> 4) * 1024 + (R & 15) * 64 + (swz_slot<CB>(R, c) << 4);
 }
 
+// ---- nms_kernel (postprocess.hip) ----
+// k-th (0-based) set bit of w; k < popcount(w): binary search over the halves' popcounts
+RT_HD int kth_set_bit(unsigned long long w, int k) {
+    int b = 0;
+    unsigned x = (unsigned)w;
+    int c = __builtin_popcount(x);
+    if (k >= c) { k -= c; b = 32; x = (unsigned)(w >> 32); }
+    c = __builtin_popcount(x & 0xFFFFu); if (k >= c) { k -= c; b += 16; x >>= 16; }
+    c = __builtin_popcount(x & 0xFFu);   if (k >= c) { k -= c; b += 8; x >>= 8; }
+    c = __builtin_popcount(x & 0xFu);    if (k >= c) { k -= c; b += 4; x >>= 4; }
+    c = __builtin_popcount(x & 0x3u);    if (k >= c) { k -= c; b += 2; x >>= 2; }
+    if (k >= (int)(x & 1u)) b += 1;
+    return b;
+}
+
+// Bitonic network, G consecutive strides (s0 << (G - 1), ..., s0) per barrier step: worker t of the step owns the 2^G keys
+// i0 + e * s0, i0 = t with G zero bits inserted at bit log2(s0); the schedule of one k-phase (strides k/2 ... 1) takes up to three
+// strides per step from the top.  bitonic_run applies the whole network to keys[0, P) in place (descending), one worker after the
+// other -- the host-side statement of what nms_kernel's threads do between barriers (tests/native/tile_math_check.cpp).
+RT_HD int bitonic_i0(int t, int ls, int G, int s0) { return ((t >> ls) << (ls + G)) | (t & (s0 - 1)); }
+RT_HD int bitonic_group(int j) { return j >= 4 ? 3 : (j >= 2 ? 2 : 1); }        // strides taken by the step that starts at stride j
+template <typename K>
+inline void bitonic_run(K *keys, int P) {
+    for (int k = 2; k <= P; k <<= 1) {
+        int j = k >> 1;
+        while (j > 0) {
+            const int g = bitonic_group(j), s0 = j >> (g - 1), E = 1 << g;
+            int ls = 0;
+            while ((1 << ls) < s0) ++ls;
+            for (int t = 0; t < (P >> g); ++t) {
+                const int i0 = bitonic_i0(t, ls, g, s0);
+                const bool desc = (i0 & k) == 0;
+                for (int h = E >> 1; h >= 1; h >>= 1)
+                    for (int e = 0; e < E; ++e)
+                        if ((e & h) == 0) {
+                            K &x = keys[i0 + e * s0], &y = keys[i0 + (e | h) * s0];
+                            if (desc ? (x < y) : (x > y)) { const K tmp = x; x = y; y = tmp; }
+                        }
+            }
+            j >>= g;
+        }
+    }
+}
+
 }  // namespace rtmodt

@@ -1,5 +1,6 @@
 // Host-side check of the integer arithmetic the conv kernels use (csrc/tile_math.h), compiled with g++ by
 // tests/test_tile_math_cpu.py.  Exit code 0 and a line "ok ..." on success; the first counter-example otherwise.
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -110,4 +111,31 @@ static int check_pt_run() {
     return 0;
 }
 
-int main() { return check_fastdiv() || check_xcd_tile() || check_pt_run() || check_swizzle(); }
+// nms_kernel's integer helpers: the k-th set bit of a word, and the bitonic schedule (up to three strides per step) as a sorting network
+static int check_nms_math() {
+    std::mt19937_64 rng(99);
+    for (int it = 0; it < 200000; ++it) {
+        unsigned long long w = rng();
+        if (it % 3 == 0) w &= rng();
+        if (it % 5 == 0) w |= rng();
+        if (it < 64) w = 1ull << it;
+        if (it == 64) w = ~0ull;
+        int k = 0;
+        for (int b = 0; b < 64; ++b)
+            if ((w >> b) & 1ull) { if (kth_set_bit(w, k) != b) { printf("kth_set_bit(%llx, %d) = %d, want %d\n", w, k, kth_set_bit(w, k), b); return 1; } ++k; }
+    }
+    for (int P = 2; P <= 16384; P <<= 1)
+        for (int rep = 0; rep < (P <= 1024 ? 20 : 3); ++rep) {
+            std::vector<unsigned long long> keys(P), ref;
+            for (auto &v : keys) v = rep == 0 ? rng() % 7 : rng();          // many equal keys in the first repetition
+            if (rep == 1) for (int i = 0; i < P; ++i) keys[i] = i;            // ascending input
+            ref = keys;
+            bitonic_run(keys.data(), P);
+            std::sort(ref.begin(), ref.end(), [](unsigned long long a, unsigned long long b) { return a > b; });
+            if (keys != ref) { printf("bitonic_run: P %d rep %d not sorted descending\n", P, rep); return 1; }
+        }
+    printf("ok nms math\n");
+    return 0;
+}
+
+int main() { return check_fastdiv() || check_xcd_tile() || check_pt_run() || check_swizzle() || check_nms_math(); }

@@ -1,5 +1,5 @@
 """The integer arithmetic of the conv kernels that can be wrong without any kernel crashing -- division by launch constants
-(every epilogue), the XCD-aware tile order, the persistent tile kernel's ownership of pixel tiles, the fused Bottleneck's LDS swizzle -- lives in
+(every epilogue), the XCD-aware tile order, the persistent tile kernel's ownership of pixel tiles, the fused Bottleneck's LDS swizzle, nms_kernel's bit selection and bitonic schedule -- lives in
 ``csrc/tile_math.h`` as plain C++; this test compiles it with g++ and checks it exhaustively on the host (no GPU)."""
 import os
 import subprocess
@@ -15,4 +15,4 @@ def test_tile_math_exhaustive(tmp_path):
     out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     sys.stdout.write(out.stdout)
     assert out.returncode == 0, out.stdout + out.stderr
-    assert out.stdout.count("ok ") == 4
+    assert out.stdout.count("ok ") == 5
