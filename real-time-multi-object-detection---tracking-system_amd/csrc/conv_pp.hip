@@ -1,0 +1,420 @@
+// conv_pp.hip -- 3x3 / stride-1 convolution with the two halves of a workgroup in ANTI-PHASE ("ping-pong") for gfx950.
+//
+// What it replaces: the 3x3 Conv+BN+SiLU layers of the YOLOv8 forward pass behind /root/reference/src/detection/detector.py:100-111
+// (C2f bottlenecks, Detect stages 0 and 1: 58 % of the net's FLOPs).  Same arithmetic as conv3x3_rows (conv.hip): implicit GEMM over
+// padded pixel positions on v_mfma_f32_16x16x32_f16, fp32 accumulate, weights = MFMA A operand, pixels = B operand.
+//
+// Why another kernel (profiles/r03/pf/): in every tile kernel of conv.hip all waves of a workgroup do the same thing at
+// the same time -- wait for the stage, issue the next DMA pieces, read fragments, multiply -- so the matrix pipe of a SIMD idles while its
+// waves wait, issue and read (a k-step of 1 500-2 000 clk around 512 clk of MFMA; two workgroups per CU at a random phase reach ~60 %).
+// Here ONE workgroup of 8 waves owns a 256-pixel x BN-cout tile and is cut into two halves (waves 0-3 / 4-7: one wave of each half on every
+// SIMD) that run the same program ONE BARRIER INTERVAL APART:
+//
+//      interval      2j                    2j+1                  2j+2
+//      half 0    R(j): read+issue      M(j): 32 x MFMA       R(j+1)
+//      half 1    M(j-1)                R(j): read+issue      M(j)
+//
+// so in every interval one wave per SIMD feeds the matrix pipe while its partner reads its fragments (ds_read_b128), issues the LDS-DMA
+// pieces of later phases and waits for its own older pieces (counted vmcnt).  A phase = one tap (kh, kw) x 64 input channels:
+// 4 x TN MFMA tiles x 2 k-halves per wave.  Tap reuse as in conv3x3_rows: a strip of 256 + 8 padded positions per (kh, 64 channels) serves
+// kw = 0, 1, 2 at row offsets 0, 1, 2.  LDS: two strip slots (33 KiB each) + a three-slot ring of per-tap weight slices (BN x 128 B).
+// A workgroup is persistent: it walks over tiles id, id + G, ... of a (grouped) launch and the DMA stream runs on into the next tile
+// (its first strip and two taps are in flight under this tile's last phases and epilogue).
+//
+// Order rules (cdna guide, "Read a staged buffer one phase AFTER the wait that retires it"):
+//  * RAW  a wave waits for ITS pieces of phase j+1 inside R(j), in front of the barrier that ends R(j); every reader of phase j+1 is behind a
+//         later barrier (half 0: the next one; half 1: the one after).
+//  * WAR  a slot is refilled from R(j+1) of half 0 on; its last reader is R(j) of half 1, one interval earlier, and every R ends with
+//         s_waitcnt lgkmcnt(0) IN FRONT of its barrier -- the reads have returned before any wave can issue into the slot.
+//  * vmcnt retires in issue order, so inside a phase the weight pieces (needed one tap later, L2-hot) are issued BEFORE the strip pieces (needed a
+//         whole super-step later, from the Infinity Cache / HBM).  Issue lists per phase and the resulting counts: tile_math.h (pp_issue, pp_wait_count),
+//         checked by a host-side replay of the stream (tests/test_tile_math_cpu.py).
+#include "conv_dev.h"
+
+namespace rtmodt {
+
+// The DMA schedule of a super-step (issue lists per phase, counted waits): pp_issue / pp_wait_count in tile_math.h, replayed on the host by
+// tests/native/tile_math_check.cpp.
+
+template <int BN>
+struct PpCfg {
+    static constexpr int BM = 256, NW = 8;
+    static constexpr int NAP = BM / 8 + 1;          // strip pieces of 8 rows x 128 B: 264 rows >= 256 + 2
+    static constexpr int ASLOT = NAP * 1024;
+    static constexpr int NBP = BN / 8;              // weight pieces per tap
+    static constexpr int BSLOT = NBP * 1024;
+    static constexpr int B_OFF = 2 * ASLOT;
+    static constexpr int LDS_BYTES = B_OFF + 3 * BSLOT;
+    static constexpr int LB = NBP / NW;             // weight pieces per wave and tap
+    static constexpr int TM = 4, TN = BN / 32;      // a wave owns 64 pixels x BN / 2 couts
+    static_assert(NBP % NW == 0, "weight pieces must split evenly over the waves");
+    static_assert(LDS_BYTES <= 160 * 1024, "LDS");
+};
+
+// Diagnostic build only (-DRTMODT_STAMP -DPP_FINE): lane 0 of waves 0 and 4 stamps the parts of ONE phase (first tile, super-step 1, kw 1) into slots
+// 0-7 / 8-15 of the workgroup's stamp row: R start, pieces issued, fragments read, counted wait done, barrier passed, MFMAs issued, barrier passed
+#if defined(RTMODT_STAMP) && defined(PP_FINE)
+#define FSTAMP(k)                                                                                                   \
+    do {                                                                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                                          \
+        if (fine && (threadIdx.x & 255) == 0) {                                                                     \
+            unsigned long long t_;                                                                                  \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                              \
+            g_stamps[(size_t)blockIdx.x * 16 + (threadIdx.x >> 8) * 8 + (k)] = t_;                                  \
+        }                                                                                                           \
+        __builtin_amdgcn_sched_barrier(0);                                                                          \
+    } while (0)
+#undef STAMP
+#define STAMP(k)
+#else
+#define FSTAMP(k)
+#endif
+
+template <int N>
+__device__ __forceinline__ void pp_wait() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <int BN>
+__global__ __launch_bounds__(512) void conv3x3_pp(ConvGroupArgs g, int total_ids) {
+    using C = PpCfg<BN>;
+    constexpr int BM = C::BM, NW = C::NW, LB = C::LB, TM = C::TM, TN = C::TN;
+    constexpr bool BIAS_AHEAD = BN <= 128;
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[C::LDS_BYTES];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r = lane & 15, q = lane >> 4;
+    const int half = wave >> 2;                       // 0: waves 0-3, 1: waves 4-7 (one of each per SIMD)
+    const int wm = wave >> 1, wn = wave & 1;          // 4 x 2 waves over 256 pixels x BN couts; half h owns pixel rows [128 h, 128 h + 128)
+    const bool w0 = wave == 0;
+
+    // LDS images: rows of 128 B (64 halves = 8 chunks of 16 B), chunk c of row R in slot (c + 2 (R >> 1)) & 7 -- a rotation that keeps
+    // ds_read_b128 conflict-free from ANY 16 consecutive rows (tile_math.h swz_slot<128>; the taps start reads at rows +0, +1, +2)
+    auto slot_of = [](int R, int c) { return ((c + 2 * (R >> 1)) & 7) << 4; };
+    int a_rd[3][2], b_rd[2];
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) a_rd[kw][kk] = wm * 64 * 128 + (r + kw) * 128 + slot_of(r + kw, kk * 4 + q);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) b_rd[kk] = C::B_OFF + wn * (BN / 2) * 128 + r * 128 + slot_of(r, kk * 4 + q);
+    const int ld_row = lane >> 3, ld_slot = lane & 7;
+    const int ld_chunk = ((ld_slot - 2 * (ld_row >> 1)) & 7) * 8;      // halves: the k-chunk whose slot this DMA lane fills (piece bases are multiples of 8 rows)
+
+    // A tile's DMA sources are (wave-uniform base: tensor + the tap row / channel chunk of the step) + (32-bit per-lane byte offset, fixed for the
+    // tile): global_load_lds takes the pair as SGPR base + VGPR offset, so a piece costs scalar adds and one vector instruction -- no per-piece 64-bit
+    // VALU address chain beside the partner's MFMAs (profiles/r04/pp/run3.txt: ~108 clk per piece with per-lane 64-bit addresses, MFMA phase 670 clk for 512)
+    struct Tile {
+        const char *in, *wt;                          // of the tile's problem (wave-uniform)
+        int z, m0, n0, ns, cin;
+        unsigned row_bytes;                           // bytes between two padded input rows (the kh step)
+        unsigned a_off[5], b_off[LB];                 // per lane, bytes: its row of strip piece wave + 8 i (i = 4: piece 32, wave 0 only); its weight row
+    };
+    const int G = gridDim.x;
+    auto locate = [&](int id, Tile &t) -> bool {      // launch-linear id -> (problem, tile); false for the alignment fillers between problems
+        int z = 0;
+        while (z + 1 < g.n && id >= g.start[z + 1]) ++z;
+        id -= g.start[z];
+        const ConvArgs &p = g.p[z];
+        const int gx = g.gx[z], gy = (p.cout + BN - 1) / BN;
+        if (id >= gx * gy) return false;
+        const int by = id / gx, bx = id - by * gx;
+        int mt, nt;
+        xcd_tile(gx, gy, bx, by, mt, nt);
+        t.z = z; t.m0 = mt * BM; t.n0 = nt * BN; t.ns = 3 * (p.cin / 64);
+        t.in = (const char *)p.in; t.wt = (const char *)p.wt; t.cin = p.cin; t.row_bytes = (unsigned)(p.in_Wp * p.in_cs) * 2u;
+        // positions past the last image are clamped so that position + kh rows stays inside the tensor: two rows above its last pixel, on the (zero)
+        // right border column for kh = 0, 1 and on the last (zero) pixel for kh = 2; no enumerated position of a real image reaches that far
+        const int clamp = p.last_pos - 2 * p.in_Wp;
+#pragma unroll
+        for (int i = 0; i < 5; ++i) t.a_off[i] = (unsigned)(min(rows_pos(p, t.m0 + (wave + NW * i) * 8 + ld_row), clamp) * p.in_cs + ld_chunk) * 2u;
+#pragma unroll
+        for (int j = 0; j < LB; ++j) t.b_off[j] = (unsigned)((t.n0 + (wave + NW * j) * 8 + ld_row) * p.kp + ld_chunk) * 2u;
+        return true;
+    };
+    auto next_valid = [&](int id, Tile &t) -> int {
+        for (; id < total_ids; id += G)
+            if (locate(id, t)) return id;
+        return total_ids;
+    };
+    auto dma = [&](const char *base, unsigned off, unsigned char *dst) {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(base + off), (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+    };
+    // weight slice of tap (kh, kw), channels [c0, c0 + 64) -> ring slot `slot`
+    auto issue_B = [&](const Tile &t, int kh, int kw, int c0, int slot) {
+        const char *base = t.wt + (size_t)(((kh * 3 + kw) * t.cin + c0) * 2);
+#pragma unroll
+        for (int j = 0; j < LB; ++j) dma(base, t.b_off[j], lds + C::B_OFF + slot * C::BSLOT + (wave + NW * j) * 1024);
+    };
+    // strip piece wave + 8 i of (kh, c0) -> strip slot `slot`
+    auto issue_A = [&](const Tile &t, int kh, int c0, int slot, int i) {
+        const char *base = t.in + ((size_t)kh * t.row_bytes + (size_t)(c0 * 2));
+        dma(base, t.a_off[i], lds + slot * C::ASLOT + (wave + NW * i) * 1024);
+    };
+
+    Tile cur, nxt, iss;                               // the tile being multiplied, the one after it, the one the DMA stream is feeding
+    int id = next_valid(blockIdx.x, cur);
+    if (id >= total_ids) return;                      // (the same for every wave of the workgroup)
+    int nid = next_valid(id + G, nxt);
+    bool have_next = nid < total_ids;
+    iss = cur;
+
+    // bias of the first tile: requested BEFORE the first DMA piece (older than all of them)
+    floatx4 bnext[TN];
+#pragma unroll
+    for (int u = 0; u < TN; ++u) bnext[u] = *(const floatx4 *)(g.p[cur.z].bias + cur.n0 + (wn * TN + u) * 16 + q * 4);
+
+    // ---- pipeline fill, in the order the steady state would have issued it: strip 0 (first part), tap 0, strip 0 (rest), tap 1 ----
+    issue_A(cur, 0, 0, 0, 0); issue_A(cur, 0, 0, 0, 1);
+    if (w0) issue_A(cur, 0, 0, 0, 4);
+    issue_B(cur, 0, 0, 0, 0);
+    issue_A(cur, 0, 0, 0, 2); issue_A(cur, 0, 0, 0, 3);
+    issue_B(cur, 0, 1, 0, 1);
+    STAMP(0);
+    pp_wait<LB>();                                    // everything but tap 1
+    __builtin_amdgcn_s_barrier();
+    STAMP(1);
+    int aslot = 0;
+    int tile_no = 0;
+
+    while (true) {
+        const ConvArgs &p = g.p[cur.z];
+        // the accumulators START at the bias (fp32; the MFMA chain then adds the products): no bias registers and no ordinary global load whose
+        // destination registers the k-loop would have to wait for -- hipcc answers ANY pending VGPR-destination load with s_waitcnt vmcnt(0) at
+        // the top of the loop, which drains the DMA ring every super-step
+        floatx4 acc[TM][TN];
+        if constexpr (!BIAS_AHEAD) {                  // (the 192-wide tile has no registers to carry the next tile's bias through the k-loop)
+            if (tile_no > 0) {
+#pragma unroll
+                for (int u = 0; u < TN; ++u) bnext[u] = *(const floatx4 *)(p.bias + cur.n0 + (wn * TN + u) * 16 + q * 4);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < TM; ++t)
+#pragma unroll
+            for (int u = 0; u < TN; ++u) acc[t][u] = bnext[u];
+        if (half == 1) __builtin_amdgcn_s_barrier();  // STAGGER: half 1 runs one interval behind half 0
+        int kh = 0, c0 = 0;
+        for (int s = 0; s < cur.ns; ++s) {
+            const bool last = s + 1 == cur.ns;
+            const bool valid = !last || have_next;    // is there a super-step s + 1 (of this tile or of the next one) to prefetch?
+            int nkh = kh, nc0 = c0 + 64;
+            if (nc0 >= cur.cin) { nc0 = 0; ++nkh; }
+            if (last) { nkh = 0; nc0 = 0; }
+            const unsigned char *sA = lds + aslot * C::ASLOT;
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const bool fine = tile_no == 0 && s == 1 && kw == 1; (void)fine;
+                FSTAMP(0);
+                // ---------------- R: DMA pieces of later phases, fragments of this phase, counted wait ----------------
+                // (the pieces go first: the texture addresser works them off while the LDS serves the fragment reads -- issued the other way round
+                // the two take turns: 16 reads ~250 clk, then ~90 clk per piece, profiles/r04/pp/)
+                if (kw == 0) {
+                    issue_B(iss, kh, 2, c0, 2);
+                    if (last && have_next) iss = nxt;                       // from here on the stream feeds the next tile
+                    if (valid) { issue_A(iss, nkh, nc0, aslot ^ 1, 0); issue_A(iss, nkh, nc0, aslot ^ 1, 1); if (w0) issue_A(iss, nkh, nc0, aslot ^ 1, 4); }
+                } else if (kw == 1) {
+                    if (valid) { issue_B(iss, nkh, 0, nc0, 0); issue_A(iss, nkh, nc0, aslot ^ 1, 2); issue_A(iss, nkh, nc0, aslot ^ 1, 3); }
+                } else {
+                    if (valid) issue_B(iss, nkh, 1, nc0, 1);
+                }
+                FSTAMP(1);
+                half8 fa[2][TM], fb[2][TN];
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+                    for (int u = 0; u < TN; ++u) fb[kk][u] = *(const half8 *)(lds + kw * C::BSLOT + u * 2048 + b_rd[kk]);
+#pragma unroll
+                    for (int t = 0; t < TM; ++t) fa[kk][t] = *(const half8 *)(sA + t * 2048 + a_rd[kw][kk]);
+                }
+                FSTAMP(2);
+                if (!valid) pp_wait<0>();             // the stream ends here: drain (once per workgroup)
+                else if (kw == 0) { if (w0) pp_wait<pp_wait_count(0, LB, true)>(); else pp_wait<pp_wait_count(0, LB, false)>(); }
+                else if (kw == 1) { if (w0) pp_wait<pp_wait_count(1, LB, true)>(); else pp_wait<pp_wait_count(1, LB, false)>(); }
+                else pp_wait<pp_wait_count(2, LB, false)>();
+                FSTAMP(3);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the fragments are in registers: the slots may be refilled behind the barrier
+                __builtin_amdgcn_s_barrier();
+                FSTAMP(4);
+                // ---------------- M: the matrix pipe is this half's ----------------
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_setprio(1);                       // (keeps hipcc from moving MFMAs across the barriers; as a priority it measured +-1 %)
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                    for (int t = 0; t < TM; ++t)
+#pragma unroll
+                        for (int u = 0; u < TN; ++u) acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[kk][u], fa[kk][t], acc[t][u], 0, 0, 0);
+                __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_sched_barrier(0);
+                FSTAMP(5);
+                __builtin_amdgcn_s_barrier();
+                FSTAMP(6);
+                if (tile_no == 0 && s == 1) STAMP(2 + kw);      // (diagnostic build only) the three phases of the second super-step
+            }
+            aslot ^= 1; kh = nkh; c0 = nc0;
+        }
+        if (half == 0) __builtin_amdgcn_s_barrier();  // BALANCE: both halves run the epilogue together (two waves per SIMD share its VALU)
+        if (tile_no == 0) STAMP(6);
+
+        // ---- epilogue straight from the accumulators (conv3x3_rows' direct-store path): padded position -> (b, y, x); border positions are junk ----
+        if (BIAS_AHEAD && have_next) {                // the next tile's bias travels under this epilogue; pinned behind the k-loop (see above)
+            int nz = nxt.z, nn0 = nxt.n0;
+            asm volatile("" : "+v"(nz), "+v"(nn0));
+            nz = __builtin_amdgcn_readfirstlane(nz); nn0 = __builtin_amdgcn_readfirstlane(nn0);
+#pragma unroll
+            for (int u = 0; u < TN; ++u) bnext[u] = *(const floatx4 *)(g.p[nz].bias + nn0 + (wn * TN + u) * 16 + q * 4);
+        }
+        // Stores in the accumulator layout are 8 bytes per lane in 32-byte runs of 16 different cache lines per instruction (9 500 clk per tile,
+        // 19 000 with the residual read the same way: profiles/r04/pp/run1_stamp.txt).  Each wave therefore turns its 64 x BN/2 outputs round by
+        // round through 4 KiB of ITS OWN in the strip slot this tile has finished with (chunk XOR pixel swizzle, no barrier: LDS serves a wave's
+        // operations in order) and stores 16 bytes per lane, whole 128-byte lines per pixel.  bias is in the accumulators; SiLU and the residual in
+        // fp32, ONE rounding: with a residual the staging holds fp32 and the shortcut is added on the store side, where it is read 16 bytes per lane.
+        {
+#if defined(RTMODT_STAMP)
+            const int ablate = p.epi_prio;            // diagnostic build: RTMODT_EPI_PRIO bit 0 = no SiLU, bit 1 = no global stores (results wrong, times only)
+#else
+            constexpr int ablate = 0;
+#endif
+            unsigned char *stg = lds + (aslot ^ 1) * C::ASLOT + wave * 4096;
+            constexpr int HB = BN / 2, CPR = HB / 8;                     // couts of this wave; 16-byte fp16 chunks per pixel
+            // the problem's scalars, fetched in ONE batch here: read where they are used (inside the lanes' branches) hipcc fetches them from the kernel
+            // argument segment again for every store, a scalar-memory round trip each -- 5 800 of the 8 000 clk this epilogue took (profiles/r04/pp/run5.txt)
+            f16 *const e_out = p.out; const f16 *const e_res = p.res;
+            const int e_M = p.M, e_Ho = p.Ho, e_Wo = p.Wo, e_wq = p.rows_wq, e_HW = p.Ho * p.rows_wq, e_cout = p.cout, e_act = p.act, e_wt = p.wthru;
+            const int e_oHp = p.out_Hp, e_oWp = p.out_Wp, e_ocs = p.out_cs, e_opad = p.out_pad, e_rHp = p.res_Hp, e_rWp = p.res_Wp, e_rcs = p.res_cs, e_rpad = p.res_pad;
+            const FastDiv e_dhwp = p.d_hwp, e_dwp = p.d_wp;
+            asm volatile("" ::"s"(e_out), "s"(e_res), "s"(e_M), "s"(e_Ho), "s"(e_Wo), "s"(e_wq), "s"(e_HW), "s"(e_cout), "s"(e_act), "s"(e_wt), "s"(e_oHp), "s"(e_oWp), "s"(e_ocs), "s"(e_opad),
+                         "s"(e_rHp), "s"(e_rWp), "s"(e_rcs), "s"(e_rpad), "s"(e_dhwp.mul), "s"(e_dhwp.shift), "s"(e_dwp.mul), "s"(e_dwp.shift));
+            auto pix_out = [&](int m, int &opix, int &rpix) -> bool {      // element offsets fit 32 bits (checked at launch)
+                if (m >= e_M) return false;
+                const int b = fdiv(m, e_dhwp), rem = m - b * e_HW;
+                const int oy = fdiv(rem, e_dwp), ox = rem - oy * e_wq;
+                if (oy >= e_Ho || ox >= e_Wo) return false;
+                opix = ((b * e_oHp + oy + e_opad) * e_oWp + ox + e_opad) * e_ocs;
+                rpix = ((b * e_rHp + oy + e_rpad) * e_rWp + ox + e_rpad) * e_rcs;
+                return true;
+            };
+            if (!e_res) {
+                constexpr int RS = HB <= 32 ? 64 : (HB <= 64 ? 128 : 256), CH = RS / 16, TR = 4096 / (16 * RS);
+                static_assert(TM % TR == 0 && (TR * 16 * CPR) % 64 == 0, "staging rounds");
+#pragma unroll
+                for (int t0 = 0; t0 < TM; t0 += TR) {
+#pragma unroll
+                    for (int tt = 0; tt < TR; ++tt)
+#pragma unroll
+                        for (int u = 0; u < TN; ++u) {
+                            floatx4 v = acc[t0 + tt][u];
+                            if (e_act && !(ablate & 1)) { v[0] = silu_f(v[0]); v[1] = silu_f(v[1]); v[2] = silu_f(v[2]); v[3] = silu_f(v[3]); }
+                            const int pl = tt * 16 + r, c = u * 2 + (q >> 1);
+                            *(half4 *)(stg + pl * RS + ((c ^ (pl & (CH - 1))) << 4) + (q & 1) * 8) = half4{(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
+                        }
+#pragma unroll
+                    for (int i = 0; i < TR * 16 * CPR / 64; ++i) {
+                        const int e = i * 64 + lane, pl = e / CPR, c = e - pl * CPR;
+                        const half8 v = *(const half8 *)(stg + pl * RS + ((c ^ (pl & (CH - 1))) << 4));
+                        int opix, rpix;
+                        const int n = cur.n0 + wn * HB + c * 8;
+                        if (pix_out(cur.m0 + (wm * TM + t0) * 16 + pl, opix, rpix) && n < e_cout && !(ablate & 2)) store16(e_out, opix + n, v, e_wt);
+                    }
+                }
+            } else if constexpr (HB <= 64) {
+                constexpr int RS = HB * 4, CH = RS / 16, TR = 4096 / (16 * RS), NI = TR * 16 * CPR / 64;
+                static_assert(TM % TR == 0 && (TR * 16 * CPR) % 64 == 0, "staging rounds");
+                // a round's shortcut values are requested one round AHEAD (they travel under the SiLU work, and their registers are not the ones a store
+                // still reads -- hipcc waits for a pending store before a load may overwrite its data registers); masked lanes read the tensor's first bytes
+                half8 rv[2][NI]; int op[2][NI]; bool ok[2][NI];
+                auto request = [&](int t0, half8 (&rvx)[NI], int (&opx)[NI], bool (&okx)[NI]) {
+#pragma unroll
+                    for (int i = 0; i < NI; ++i) {
+                        const int e = i * 64 + lane, pl = e / CPR, c = e - pl * CPR;
+                        int rpix = 0;
+                        const int n = cur.n0 + wn * HB + c * 8;
+                        okx[i] = pix_out(cur.m0 + (wm * TM + t0) * 16 + pl, opx[i], rpix) && n < e_cout;
+                        opx[i] += n;
+                        rvx[i] = *(const half8 *)(e_res + (okx[i] ? rpix + n : 0));
+                    }
+                };
+                request(0, rv[0], op[0], ok[0]);
+#pragma unroll
+                for (int t0 = 0; t0 < TM; t0 += TR) {
+                    const int cb = (t0 / TR) & 1;
+                    if (t0 + TR < TM) request(t0 + TR, rv[cb ^ 1], op[cb ^ 1], ok[cb ^ 1]);
+#pragma unroll
+                    for (int tt = 0; tt < TR; ++tt)
+#pragma unroll
+                        for (int u = 0; u < TN; ++u) {
+                            floatx4 v = acc[t0 + tt][u];
+                            if (e_act) { v[0] = silu_f(v[0]); v[1] = silu_f(v[1]); v[2] = silu_f(v[2]); v[3] = silu_f(v[3]); }
+                            const int pl = tt * 16 + r, c = u * 4 + q;
+                            *(floatx4 *)(stg + pl * RS + ((c ^ (pl & (CH - 1))) << 4)) = v;
+                        }
+#pragma unroll
+                    for (int i = 0; i < NI; ++i) {
+                        const int e = i * 64 + lane, pl = e / CPR, c = e - pl * CPR;
+                        const floatx4 lo = *(const floatx4 *)(stg + pl * RS + (((2 * c) ^ (pl & (CH - 1))) << 4));
+                        const floatx4 hi = *(const floatx4 *)(stg + pl * RS + (((2 * c + 1) ^ (pl & (CH - 1))) << 4));
+                        const half8 x = rv[cb][i];
+                        const half8 o = {(f16)(lo[0] + (float)x[0]), (f16)(lo[1] + (float)x[1]), (f16)(lo[2] + (float)x[2]), (f16)(lo[3] + (float)x[3]),
+                                         (f16)(hi[0] + (float)x[4]), (f16)(hi[1] + (float)x[5]), (f16)(hi[2] + (float)x[6]), (f16)(hi[3] + (float)x[7])};
+                        if (ok[cb][i]) store16(e_out, op[cb][i], o, e_wt);
+                    }
+                }
+            }
+        }
+        if (have_next) __builtin_amdgcn_s_barrier();     // every wave is done with its staging area: the next tile's strips may land there
+        if (tile_no == 0) STAMP(7);
+        ++tile_no;
+        if (!have_next) break;
+        cur = nxt;
+        id = nid;
+        nid = next_valid(id + G, nxt);
+        have_next = nid < total_ids;
+    }
+    STAMP(9);
+}
+
+// ---- host side ----
+template <int BN>
+static int launch_pp_bn(const ConvArgs *a, int n, hipStream_t s) {
+    using C = PpCfg<BN>;
+    ConvGroupArgs g;
+    g.n = n; g.start[0] = 0;
+    for (int i = 0; i < n; ++i) {
+        g.p[i] = a[i];
+        g.gx[i] = cdiv(a[i].M, C::BM);
+        g.start[i + 1] = (int)align_up((size_t)g.start[i] + (size_t)g.gx[i] * cdiv(a[i].cout, BN), 8);
+    }
+    for (int i = n; i < MAX_GROUP; ++i) { g.start[i + 1] = g.start[n]; g.gx[i] = 1; }
+    const int total = g.start[n];
+    static int cus = 0;                               // one persistent workgroup per CU (its LDS leaves no room for a second)
+    if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        RT_HIP(hipGetDevice(&dev));
+        RT_HIP(hipGetDeviceProperties(&prop, dev));
+        cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    int G = std::min(total, cus);
+    if (G >= 8) G &= ~7;                              // a workgroup's ids keep their residue mod 8: one XCD's share of the tile order
+    hipLaunchKernelGGL((conv3x3_pp<BN>), dim3(G), dim3(512), 0, s, g, total);
+    return RTMODT_OK;
+}
+
+int launch_conv3x3_pp(const ConvArgs *a, int n, int bn, hipStream_t s) {
+    for (int i = 0; i < n; ++i) {
+        RT_CHECK(a[i].ks == 3 && a[i].stride == 1 && a[i].cin % 64 == 0 && a[i].kp % 64 == 0 && !a[i].in2 && !a[i].out2 && !a[i].t_wt, RTMODT_E_INVALID,
+                 "launch_conv: the ping-pong tile runs 3x3 stride-1 convs with cin %% 64 == 0, no second destination, no tail");
+        // 16-byte stores (and residual loads): channel offsets and pixel strides in multiples of 8 halves
+        RT_CHECK(a[i].cout % 8 == 0 && (uintptr_t)a[i].out % 16 == 0 && a[i].out_cs % 8 == 0 && (!a[i].res || ((uintptr_t)a[i].res % 16 == 0 && a[i].res_cs % 8 == 0)),
+                 RTMODT_E_INVALID, "launch_conv: the ping-pong tile stores 16 bytes per lane (cout, channel offsets and strides %% 8 == 0)");
+        RT_CHECK(!a[i].res || bn <= 128, RTMODT_E_INVALID, "launch_conv: the 192-wide ping-pong tile takes no residual");
+    }
+    switch (bn) {
+        case 128: return launch_pp_bn<128>(a, n, s);
+        case 64: return launch_pp_bn<64>(a, n, s);
+        case 192: return launch_pp_bn<192>(a, n, s);
+        default: return fail(RTMODT_E_INVALID, "launch_conv: ping-pong tile with BN %d", bn);
+    }
+}
+
+}  // namespace rtmodt

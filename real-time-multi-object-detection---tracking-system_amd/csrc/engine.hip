@@ -996,6 +996,7 @@ static bool tail_tile_legal(const ConvLaunch &c, int t) {
 // their LDS fits 160 KiB together -- which is what lets the stages of the staged engine overlap
 static int tile_lds_kib(int t) {
     const TileShape ts = tile_shape(t);
+    if (tile_is_pp(t)) return 2 * (ts.bm / 8 + 1) + 3 * (ts.bn / 8);      // two strip slots + three per-tap weight slots (conv_pp.hip)
     if (tile_is_rows(t)) { const int rp = tile_needs_cin64(t) ? 8 : 16; return 2 * (ts.bm / rp + 1 + 3 * (ts.bn / rp)); }
     if (t >= TILE_WSK_64x64 && t <= TILE_WSK_64x32) return std::max(8 * (ts.bm / 16 + ts.bn / 16), 4 * (ts.bm / 16) * (ts.bn / 16));
     if (tile_is_ws(t)) return 150;                         // persistent, (nearly) the whole LDS

@@ -68,13 +68,17 @@ enum ConvTile {
     // 64-deep tile kernel with a SOFTWARE-PIPELINED k-loop (two fragment sets, the barrier between the two MFMA blocks of a step, DMA pieces issued between MFMAs):
     // 4 waves x 64x64 outputs, two workgroups per CU; 8 waves on 256x128 with three stages, one workgroup per CU
     TILE_K64_PF_128x128_S2 = 55, TILE_K64_PF_256x128_S3_W8 = 56,
-    TILE_COUNT = 57
+    // 3x3 / stride-1 PING-PONG kernel (conv_pp.hip): one persistent 8-wave workgroup per CU, its two halves one barrier interval apart
+    // (one reads + issues DMA while the other multiplies), tap reuse, 256 positions x BN couts
+    TILE_PP_256x128 = 57, TILE_PP_256x64 = 58, TILE_PP_256x192 = 59,
+    TILE_COUNT = 60
 };
 const char *tile_name(int tile);
 bool tile_needs_cin64(int tile);
 bool tile_is_rows(int tile);      // 3x3 stride-1 only, bordered input
 bool tile_is_pf(int tile);        // software-pipelined 64-deep tile kernel (single problems)
 bool tile_is_rows_pt(int tile);   // ... its persistent form (groups allowed)
+bool tile_is_pp(int tile);        // ping-pong 3x3 / stride-1 kernel (conv_pp.hip): cin % 64 == 0, groups allowed
 bool tile_is_tail(int tile);      // runs ConvLaunch::tail_* as well; needs cout == the tile's BN
 bool tile_reads_lo(int tile);     // can serve ConvLaunch::in_lo
 bool tile_is_w8(int tile);        // 8-wave 64-deep tile kernel (conv_mfma64_w8): one conv per launch

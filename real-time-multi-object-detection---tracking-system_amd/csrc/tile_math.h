@@ -108,4 +108,20 @@ inline void bitonic_run(K *keys, int P) {
     }
 }
 
+// ---- conv3x3_pp (conv_pp.hip) ----
+// The ping-pong kernel's DMA stream, per wave: what a wave issues in phase kw (= tap kw) of super-step s, in issue order, and when each piece is
+// first read.  lb = weight pieces per wave and tap; wave 0 carries the 33rd strip piece.
+//   kw 0:  B(s, kw 2) x lb            A(s+1) x 2 (+1 for wave 0)
+//   kw 1:  B(s+1, kw 0) x lb          A(s+1) x 2
+//   kw 2:  B(s+1, kw 1) x lb
+// vmcnt retires in issue order, so "everything phase kw + 1 reads has landed" == "at most N pieces are outstanding", N = the pieces issued after the
+// youngest piece phase kw + 1 reads:
+//   kw 0 -> B(s, kw 1), issued in kw 2 of s - 1: this phase's pieces are younger               N = lb + 2 (+1)
+//   kw 1 -> B(s, kw 2), the first lb of kw 0: kw 0's strip pieces and this phase's are younger   N = 2 (+1) + lb + 2
+//   kw 2 -> A(s+1) and B(s+1, kw 0): only this phase's weight pieces are younger                 N = lb
+// (tests/native/tile_math_check.cpp replays the stream and checks the three counts: never too loose, never tighter than needed)
+struct PpIssue { int nB, nA; };
+RT_HD PpIssue pp_issue(int kw, int lb, bool wave0) { return kw == 0 ? PpIssue{lb, 2 + (wave0 ? 1 : 0)} : (kw == 1 ? PpIssue{lb, 2} : PpIssue{lb, 0}); }
+constexpr int pp_wait_count(int kw, int lb, bool wave0) { return kw == 0 ? lb + 2 + (wave0 ? 1 : 0) : (kw == 1 ? 2 + (wave0 ? 1 : 0) + lb + 2 : lb); }
+
 }  // namespace rtmodt

@@ -138,4 +138,54 @@ static int check_nms_math() {
     return 0;
 }
 
-int main() { return check_fastdiv() || check_xcd_tile() || check_pt_run() || check_swizzle() || check_nms_math(); }
+// conv3x3_pp's DMA stream replayed per wave: after the counted wait at the end of R(kw) every piece the NEXT phase reads has retired (vmcnt retires
+// in issue order: "at most N outstanding" == "all but the N youngest done"), and the wait is exact (the youngest piece it covers IS one the next
+// phase reads -- a smaller count would stall on pieces nobody needs yet).  Also the fragment reads of the three taps (rows r + kw of the rotated
+// 128-byte-row image) are bank-conflict free under ds_read_b128's lane groups.
+static int check_pp_schedule() {
+    long cases = 0;
+    for (int lb = 1; lb <= 4; ++lb)
+        for (int w0 = 0; w0 < 2; ++w0) {
+            std::vector<int> need;                       // need[i] = global phase index (3 s + kw) that first reads piece i; issue order
+            const int S = 6;
+            // fill: strip 0 (first part), tap 0, strip 0 (rest), tap 1 -- then the fill's wait (all but tap 1)
+            for (int i = 0; i < 2 + w0; ++i) need.push_back(0);
+            for (int i = 0; i < lb; ++i) need.push_back(0);
+            for (int i = 0; i < 2; ++i) need.push_back(0);
+            for (int i = 0; i < lb; ++i) need.push_back(1);
+            auto check_wait = [&](int n_out, int next_phase, const char *where) -> int {
+                const int done = (int)need.size() - n_out;                      // pieces [0, done) have retired
+                for (int i = done; i < (int)need.size(); ++i)
+                    if (need[i] <= next_phase) { printf("pp schedule: lb %d wave0 %d %s: piece %d (first read in phase %d) may still be in flight before phase %d\n", lb, w0, where, i, need[i], next_phase); return 1; }
+                if (done > 0 && need[done - 1] > next_phase) { printf("pp schedule: lb %d wave0 %d %s: waits for piece %d, first read only in phase %d (next phase %d)\n", lb, w0, where, done - 1, need[done - 1], next_phase); return 1; }
+                return 0;
+            };
+            if (check_wait(lb, 0, "fill")) return 1;
+            for (int s = 0; s < S; ++s)
+                for (int kw = 0; kw < 3; ++kw) {
+                    const PpIssue is = pp_issue(kw, lb, w0 != 0);
+                    const int nb_need = kw == 0 ? 3 * s + 2 : (kw == 1 ? 3 * (s + 1) : 3 * (s + 1) + 1);
+                    for (int i = 0; i < is.nB; ++i) need.push_back(nb_need);
+                    for (int i = 0; i < is.nA; ++i) need.push_back(3 * (s + 1));
+                    if (check_wait(pp_wait_count(kw, lb, w0 != 0), 3 * s + kw + 1, kw == 0 ? "kw 0" : (kw == 1 ? "kw 1" : "kw 2"))) return 1;
+                    ++cases;
+                }
+        }
+    // bank conflicts of the fragment reads: ds_read_b128 serves 4 groups of 16 lanes, bank row = 256 B = 16 slots of 16 B
+    const int grp[2][16] = {{0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27}, {4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31}};
+    for (int kw = 0; kw < 3; ++kw)
+        for (int kk = 0; kk < 2; ++kk)
+            for (int hi = 0; hi < 2; ++hi)
+                for (int gi = 0; gi < 2; ++gi) {
+                    int used[16] = {};
+                    for (int li = 0; li < 16; ++li) {
+                        const int lane = grp[gi][li] + 32 * hi, r = lane & 15, q = lane >> 4, R = r + kw;
+                        const int addr = R * 128 + (swz_slot<128>(R, kk * 4 + q) << 4);
+                        if (used[(addr >> 4) & 15]++) { printf("pp swizzle: tap %d k-half %d: bank conflict in lane group %d\n", kw, kk, gi + 2 * hi); return 1; }
+                    }
+                }
+    printf("ok pp schedule %ld phases replayed, fragment reads conflict-free\n", cases);
+    return 0;
+}
+
+int main() { return check_fastdiv() || check_xcd_tile() || check_pt_run() || check_swizzle() || check_nms_math() || check_pp_schedule(); }

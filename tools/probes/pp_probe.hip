@@ -1,0 +1,240 @@
+// pp_probe.hip -- development harness of the ping-pong 3x3 kernel (csrc/conv_pp.hip): the benchmarked 3x3 / stride-1 shapes of YOLOv8s at 32
+// frames on synthetic tensors, every candidate tile against a reference tile of conv.hip (values) and against each other (time).
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -o tools/probes/bin/pp_probe tools/probes/pp_probe.hip            (timing + values)
+//   hipcc ... -DRTMODT_STAMP -o tools/probes/bin/pp_probe_stamp tools/probes/pp_probe.hip                        (phase stamps; read shares, not times)
+// Usage: pp_probe [shape-filter]      -- prints one line per (shape, tile)
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../real-time-multi-object-detection---tracking-system_amd/csrc/conv.hip"
+#include "../../real-time-multi-object-detection---tracking-system_amd/csrc/conv_pp.hip"
+
+namespace rtmodt {
+#ifdef RTMODT_STAMP
+__device__ unsigned long long *g_stamps;
+#endif
+std::string &last_error() { static std::string e; return e; }
+int fail(int code, const char *fmt, ...) { va_list ap; va_start(ap, fmt); vfprintf(stderr, fmt, ap); va_end(ap); fputc('\n', stderr); return code; }
+}
+using namespace rtmodt;
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s -> %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+
+static unsigned rng_state = 12345;
+static float frand() { rng_state = rng_state * 1664525u + 1013904223u; return ((rng_state >> 8) & 0xFFFF) / 65536.f - 0.5f; }
+
+struct Problem {
+    int cin, cout, HW, B; bool res;
+    f16 *in = nullptr, *out = nullptr, *resbuf = nullptr, *w = nullptr; float *bias = nullptr;
+    size_t out_elems = 0;
+    ConvLaunch c;
+};
+
+static void make_problem(Problem &P) {
+    const int Hp = P.HW + 2;
+    const size_t per = (size_t)Hp * Hp;
+    std::vector<f16> h(per * P.B * P.cin, (f16)0.f);
+    for (int b = 0; b < P.B; ++b)
+        for (int y = 1; y <= P.HW; ++y)
+            for (int x = 1; x <= P.HW; ++x) {
+                f16 *px = &h[((size_t)(b * Hp + y) * Hp + x) * P.cin];
+                for (int c = 0; c < P.cin; ++c) px[c] = (f16)(2.f * frand());
+            }
+    CK(hipMalloc(&P.in, h.size() * 2)); CK(hipMemcpy(P.in, h.data(), h.size() * 2, hipMemcpyHostToDevice));
+    P.out_elems = per * P.B * P.cout;
+    CK(hipMalloc(&P.out, P.out_elems * 2)); CK(hipMemset(P.out, 0, P.out_elems * 2));
+    if (P.res) {
+        std::vector<f16> hr(P.out_elems);
+        for (auto &v : hr) v = (f16)frand();
+        CK(hipMalloc(&P.resbuf, hr.size() * 2)); CK(hipMemcpy(P.resbuf, hr.data(), hr.size() * 2, hipMemcpyHostToDevice));
+    }
+    const int cp = (P.cout + 127) / 128 * 128, K = 9 * P.cin;
+    std::vector<f16> hw((size_t)cp * K, (f16)0.f);
+    const float sc = 2.0f / std::sqrt((float)K);
+    for (int n = 0; n < P.cout; ++n)
+        for (int k = 0; k < K; ++k) hw[(size_t)n * K + k] = (f16)(sc * frand());
+    CK(hipMalloc(&P.w, hw.size() * 2)); CK(hipMemcpy(P.w, hw.data(), hw.size() * 2, hipMemcpyHostToDevice));
+    std::vector<float> hb(cp, 0.f);
+    for (int n = 0; n < P.cout; ++n) hb[n] = 0.5f * frand();
+    CK(hipMalloc(&P.bias, hb.size() * 4)); CK(hipMemcpy(P.bias, hb.data(), hb.size() * 4, hipMemcpyHostToDevice));
+    auto view = [&](f16 *base, int Ct) { TensorView v; v.base = base; v.H = v.W = P.HW; v.C = Ct; v.pad = 1; v.coff = 0; v.c = Ct; return v; };
+    ConvLaunch &c = P.c;
+    c.in = view(P.in, P.cin); c.out = view(P.out, P.cout);
+    if (P.res) c.res = view(P.resbuf, P.cout);
+    c.wt = P.w; c.bias = P.bias; c.B = P.B; c.cin = P.cin; c.cout = P.cout; c.ks = 3; c.stride = 1; c.act = 1; c.kp = K;
+}
+static void free_problem(Problem &P) {
+    hipFree(P.in); hipFree(P.out); hipFree(P.w); hipFree(P.bias); if (P.resbuf) hipFree(P.resbuf);
+}
+
+static std::vector<f16> fetch(const Problem &P) {
+    std::vector<f16> h(P.out_elems);
+    CK(hipMemcpy(h.data(), P.out, h.size() * 2, hipMemcpyDeviceToHost));
+    return h;
+}
+
+// run `n` problems as one (grouped) launch of tile `tile`; returns us per launch, -1 when the tile refuses
+static float time_group(std::vector<Problem> &ps, int tile, int iters) {
+    std::vector<ConvLaunch> cl;
+    for (auto &p : ps) { p.c.tile = tile; cl.push_back(p.c); }
+    for (auto &p : ps) CK(hipMemset(p.out, 0, p.out_elems * 2));
+    if (launch_conv_group(cl.data(), (int)cl.size(), tile, nullptr) != 0) { printf("   (tile %s refused: %s)\n", tile_name(tile), last_error().c_str()); return -1.f; }
+    CK(hipDeviceSynchronize());
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int i = 0; i < 3; ++i) launch_conv_group(cl.data(), (int)cl.size(), tile, nullptr);
+    CK(hipEventRecord(e0, nullptr));
+    for (int i = 0; i < iters; ++i) launch_conv_group(cl.data(), (int)cl.size(), tile, nullptr);
+    CK(hipEventRecord(e1, nullptr)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    CK(hipEventDestroy(e0)); CK(hipEventDestroy(e1));
+    return ms * 1e3f / iters;
+}
+
+struct Cmp { double max_abs = 0, max_ref = 0; size_t bad = 0, n = 0; };
+static Cmp compare(const std::vector<f16> &a, const std::vector<f16> &ref) {
+    Cmp c;
+    for (size_t i = 0; i < ref.size(); ++i) c.max_ref = std::max(c.max_ref, (double)std::fabs((float)ref[i]));
+    const double tol = 2e-3 * c.max_ref + 2e-3;
+    for (size_t i = 0; i < ref.size(); ++i) {
+        const double d = std::fabs((double)(float)a[i] - (double)(float)ref[i]);
+        if (!(d <= tol)) ++c.bad;                     // (NaN counts as bad)
+        if (d > c.max_abs) c.max_abs = d;
+        ++c.n;
+    }
+    return c;
+}
+
+#if defined(RTMODT_STAMP) && defined(PP_FINE)
+static void print_stamps(int wgs) {
+    unsigned long long *d_st;
+    CK(hipMemcpyFromSymbol(&d_st, HIP_SYMBOL(g_stamps), sizeof(d_st)));
+    std::vector<unsigned long long> st((size_t)wgs * 16);
+    CK(hipMemcpy(st.data(), d_st, st.size() * 8, hipMemcpyDeviceToHost));
+    const char *pn[] = {"R: DMA pieces issued", "R: fragments read (issue -> all returned)", "R: counted vmcnt wait", "R: lgkmcnt + barrier", "M: 32 MFMAs issued", "M: barrier"};
+    for (int h = 0; h < 2; ++h)
+        for (int k = 0; k < 6; ++k) {
+            std::vector<double> d;
+            for (int g = 0; g < wgs; ++g) { const unsigned long long *s = &st[(size_t)g * 16 + h * 8]; if (s[k] && s[k + 1]) d.push_back((double)(s[k + 1] - s[k])); }
+            if (d.empty()) continue;
+            std::sort(d.begin(), d.end());
+            printf("      half %d  %-44s median %6.0f clk   (p10 %6.0f, p90 %6.0f)\n", h, pn[k], d[d.size() / 2], d[d.size() / 10], d[d.size() * 9 / 10]);
+        }
+    std::vector<double> d;      // half 1's R start against half 0's M start: the stagger
+    for (int g = 0; g < wgs; ++g) { const unsigned long long *s = &st[(size_t)g * 16]; if (s[4] && s[8]) d.push_back((double)s[8] - (double)s[4]); }
+    if (!d.empty()) { std::sort(d.begin(), d.end()); printf("      half 1 R start - half 0 M start: median %6.0f clk\n", d[d.size() / 2]); }
+}
+#elif defined(RTMODT_STAMP)
+static void print_stamps(int wgs) {
+    unsigned long long *d_st;
+    CK(hipMemcpyFromSymbol(&d_st, HIP_SYMBOL(g_stamps), sizeof(d_st)));
+    std::vector<unsigned long long> st((size_t)wgs * 16);
+    CK(hipMemcpy(st.data(), d_st, st.size() * 8, hipMemcpyDeviceToHost));
+    const int pa[][2] = {{0, 1}, {2, 3}, {3, 4}, {1, 6}, {6, 7}, {0, 9}};
+    const char *pn[] = {"fill: DMA issue -> first stage landed", "super-step 1: phase kw 1 (both halves)", "super-step 1: phase kw 2", "k-loop of the first tile", "epilogue of the first tile", "workgroup life"};
+    for (int k = 0; k < 6; ++k) {
+        std::vector<double> d;
+        for (int g = 0; g < wgs; ++g) { const unsigned long long *s = &st[(size_t)g * 16]; if (s[pa[k][0]] && s[pa[k][1]]) d.push_back((double)(s[pa[k][1]] - s[pa[k][0]])); }
+        if (d.empty()) continue;
+        std::sort(d.begin(), d.end());
+        printf("      %-44s median %8.0f clk   (p10 %8.0f, p90 %8.0f; %zu workgroups)\n", pn[k], d[d.size() / 2], d[d.size() / 10], d[d.size() * 9 / 10], d.size());
+    }
+    std::vector<double> ghz;
+    for (int g = 0; g < wgs; ++g) { const unsigned long long *s = &st[(size_t)g * 16]; if (s[15] > s[13] && s[14] > s[12]) ghz.push_back((double)(s[14] - s[12]) / (double)(s[15] - s[13]) * 0.1); }
+    if (!ghz.empty()) { std::sort(ghz.begin(), ghz.end()); printf("      in-kernel shader clock: median %.3f GHz\n", ghz[ghz.size() / 2]); }
+}
+#endif
+
+int main(int argc, char **argv) {
+    const char *filter = argc > 1 ? argv[1] : "";
+    const int iters = argc > 2 ? atoi(argv[2]) : 20;
+#ifdef RTMODT_STAMP
+    unsigned long long *d_st;
+    CK(hipMalloc(&d_st, (size_t)4096 * 16 * 8));
+    CK(hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), &d_st, sizeof(d_st)));
+#endif
+    struct Shape { const char *name; int cin, cout, HW, B; bool res; };
+    const Shape shapes[] = {
+        {"6.m.0.cv1  128->128 @40", 128, 128, 40, 32, false},
+        {"6.m.0.cv2  128->128 @40 +res", 128, 128, 40, 32, true},
+        {"4.m.0.cv1  64->64 @80", 64, 64, 80, 32, false},
+        {"8.m.0.cv1  256->256 @20", 256, 256, 20, 32, false},
+        {"22.s0 P3   128->192 @80", 128, 192, 80, 32, false},
+        {"22.s0 P4   256->192 @40", 256, 192, 40, 32, false},
+        {"22.s0 P5   512->192 @20", 512, 192, 20, 32, false},
+        {"22.s1 P3   128->128 @80", 128, 128, 80, 32, false},
+        {"22.s1 P3b  64->64 @80", 64, 64, 80, 32, false},
+        {"small      64->128 @12 B=3", 64, 128, 12, 3, true},
+    };
+    const int tiles[] = {TILE_ROWS_K64_256x64_W8, TILE_ROWS_256x64_W8, TILE_ROWS_K64_128x128_W8, TILE_PT_128x128_S2, TILE_PT_128x64_S2, TILE_K64_128x128_S2_W8, TILE_PP_256x128, TILE_PP_256x64, TILE_PP_256x192};
+    for (const Shape &sh : shapes) {
+        if (*filter && !strstr(sh.name, filter)) continue;
+        std::vector<Problem> ps(1);
+        ps[0].cin = sh.cin; ps[0].cout = sh.cout; ps[0].HW = sh.HW; ps[0].B = sh.B; ps[0].res = sh.res;
+        make_problem(ps[0]);
+        const double gflop = 2.0 * sh.B * sh.HW * sh.HW * (double)sh.cout * 9 * sh.cin * 1e-9;
+        printf("%s  (B %d, %.2f GFLOP)\n", sh.name, sh.B, gflop);
+        std::vector<f16> ref;
+        for (int t : tiles) {
+            if (tile_is_pt(t) && (((long)sh.B * sh.HW * sh.HW) % tile_shape(t).bm != 0 || sh.cout % tile_shape(t).bn != 0)) continue;
+            if (t == TILE_PP_256x192 && (sh.cout % 192 != 0 || sh.res)) continue;
+#ifdef RTMODT_STAMP
+            if (!tile_is_pp(t)) continue;
+            CK(hipMemset(d_st, 0, (size_t)4096 * 16 * 8));
+#endif
+            const float us = time_group(ps, t, iters);
+            if (us < 0) continue;
+            std::vector<f16> got = fetch(ps[0]);
+            if (ref.empty()) ref = got;
+            const Cmp c = compare(got, ref);
+            printf("   %-20s %8.2f us  %7.1f TFLOP/s   max|d| %.4g (max|ref| %.3g)  outside tol: %zu of %zu%s\n", tile_name(t), us, gflop / us, c.max_abs, c.max_ref, c.bad, c.n,
+                   c.bad ? "   <-- MISMATCH" : "");
+#ifdef RTMODT_STAMP
+            print_stamps(256);
+#endif
+        }
+        free_problem(ps[0]);
+    }
+    // ---- grouped launches: Detect stage 0 (3 levels) and stage 1 (6 convs) ----
+    if (!*filter || strstr("group", filter)) {
+        struct G { const char *name; std::vector<Shape> s; };
+        const G groups[] = {
+            {"22.stage0 (3 levels, cout 192)", {{"", 128, 192, 80, 32, false}, {"", 256, 192, 40, 32, false}, {"", 512, 192, 20, 32, false}}},
+            {"22.stage1 cv3 (3 levels, 128->128)", {{"", 128, 128, 80, 32, false}, {"", 128, 128, 40, 32, false}, {"", 128, 128, 20, 32, false}}},
+            {"22.stage1 cv2 (3 levels, 64->64)", {{"", 64, 64, 80, 32, false}, {"", 64, 64, 40, 32, false}, {"", 64, 64, 20, 32, false}}},
+        };
+        const int gtiles[] = {TILE_ROWS_PT_256x64, TILE_ROWS_256x64_W8, TILE_ROWS_K64_256x64_W8, TILE_PP_256x128, TILE_PP_256x64, TILE_PP_256x192};
+        for (const G &gr : groups) {
+            std::vector<Problem> ps(gr.s.size());
+            double gflop = 0;
+            for (size_t i = 0; i < ps.size(); ++i) {
+                const Shape &sh = gr.s[i];
+                ps[i].cin = sh.cin; ps[i].cout = sh.cout; ps[i].HW = sh.HW; ps[i].B = sh.B; ps[i].res = sh.res;
+                make_problem(ps[i]);
+                gflop += 2.0 * sh.B * sh.HW * sh.HW * (double)sh.cout * 9 * sh.cin * 1e-9;
+            }
+            printf("%s  (%.2f GFLOP)\n", gr.name, gflop);
+            std::vector<std::vector<f16>> ref;
+            for (int t : gtiles) {
+#ifdef RTMODT_STAMP
+                if (!tile_is_pp(t)) continue;
+#endif
+                const float us = time_group(ps, t, iters);
+                if (us < 0) continue;
+                size_t bad = 0; double md = 0;
+                for (size_t i = 0; i < ps.size(); ++i) {
+                    std::vector<f16> got = fetch(ps[i]);
+                    if (ref.size() <= i) ref.push_back(got);
+                    const Cmp c = compare(got, ref[i]);
+                    bad += c.bad; md = std::max(md, c.max_abs);
+                }
+                printf("   %-20s %8.2f us  %7.1f TFLOP/s   max|d| %.4g  outside tol: %zu%s\n", tile_name(t), us, gflop / us, md, bad, bad ? "   <-- MISMATCH" : "");
+            }
+            for (auto &p : ps) free_problem(p);
+        }
+    }
+    return 0;
+}
