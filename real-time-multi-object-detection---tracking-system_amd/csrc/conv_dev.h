@@ -367,5 +367,7 @@ __device__ __forceinline__ int group_pick(const ConvGroupArgs &g, int &bx, int &
 
 // conv_pp.hip: n 3x3 / stride-1 problems (ConvArgs prepared for the tap-reuse enumeration) as one ping-pong launch with cout tile bn
 int launch_conv3x3_pp(const ConvArgs *a, int n, int bn, hipStream_t s);
+// ... one conv of any kernel size / stride without tap reuse (1x1, 3x3 stride 2) on the ping-pong tile kernel
+int launch_conv_tile_pp(const ConvArgs &a, int bn, hipStream_t s);
 
 }  // namespace rtmodt

@@ -29,6 +29,11 @@
 //  * vmcnt retires in issue order, so inside a phase the weight pieces (needed one tap later, L2-hot) are issued BEFORE the strip pieces (needed a
 //         whole super-step later, from the Infinity Cache / HBM).  Issue lists per phase and the resulting counts: tile_math.h (pp_issue, pp_wait_count),
 //         checked by a host-side replay of the stream (tests/test_tile_math_cpu.py).
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
 #include "conv_dev.h"
 
 namespace rtmodt {
@@ -74,7 +79,7 @@ template <int N>
 __device__ __forceinline__ void pp_wait() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 template <int BN>
-__global__ __launch_bounds__(512) void conv3x3_pp(ConvGroupArgs g, int total_ids) {
+__global__ __launch_bounds__(512) void conv3x3_pp(ConvGroupArgs g, int total_ids, const int *sched, int sched_T) {
     using C = PpCfg<BN>;
     constexpr int BM = C::BM, NW = C::NW, LB = C::LB, TM = C::TM, TN = C::TN;
     constexpr bool BIAS_AHEAD = BN <= 128;
@@ -107,7 +112,8 @@ __global__ __launch_bounds__(512) void conv3x3_pp(ConvGroupArgs g, int total_ids
         const char *in, *wt;                          // of the tile's problem (wave-uniform)
         int z, m0, n0, ns, cin;
         unsigned row_bytes;                           // bytes between two padded input rows (the kh step)
-        unsigned a_off[5], b_off[LB];                 // per lane, bytes: its row of strip piece wave + 8 i (i = 4: piece 32, wave 0 only); its weight row
+        unsigned a_off[5], b_off;                     // per lane, bytes: its row of strip piece wave + 8 i (i = 4: piece 32, wave 0 only); its row of weight piece `wave`
+        unsigned b_step;                              // (wave-uniform) bytes from weight piece j to j + 8: 64 cout rows
     };
     const int G = gridDim.x;
     auto locate = [&](int id, Tile &t) -> bool {      // launch-linear id -> (problem, tile); false for the alignment fillers between problems
@@ -127,14 +133,24 @@ __global__ __launch_bounds__(512) void conv3x3_pp(ConvGroupArgs g, int total_ids
         const int clamp = p.last_pos - 2 * p.in_Wp;
 #pragma unroll
         for (int i = 0; i < 5; ++i) t.a_off[i] = (unsigned)(min(rows_pos(p, t.m0 + (wave + NW * i) * 8 + ld_row), clamp) * p.in_cs + ld_chunk) * 2u;
-#pragma unroll
-        for (int j = 0; j < LB; ++j) t.b_off[j] = (unsigned)((t.n0 + (wave + NW * j) * 8 + ld_row) * p.kp + ld_chunk) * 2u;
+        t.b_off = (unsigned)((t.n0 + wave * 8 + ld_row) * p.kp + ld_chunk) * 2u;
+        t.b_step = (unsigned)(64 * p.kp) * 2u;
         return true;
     };
-    auto next_valid = [&](int id, Tile &t) -> int {
-        for (; id < total_ids; id += G)
-            if (locate(id, t)) return id;
-        return total_ids;
+    // the j-th tile of this workgroup: from the launch's schedule (pp_lpt_schedule, read through the SCALAR cache: a vector load would sit in the vmcnt
+    // queue of the DMA stream), or -- no schedule -- the ids blockIdx.x, + G, ... with the alignment fillers between problems skipped.  false: no more.
+    int walk = blockIdx.x;                            // static walk: the next id to try
+    auto next_tile = [&](int j, Tile &t) -> bool {
+        if (sched) {
+            if (j >= sched_T) return false;
+            int id;
+            const int off = (blockIdx.x * sched_T + j) * 4;
+            asm volatile("s_load_dword %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=s"(id) : "s"(sched), "s"(off) : "memory");
+            return id >= 0 && locate(id, t);
+        }
+        for (; walk < total_ids; walk += G)
+            if (locate(walk, t)) { walk += G; return true; }
+        return false;
     };
     auto dma = [&](const char *base, unsigned off, unsigned char *dst) {
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(base + off), (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
@@ -143,7 +159,7 @@ __global__ __launch_bounds__(512) void conv3x3_pp(ConvGroupArgs g, int total_ids
     auto issue_B = [&](const Tile &t, int kh, int kw, int c0, int slot) {
         const char *base = t.wt + (size_t)(((kh * 3 + kw) * t.cin + c0) * 2);
 #pragma unroll
-        for (int j = 0; j < LB; ++j) dma(base, t.b_off[j], lds + C::B_OFF + slot * C::BSLOT + (wave + NW * j) * 1024);
+        for (int j = 0; j < LB; ++j) dma(base + (size_t)j * t.b_step, t.b_off, lds + C::B_OFF + slot * C::BSLOT + (wave + NW * j) * 1024);
     };
     // strip piece wave + 8 i of (kh, c0) -> strip slot `slot`
     auto issue_A = [&](const Tile &t, int kh, int c0, int slot, int i) {
@@ -152,10 +168,9 @@ __global__ __launch_bounds__(512) void conv3x3_pp(ConvGroupArgs g, int total_ids
     };
 
     Tile cur, nxt, iss;                               // the tile being multiplied, the one after it, the one the DMA stream is feeding
-    int id = next_valid(blockIdx.x, cur);
-    if (id >= total_ids) return;                      // (the same for every wave of the workgroup)
-    int nid = next_valid(id + G, nxt);
-    bool have_next = nid < total_ids;
+    int tj = 0;
+    if (!next_tile(tj++, cur)) return;                // (the same for every wave of the workgroup)
+    bool have_next = next_tile(tj++, nxt);
     iss = cur;
 
     // bias of the first tile: requested BEFORE the first DMA piece (older than all of them)
@@ -366,11 +381,214 @@ __global__ __launch_bounds__(512) void conv3x3_pp(ConvGroupArgs g, int total_ids
         ++tile_no;
         if (!have_next) break;
         cur = nxt;
-        id = nid;
-        nid = next_valid(id + G, nxt);
-        have_next = nid < total_ids;
+        have_next = next_tile(tj++, nxt);
     }
     STAMP(9);
+}
+
+
+// ---------------------------------------------------------------------------------------
+// conv_tile_pp: the same two-halves-in-anti-phase schedule for the convs WITHOUT tap reuse -- 1x1 (C2f.cv1 / cv2, SPPF, incl. the neck layers that
+// read their upsampled channels from the half-resolution tensor) and 3x3 / stride 2 (layers 5, 7, 16, 19): 256 pixels x BN couts per tile, one phase =
+// one 64-deep k-step (kh, kw, 64 channels): 32 pixel pieces + BN / 8 weight pieces by LDS-DMA, 4 x TN x 2 MFMA tiles per wave.  Three-slot rings for
+// both operands, the stream two phases ahead of the multiplication: phase j issues phase j + 2 into the slots phase j - 1 has just left and waits for
+// ITS pieces of phase j + 1 (all but the ones just issued).  One problem per launch, persistent workgroups (tiles g, g + G, ...), the stream runs on
+// into the next tile.  These layers have 3 - 36 phases per tile, so a tile's fill and epilogue weigh as much as its k-loop: what the kernel buys there
+// is the cross-tile prefetch and the 16-byte line-wide stores of the shared epilogue.
+// ---------------------------------------------------------------------------------------
+template <int BN>
+struct PtileCfg {
+    static constexpr int BM = 256, NW = 8;
+    static constexpr int NAP = BM / 8, ASLOT = NAP * 1024;          // 32 pieces of 8 pixels x 128 B
+    static constexpr int NBP = BN / 8, BSLOT = NBP * 1024;
+    static constexpr int NS = 3;                                    // ring slots per operand
+    static constexpr int B_OFF = NS * ASLOT;
+    static constexpr int LDS_BYTES = B_OFF + NS * BSLOT;
+    static constexpr int LA = NAP / NW, LB = NBP / NW, L = LA + LB;
+    static constexpr int TM = 4, TN = BN / 32;
+    static_assert(NBP % NW == 0 && LDS_BYTES <= 160 * 1024, "tile");
+};
+
+template <int BN>
+__global__ __launch_bounds__(512) void conv_tile_pp(ConvArgs p, int n_tiles) {
+    using C = PtileCfg<BN>;
+    constexpr int BM = C::BM, NW = C::NW, LA = C::LA, LB = C::LB, L = C::L, TM = C::TM, TN = C::TN, NS = C::NS;
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[C::LDS_BYTES];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r = lane & 15, q = lane >> 4;
+    const int half = wave >> 2, wm = wave >> 1, wn = wave & 1;
+    auto slot_of = [](int R, int c) { return ((c + 2 * (R >> 1)) & 7) << 4; };
+    int a_rd[2], b_rd[2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+        a_rd[kk] = wm * 64 * 128 + r * 128 + slot_of(r, kk * 4 + q);
+        b_rd[kk] = C::B_OFF + wn * (BN / 2) * 128 + r * 128 + slot_of(r, kk * 4 + q);
+    }
+    const int ld_row = lane >> 3, ld_slot = lane & 7;
+    const int ld_chunk = ((ld_slot - 2 * (ld_row >> 1)) & 7) * 8;
+
+    const int gx = (p.M + BM - 1) / BM, gy = (p.cout + BN - 1) / BN;
+    const int nph = p.ks * p.ks * (p.cin / 64);      // phases per tile (>= 2: checked at launch)
+    const int G = gridDim.x;
+    // Per-lane DMA offsets of a tile (bytes): its pixel rows in `in` / in the half-resolution source, its weight rows.  Kept as plain arrays and copied
+    // element by element: a struct of them that is assigned under a branch, or passed by reference to a lambda that may see one of two, ends up in scratch
+    // memory and is reloaded -- with s_waitcnt vmcnt(0) -- in every phase.
+    unsigned ia_off[LA], ia_lo[LA], ib_off[LB];      // the tile the DMA stream is feeding
+    unsigned na_off[LA], na_lo[LA], nb_off[LB];      // the tile after the one being multiplied
+    int cur_m0, cur_n0, nxt_m0 = 0, nxt_n0 = 0;
+    auto locate = [&](int id, int &m0, int &n0, unsigned (&ao)[LA], unsigned (&al)[LA], unsigned (&bo)[LB]) __attribute__((always_inline)) {
+        const int by = id / gx, bx = id - by * gx;
+        int mt, nt;
+        xcd_tile(gx, gy, bx, by, mt, nt);
+        m0 = mt * BM; n0 = nt * BN;
+#pragma unroll
+        for (int i = 0; i < LA; ++i) {
+            const int m = m0 + (wave + NW * i) * 8 + ld_row;
+            ao[i] = (unsigned)(input_offset(p, m) + ld_chunk) * 2u;
+            al[i] = p.in2 ? (unsigned)(input_offset_lo(p, m) + ld_chunk) * 2u : 0u;
+        }
+#pragma unroll
+        for (int j = 0; j < LB; ++j) bo[j] = (unsigned)((n0 + (wave + NW * j) * 8 + ld_row) * p.kp + ld_chunk) * 2u;
+    };
+    auto dma = [&](const char *base, unsigned off, unsigned char *dst) __attribute__((always_inline)) {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(base + off), (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+    };
+    // the DMA stream's cursor: (tile, k-step) of the next phase to issue
+    struct Cursor { int kh, kw, c0, k; };
+    auto issue = [&](Cursor &c, int slot) __attribute__((always_inline)) {
+        const char *wb = (const char *)p.wt + (size_t)c.k * 128;
+#pragma unroll
+        for (int j = 0; j < LB; ++j) dma(wb, ib_off[j], lds + C::B_OFF + slot * C::BSLOT + (wave + NW * j) * 1024);
+        // the upsampled half of a neck concat is read where it was produced (per-element select: two arrays behind one branch would again be indexed in memory)
+        const bool lo = p.in2 && c.c0 < p.split;
+        const char *ab = lo ? (const char *)p.in2 + (size_t)c.c0 * 2 : (const char *)p.in + (size_t)(((c.kh * p.in_Wp + c.kw) * p.in_cs + c.c0) * 2);
+#pragma unroll
+        for (int i = 0; i < LA; ++i) dma(ab, lo ? ia_lo[i] : ia_off[i], lds + slot * C::ASLOT + (wave + NW * i) * 1024);
+        ++c.k; c.c0 += 64;
+        if (c.c0 >= p.cin) { c.c0 = 0; if (++c.kw == p.ks) { c.kw = 0; ++c.kh; } }
+    };
+
+    int tid = blockIdx.x;
+    if (tid >= n_tiles) return;
+    // The DMA stream feeds the tile being multiplied, or -- for its last two phases -- already the next one (a tile has >= 3 phases, so the stream
+    // never needs a tile that has not been located yet).
+    locate(tid, cur_m0, cur_n0, ia_off, ia_lo, ib_off);
+    bool have_next = tid + G < n_tiles;
+    if (have_next) locate(tid + G, nxt_m0, nxt_n0, na_off, na_lo, nb_off);
+    Cursor ic{0, 0, 0, 0};
+    bool iss_ahead = false, stream_open = true;
+    floatx4 bnext[TN];
+#pragma unroll
+    for (int u = 0; u < TN; ++u) bnext[u] = *(const floatx4 *)(p.bias + cur_n0 + (wn * TN + u) * 16 + q * 4);
+    int islot = 0;                                   // ring slot of the next phase to issue
+    auto issue_next = [&]() __attribute__((always_inline)) -> bool {      // issues one phase if the stream has one left
+        if (!stream_open) return false;
+        issue(ic, islot);
+        islot = islot + 1 == NS ? 0 : islot + 1;
+        if (ic.k == nph) {                           // that was the tile's last phase: on to the next tile, or the stream ends
+            if (!iss_ahead && have_next) {
+                ic = Cursor{0, 0, 0, 0}; iss_ahead = true;
+#pragma unroll
+                for (int i = 0; i < LA; ++i) { ia_off[i] = na_off[i]; ia_lo[i] = na_lo[i]; }
+#pragma unroll
+                for (int j = 0; j < LB; ++j) ib_off[j] = nb_off[j];
+            } else stream_open = false;
+        }
+        return true;
+    };
+    issue_next();
+    issue_next();
+    pp_wait<L>();                                    // phase 0 has landed, phase 1 may be in flight
+    __builtin_amdgcn_s_barrier();
+    int rslot = 0;
+    int tile_no = 0;
+
+    while (true) {
+        floatx4 acc[TM][TN];
+#pragma unroll
+        for (int t = 0; t < TM; ++t)
+#pragma unroll
+            for (int u = 0; u < TN; ++u) acc[t][u] = bnext[u];
+        if (half == 1) __builtin_amdgcn_s_barrier();  // STAGGER
+        for (int j = 0; j < nph; ++j) {
+            // ---------------- R ----------------
+            const bool issued = issue_next();
+            half8 fa[2][TM], fb[2][TN];
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+                for (int u = 0; u < TN; ++u) fb[kk][u] = *(const half8 *)(lds + rslot * C::BSLOT + u * 2048 + b_rd[kk]);
+#pragma unroll
+                for (int t = 0; t < TM; ++t) fa[kk][t] = *(const half8 *)(lds + rslot * C::ASLOT + t * 2048 + a_rd[kk]);
+            }
+            if (issued) pp_wait<L>(); else pp_wait<0>();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            // ---------------- M ----------------
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int t = 0; t < TM; ++t)
+#pragma unroll
+                    for (int u = 0; u < TN; ++u) acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[kk][u], fa[kk][t], acc[t][u], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            rslot = rslot + 1 == NS ? 0 : rslot + 1;
+        }
+        if (half == 0) __builtin_amdgcn_s_barrier();  // BALANCE
+        const int stg_slot = rslot == 0 ? NS - 1 : rslot - 1;      // the slot of the phase just multiplied: free until the next tile's first R refills it
+        if (have_next) {
+            int nn0 = nxt_n0;
+            asm volatile("" : "+v"(nn0));
+            nn0 = __builtin_amdgcn_readfirstlane(nn0);
+#pragma unroll
+            for (int u = 0; u < TN; ++u) bnext[u] = *(const floatx4 *)(p.bias + nn0 + (wn * TN + u) * 16 + q * 4);
+        }
+        {
+            unsigned char *stg = lds + stg_slot * C::ASLOT + wave * 4096;
+            constexpr int HB = BN / 2, CPR = HB / 8;
+            constexpr int RS = HB <= 32 ? 64 : (HB <= 64 ? 128 : 256), CH = RS / 16, TR = 4096 / (16 * RS);
+            static_assert(TM % TR == 0 && (TR * 16 * CPR) % 64 == 0, "staging rounds");
+            const int HoWo = p.Ho * p.Wo;
+#pragma unroll
+            for (int t0 = 0; t0 < TM; t0 += TR) {
+#pragma unroll
+                for (int tt = 0; tt < TR; ++tt)
+#pragma unroll
+                    for (int u = 0; u < TN; ++u) {
+                        floatx4 v = acc[t0 + tt][u];
+                        if (p.act) { v[0] = silu_f(v[0]); v[1] = silu_f(v[1]); v[2] = silu_f(v[2]); v[3] = silu_f(v[3]); }
+                        const int pl = tt * 16 + r, c = u * 2 + (q >> 1);
+                        *(half4 *)(stg + pl * RS + ((c ^ (pl & (CH - 1))) << 4) + (q & 1) * 8) = half4{(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
+                    }
+#pragma unroll
+                for (int i = 0; i < TR * 16 * CPR / 64; ++i) {
+                    const int e = i * 64 + lane, pl = e / CPR, c = e - pl * CPR;
+                    const half8 v = *(const half8 *)(stg + pl * RS + ((c ^ (pl & (CH - 1))) << 4));
+                    const int m = cur_m0 + (wm * TM + t0) * 16 + pl, n = cur_n0 + wn * HB + c * 8;
+                    if (m < p.M && n < p.cout) {
+                        const int b = fdiv(m, p.d_howo), rem = m - b * HoWo;
+                        const int oy = fdiv(rem, p.d_wo), ox = rem - oy * p.Wo;
+                        const int opix = ((b * p.out_Hp + oy + p.out_pad) * p.out_Wp + ox + p.out_pad) * p.out_cs;
+                        store16(p.out, opix + n, v, p.wthru);
+                    }
+                }
+            }
+        }
+        ++tile_no;
+        if (!have_next) break;
+        __builtin_amdgcn_s_barrier();                 // every wave is done with its staging area
+        cur_m0 = nxt_m0; cur_n0 = nxt_n0;
+        tid += G;
+        have_next = tid + G < n_tiles;
+        if (have_next) locate(tid + G, nxt_m0, nxt_n0, na_off, na_lo, nb_off);
+        iss_ahead = false;                            // (the stream is on this tile, two phases in)
+    }
 }
 
 // ---- host side ----
@@ -396,8 +614,75 @@ static int launch_pp_bn(const ConvArgs *a, int n, hipStream_t s) {
     }
     int G = std::min(total, cus);
     if (G >= 8) G &= ~7;                              // a workgroup's ids keep their residue mod 8: one XCD's share of the tile order
-    hipLaunchKernelGGL((conv3x3_pp<BN>), dim3(G), dim3(512), 0, s, g, total);
+    // Balanced tile lists (pp_lpt_schedule) for launches whose workgroups run more than one tile of DIFFERENT problems: built once per launch shape and
+    // device, kept for the life of the process (a few KiB each).  A shape first seen while its stream is being captured runs on the static stride.
+    const int *sched = nullptr; int sched_T = 0;
+    if (n > 1 && total > G && G <= 1024) {
+        int dev = 0;
+        RT_HIP(hipGetDevice(&dev));
+        std::string key = std::to_string(dev) + ":" + std::to_string(BN) + ":" + std::to_string(G);
+        for (int i = 0; i < n; ++i) key += ":" + std::to_string(g.gx[i] * cdiv(a[i].cout, BN)) + "x" + std::to_string(a[i].cin);
+        static std::mutex mu;
+        static std::map<std::string, std::pair<int *, int>> plans;
+        std::lock_guard<std::mutex> lock(mu);
+        auto it = plans.find(key);
+        if (it == plans.end()) {
+            hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+            if (s) RT_HIP(hipStreamIsCapturing(s, &cs));
+            if (cs == hipStreamCaptureStatusNone) {
+                int tiles[MAX_GROUP]; long cost[MAX_GROUP];
+                for (int i = 0; i < n; ++i) {
+                    tiles[i] = g.gx[i] * cdiv(a[i].cout, BN);
+                    cost[i] = (long)(9 * (a[i].cin / 64)) * (BN == 64 ? 1000 : (BN == 128 ? 1250 : 1750)) + (BN == 64 ? 3500 : (BN == 128 ? 5500 : 8000));      // phases x clk per phase + epilogue
+                }
+                const int max_T = total / (G >= 8 ? 8 : 1) + 1;      // a whole XCD share on one workgroup at worst
+                std::vector<int> wide((size_t)G * max_T);
+                const int T = pp_lpt_schedule(n, g.start, tiles, cost, G, wide.data(), max_T);
+                std::pair<int *, int> plan{nullptr, 0};
+                if (T > 0) {
+                    std::vector<int> tab((size_t)G * T);
+                    for (int w = 0; w < G; ++w)
+                        for (int j = 0; j < T; ++j) tab[(size_t)w * T + j] = wide[(size_t)w * max_T + j];
+                    RT_HIP(hipMalloc(&plan.first, tab.size() * sizeof(int)));
+                    RT_HIP(hipMemcpy(plan.first, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice));
+                    plan.second = T;
+                }
+                it = plans.emplace(key, plan).first;
+            }
+        }
+        if (it != plans.end()) { sched = it->second.first; sched_T = it->second.second; }
+    }
+    hipLaunchKernelGGL((conv3x3_pp<BN>), dim3(G), dim3(512), 0, s, g, total, sched, sched_T);
     return RTMODT_OK;
+}
+
+template <int BN>
+static int launch_tile_pp_bn(const ConvArgs &a, hipStream_t s) {
+    const int n_tiles = cdiv(a.M, 256) * cdiv(a.cout, BN);
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        RT_HIP(hipGetDevice(&dev));
+        RT_HIP(hipGetDeviceProperties(&prop, dev));
+        cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    int G = std::min(n_tiles, cus);
+    if (G >= 8) G &= ~7;
+    hipLaunchKernelGGL((conv_tile_pp<BN>), dim3(G), dim3(512), 0, s, a, n_tiles);
+    return RTMODT_OK;
+}
+
+int launch_conv_tile_pp(const ConvArgs &a, int bn, hipStream_t s) {
+    RT_CHECK(a.cin % 64 == 0 && a.kp == a.K && a.ks * a.ks * (a.cin / 64) >= 3 && !a.out2 && !a.t_wt && !a.res, RTMODT_E_INVALID,
+             "launch_conv: the ping-pong tile kernel runs one conv with cin %% 64 == 0 and K >= 192, no residual, second destination or tail");
+    RT_CHECK(a.cout % 8 == 0 && (uintptr_t)a.out % 16 == 0 && a.out_cs % 8 == 0, RTMODT_E_INVALID,
+             "launch_conv: the ping-pong tile kernel stores 16 bytes per lane (cout, channel offsets and strides %% 8 == 0)");
+    switch (bn) {
+        case 128: return launch_tile_pp_bn<128>(a, s);
+        case 64: return launch_tile_pp_bn<64>(a, s);
+        default: return fail(RTMODT_E_INVALID, "launch_conv: ping-pong tile kernel with BN %d", bn);
+    }
 }
 
 int launch_conv3x3_pp(const ConvArgs *a, int n, int bn, hipStream_t s) {

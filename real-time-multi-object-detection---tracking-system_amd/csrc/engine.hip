@@ -387,6 +387,7 @@ static int pick_tile(int M, int cout) {
 }
 
 // upload a fused conv (one or more records concatenated along cout) in the MFMA layout
+static bool tile_legal(const ConvLaunch *c, int n, int t);
 static int make_conv(rtmodt_detector *d, WeightFile &wf, const std::vector<std::string> &names, const std::string &op_name,
                      const TensorView &in, const TensorView &out, const TensorView *res, int cout_pad4,
                      std::vector<Op> *dst = nullptr) {
@@ -432,12 +433,12 @@ static int make_conv(rtmodt_detector *d, WeightFile &wf, const std::vector<std::
         if (t >= 0 && t < TILE_COUNT && tile_needs_cin64(t) && !tile_is_rows(t) && !tile_is_tail(t) && c.cin % 64 == 0 && kp % 64 == 0 && !dst &&
             (!tile_is_ws(t) || (c.ks == 1 && c.stride == 1 && tile_ws_fits(t, kp) && ((long)d->B * out.H * out.W) % 128 == 0 && cout_eff % tile_shape(t).bn == 0 && !res && out.coff % 8 == 0 && out.C % 8 == 0)) &&
             (!tile_is_pt(t) || (((long)d->B * out.H * out.W) % tile_shape(t).bm == 0 && cout_eff % tile_shape(t).bn == 0 && out.coff % 8 == 0 && out.C % 8 == 0)) &&
-            (tile_shape(t).bn <= 128 || cout_eff % tile_shape(t).bn == 0)) c.tile = t;
+            (tile_shape(t).bn <= 128 || cout_eff % tile_shape(t).bn == 0) && (!tile_is_ppt(t) || tile_legal(&c, 1, t))) c.tile = t;
     }
     if (const char *e = getenv("RTMODT_TILE_3X3S1")) {          // test hook: force a tap-reuse tile wherever it is legal
         int t = atoi(e);
         if (t >= 0 && t < TILE_COUNT && tile_is_rows(t) && c.ks == 3 && c.stride == 1 && c.in.pad == 1 &&
-            c.cin % (tile_needs_cin64(t) ? 64 : 32) == 0)
+            c.cin % (tile_needs_cin64(t) ? 64 : 32) == 0 && (!tile_is_pp(t) || tile_legal(&c, 1, t)))
             c.tile = t;
     }
     op.flops = 2LL * out.H * out.W * cout * K;
@@ -984,6 +985,13 @@ static bool tile_legal(const ConvLaunch *c, int n, int t) {
         if (tile_shape(t).bn > 128 && c[i].cout % tile_shape(t).bn != 0) return false;
     if (tile_is_pt(t) && (n != 1 || c[0].out2.base || ((long)c[0].B * c[0].out.H * c[0].out.W) % tile_shape(t).bm != 0 ||
                           c[0].cout % tile_shape(t).bn != 0 || c[0].out.coff % 8 != 0 || c[0].out.C % 8 != 0)) return false;
+    if (tile_is_ppt(t) && (n != 1 || c[0].out2.base || c[0].res.base || c[0].tail_wt || c[0].kp != c[0].ks * c[0].ks * c[0].cin || c[0].ks * c[0].ks * (c[0].cin / 64) < 3 ||
+                           c[0].cout % 8 != 0 || c[0].out.coff % 8 != 0 || c[0].out.C % 8 != 0)) return false;
+    // the ping-pong 3x3 kernel stores (and reads the shortcut) 16 bytes per lane, has no second destination, and its 192-wide form no shortcut
+    if (tile_is_pp(t))
+        for (int i = 0; i < n; ++i)
+            if (c[i].out2.base || c[i].in_lo.base || c[i].tail_wt || c[i].cout % 8 != 0 || c[i].out.coff % 8 != 0 || c[i].out.C % 8 != 0 ||
+                (c[i].res.base && (c[i].res.coff % 8 != 0 || c[i].res.C % 8 != 0 || tile_shape(t).bn > 128))) return false;
     if (tile_is_ws(t) && (n != 1 || c[0].ks != 1 || c[0].stride != 1 || c[0].in_lo.base || c[0].res.base || c[0].out2.base || !tile_ws_fits(t, c[0].kp) ||
                           ((long)c[0].B * c[0].out.H * c[0].out.W) % 128 != 0 || c[0].cout % tile_shape(t).bn != 0 || c[0].out.coff % 8 != 0 || c[0].out.C % 8 != 0)) return false;
     return true;
@@ -996,6 +1004,7 @@ static bool tail_tile_legal(const ConvLaunch &c, int t) {
 // their LDS fits 160 KiB together -- which is what lets the stages of the staged engine overlap
 static int tile_lds_kib(int t) {
     const TileShape ts = tile_shape(t);
+    if (tile_is_ppt(t)) return 3 * (ts.bm / 8 + ts.bn / 8);                  // three-slot rings for both operands
     if (tile_is_pp(t)) return 2 * (ts.bm / 8 + 1) + 3 * (ts.bn / 8);      // two strip slots + three per-tap weight slots (conv_pp.hip)
     if (tile_is_rows(t)) { const int rp = tile_needs_cin64(t) ? 8 : 16; return 2 * (ts.bm / rp + 1 + 3 * (ts.bn / rp)); }
     if (t >= TILE_WSK_64x64 && t <= TILE_WSK_64x32) return std::max(8 * (ts.bm / 16 + ts.bn / 16), 4 * (ts.bm / 16) * (ts.bn / 16));

@@ -71,7 +71,9 @@ enum ConvTile {
     // 3x3 / stride-1 PING-PONG kernel (conv_pp.hip): one persistent 8-wave workgroup per CU, its two halves one barrier interval apart
     // (one reads + issues DMA while the other multiplies), tap reuse, 256 positions x BN couts
     TILE_PP_256x128 = 57, TILE_PP_256x64 = 58, TILE_PP_256x192 = 59,
-    TILE_COUNT = 60
+    // the ping-pong schedule without tap reuse (1x1, 3x3 stride 2): one conv per launch, cin % 64 == 0, K >= 192
+    TILE_PPT_256x128 = 60, TILE_PPT_256x64 = 61,
+    TILE_COUNT = 62
 };
 const char *tile_name(int tile);
 bool tile_needs_cin64(int tile);
@@ -79,6 +81,7 @@ bool tile_is_rows(int tile);      // 3x3 stride-1 only, bordered input
 bool tile_is_pf(int tile);        // software-pipelined 64-deep tile kernel (single problems)
 bool tile_is_rows_pt(int tile);   // ... its persistent form (groups allowed)
 bool tile_is_pp(int tile);        // ping-pong 3x3 / stride-1 kernel (conv_pp.hip): cin % 64 == 0, groups allowed
+bool tile_is_ppt(int tile);       // ping-pong tile kernel without tap reuse (conv_pp.hip): one conv, cin % 64 == 0, K >= 192, no residual / second destination
 bool tile_is_tail(int tile);      // runs ConvLaunch::tail_* as well; needs cout == the tile's BN
 bool tile_reads_lo(int tile);     // can serve ConvLaunch::in_lo
 bool tile_is_w8(int tile);        // 8-wave 64-deep tile kernel (conv_mfma64_w8): one conv per launch

@@ -124,4 +124,40 @@ struct PpIssue { int nB, nA; };
 RT_HD PpIssue pp_issue(int kw, int lb, bool wave0) { return kw == 0 ? PpIssue{lb, 2 + (wave0 ? 1 : 0)} : (kw == 1 ? PpIssue{lb, 2} : PpIssue{lb, 0}); }
 constexpr int pp_wait_count(int kw, int lb, bool wave0) { return kw == 0 ? lb + 2 + (wave0 ? 1 : 0) : (kw == 1 ? 2 + (wave0 ? 1 : 0) + lb + 2 : lb); }
 
+// Which tiles each persistent workgroup of a (grouped) ping-pong launch runs: longest-processing-time-first inside each XCD's share.
+// A launch holds the tiles of up to 6 problems back to back (launch-linear ids, problem z = ids start[z] .. start[z] + tiles[z]), sorted deepest K
+// first; workgroup g of G (G % 8 == 0 or G < 8) sits, under round-robin placement, on XCD g & 7 and is given ids with the same residue mod 8 (the ids
+// of one residue are one XCD's share of xcd_tile_id's tile order: neighbouring tiles meet in one L2).  With the static stride g, g + G, ... a launch
+// whose problems differ in depth is badly balanced -- Detect stage 0 at 32 frames: 53 tiles of 72 taps x 64 channels, 205 of 36, 810 of 18; the
+// workgroups that start with a deep tile then take as many more as everybody else (284 k clk against 159 k).  Here every id goes, in order of
+// decreasing cost, to the least loaded workgroup of its XCD.  Returns T (entries per workgroup); table[g * T + j] = j-th id of workgroup g, or -1.
+// cost[z] = relative cost of one tile of problem z.
+inline int pp_lpt_schedule(int n, const int *start, const int *tiles, const long *cost, int G, int *table /* G * max_T */, int max_T) {
+    const int X = G >= 8 ? 8 : 1;
+    long load[1024] = {};
+    int cnt[1024] = {};
+    if (G > 1024) return -1;
+    for (int i = 0; i < G * max_T; ++i) table[i] = -1;
+    // problems are visited in order of decreasing cost (stable), their ids ascending
+    int order[16];
+    for (int z = 0; z < n; ++z) order[z] = z;
+    for (int i = 1; i < n; ++i)
+        for (int j = i; j > 0 && cost[order[j]] > cost[order[j - 1]]; --j) { const int t = order[j]; order[j] = order[j - 1]; order[j - 1] = t; }
+    for (int oi = 0; oi < n; ++oi) {
+        const int z = order[oi];
+        for (int k = 0; k < tiles[z]; ++k) {
+            const int id = start[z] + k, x = X == 8 ? (id & 7) : 0;
+            int best = -1;
+            for (int g = x; g < G; g += X)
+                if (best < 0 || load[g] < load[best]) best = g;
+            if (cnt[best] >= max_T) return -1;
+            table[best * max_T + cnt[best]++] = id;
+            load[best] += cost[z];
+        }
+    }
+    int T = 0;
+    for (int g = 0; g < G; ++g) T = cnt[g] > T ? cnt[g] : T;
+    return T;
+}
+
 }  // namespace rtmodt

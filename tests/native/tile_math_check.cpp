@@ -188,4 +188,52 @@ static int check_pp_schedule() {
     return 0;
 }
 
-int main() { return check_fastdiv() || check_xcd_tile() || check_pt_run() || check_swizzle() || check_nms_math() || check_pp_schedule(); }
+// pp_lpt_schedule: every launch-linear tile id of every problem appears in exactly one workgroup's list, ids keep their residue mod 8 (one XCD's
+// share), lists are dense prefixes, and no workgroup carries more than the lightest one plus one tile of the costliest problem it could still take
+static int check_pp_lpt() {
+    struct Case { int n; int tiles[6]; long cost[6]; int G; };
+    const Case cases[] = {
+        {3, {53, 205, 810}, {126000, 63000, 31500}, 256},       // Detect stage 0 at 32 frames, 192-wide tile
+        {3, {159, 615, 2430}, {75500, 39500, 21500}, 256},      // ... 64-wide tile
+        {6, {53, 53, 205, 205, 810, 810}, {24000, 24000, 24000, 24000, 24000, 24000}, 256},
+        {2, {3, 40}, {1000, 10}, 8},
+        {1, {5}, {7}, 5},
+        {2, {1000, 24}, {10, 900}, 64},
+    };
+    for (const Case &c : cases) {
+        int start[7] = {0};
+        for (int z = 0; z < c.n; ++z) start[z + 1] = (start[z] + c.tiles[z] + 7) / 8 * 8;
+        const int total = start[c.n], max_T = total / (c.G >= 8 ? 8 : 1) + 1;      // (what the launcher passes: a whole XCD share on one workgroup at worst)
+        std::vector<int> table((size_t)c.G * max_T);
+        const int T = pp_lpt_schedule(c.n, start, c.tiles, c.cost, c.G, table.data(), max_T);
+        if (T <= 0) { printf("pp_lpt_schedule: no schedule (G %d)\n", c.G); return 1; }
+        std::vector<int> seen(total, 0);
+        std::vector<long> load(c.G, 0);
+        long maxcost = 0;
+        for (int z = 0; z < c.n; ++z) maxcost = std::max(maxcost, c.cost[z]);
+        for (int g = 0; g < c.G; ++g) {
+            bool ended = false;
+            for (int j = 0; j < max_T; ++j) {
+                const int id = table[(size_t)g * max_T + j];
+                if (id < 0) { ended = true; continue; }
+                if (ended || j >= T) { printf("pp_lpt_schedule: hole in the list of workgroup %d\n", g); return 1; }
+                if (c.G >= 8 && (id & 7) != (g & 7)) { printf("pp_lpt_schedule: id %d left its XCD share (workgroup %d)\n", id, g); return 1; }
+                int z = 0;
+                while (z + 1 < c.n && id >= start[z + 1]) ++z;
+                if (id - start[z] >= c.tiles[z] || seen[id]++) { printf("pp_lpt_schedule: id %d is a filler or appears twice\n", id); return 1; }
+                load[g] += c.cost[z];
+            }
+        }
+        for (int z = 0; z < c.n; ++z)
+            for (int k = 0; k < c.tiles[z]; ++k) if (!seen[start[z] + k]) { printf("pp_lpt_schedule: id %d has no owner\n", start[z] + k); return 1; }
+        for (int x = 0; x < (c.G >= 8 ? 8 : 1); ++x) {
+            long lo = -1, hi = 0;
+            for (int g = x; g < c.G; g += (c.G >= 8 ? 8 : 1)) { lo = lo < 0 ? load[g] : std::min(lo, load[g]); hi = std::max(hi, load[g]); }
+            if (hi - lo > maxcost) { printf("pp_lpt_schedule: XCD share %d unbalanced: %ld .. %ld (costliest tile %ld)\n", x, lo, hi, maxcost); return 1; }
+        }
+    }
+    printf("ok pp lpt schedule\n");
+    return 0;
+}
+
+int main() { return check_fastdiv() || check_xcd_tile() || check_pt_run() || check_swizzle() || check_nms_math() || check_pp_schedule() || check_pp_lpt(); }

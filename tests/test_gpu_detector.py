@@ -1358,6 +1358,62 @@ def test_persistent_tap_reuse_kernel(pkg, wdir, monkeypatch, tile, size, batch, 
         assert np.array_equal(a.xyxy.view(np.int32), b.xyxy.view(np.int32)) and a.class_id.tolist() == b.class_id.tolist()
 
 
+
+@pytest.mark.parametrize("tile,size,batch,scale", [(57, 320, 32, "s"), (58, 320, 32, "s"), (59, 320, 32, "s"), (57, 288, 3, "s"), (58, 640, 4, "s"), (57, 320, 8, "m"), (58, 320, 5, "n")])
+def test_ping_pong_3x3_kernel(pkg, wdir, monkeypatch, tile, size, batch, scale):
+    """conv3x3_pp (TILE_PP_*, csrc/conv_pp.hip): the 3x3 / stride-1 kernel whose two wave halves run one barrier interval apart, forced onto
+    every conv where it is legal -- Bottlenecks with their shortcuts (fp32 staging + 16-byte shortcut reads), the grouped Detect launches (a
+    workgroup walks tiles of several problems; with the balanced schedule of pp_lpt_schedule), the 192-wide form on Detect stage 0 -- at batches
+    where a workgroup runs several tiles, at 288 x 288 (partial tiles, fewer tiles than workgroups) and on the n / m widths.  Every stored layer
+    of the first and the last image against the oracle fed the engine's own inputs."""
+    monkeypatch.setenv("RTMODT_BNECK", "0")
+    monkeypatch.setenv("RTMODT_TAIL", "0")
+    monkeypatch.setenv("RTMODT_TILE_3X3S1", str(tile))
+    frames = list(pkg.synth.frames(batch, size, size, seed=41 + tile))
+    names = [c.name for c in pkg.weights.spec(scale)]
+    det, w = make_detector(pkg, wdir, scale, size, autotune=False, batch=batch, confidence=0.05)
+    used = [n for n, _, _ in det.profile(1) if "pp:" in n]
+    assert len(used) >= (1 if tile == 59 else 6), [n for n, _, _ in det.profile(1)]
+    det.detect_batch(frames)
+    for img in sorted({0, batch - 1}):
+        inp, _, _ = det.debug_fetch(img, want_heads=False, want_pred=False)
+        gpu = fetch_layers(pkg, det, names, img)
+        taps = {}
+        Y.forward(inp.astype(np.float32), w, scale, taps=taps, force=gpu)
+        for n in gpu:
+            tol = 2e-3 * np.abs(taps[n]).max() + 2e-3
+            err = float(np.abs(taps[n] - gpu[n]).max())
+            assert err <= tol, f"tile {tile} img {img} layer {n}: max err {err:.4g} > tol {tol:.4g}; launches: {used}"
+    det.close()
+
+
+@pytest.mark.parametrize("tile,size,batch,up_read,scale", [(60, 320, 32, "1", "s"), (61, 320, 32, "0", "s"), (60, 288, 3, "1", "s"), (60, 640, 2, "1", "s"), (61, 320, 8, "1", "m")])
+def test_ping_pong_tile_kernel(pkg, wdir, monkeypatch, tile, size, batch, up_read, scale):
+    """conv_tile_pp (TILE_PPT_*): the ping-pong schedule without tap reuse -- 1x1 convs (incl. the neck layers that read their upsampled channels
+    from the half-resolution tensor, up_read = 1) and the 3x3 / stride-2 convs -- forced wherever it is legal (cin % 64 == 0, K >= 192, no shortcut);
+    persistent workgroups over several tiles, partial tiles at 288 x 288.  Every stored layer of the first and the last image against the oracle."""
+    monkeypatch.setenv("RTMODT_BNECK", "0")
+    monkeypatch.setenv("RTMODT_TAIL", "0")
+    monkeypatch.setenv("RTMODT_UP_READ", up_read)
+    monkeypatch.setenv("RTMODT_TILE_K64", str(tile))
+    monkeypatch.setenv("RTMODT_TILE_3X3S1", "-1")            # (no tap-reuse tiles: the 3x3 / stride-1 convs without a shortcut take the forced tile too)
+    frames = list(pkg.synth.frames(batch, size, size, seed=61 + tile))
+    names = [c.name for c in pkg.weights.spec(scale)]
+    det, w = make_detector(pkg, wdir, scale, size, autotune=False, batch=batch, confidence=0.05)
+    used = [n for n, _, _ in det.profile(1) if "ppt:" in n]
+    assert len(used) >= 8, [n for n, _, _ in det.profile(1)]
+    det.detect_batch(frames)
+    for img in sorted({0, batch - 1}):
+        inp, _, _ = det.debug_fetch(img, want_heads=False, want_pred=False)
+        gpu = fetch_layers(pkg, det, names, img)
+        taps = {}
+        Y.forward(inp.astype(np.float32), w, scale, taps=taps, force=gpu)
+        for n in gpu:
+            tol = 2e-3 * np.abs(taps[n]).max() + 2e-3
+            err = float(np.abs(taps[n] - gpu[n]).max())
+            assert err <= tol, f"tile {tile} img {img} layer {n}: max err {err:.4g} > tol {tol:.4g}; launches: {used}"
+    det.close()
+
 def test_in_kernel_clock_sampling(pkg, wdir):
     """rtmodt_detector_clock_enable / _read: one wave behind every batch's NMS reads the shader-cycle counter against the constant
     100 MHz counter; the clock must be a plausible gfx950 shader clock, one sample per batch, and sampling must not change results."""

@@ -28,20 +28,21 @@ static unsigned rng_state = 12345;
 static float frand() { rng_state = rng_state * 1664525u + 1013904223u; return ((rng_state >> 8) & 0xFFFF) / 65536.f - 0.5f; }
 
 struct Problem {
-    int cin, cout, HW, B; bool res;
+    int cin, cout, HW, B; bool res; int ks = 3, stride = 1;      // HW = OUTPUT size; the input is HW * stride
     f16 *in = nullptr, *out = nullptr, *resbuf = nullptr, *w = nullptr; float *bias = nullptr;
     size_t out_elems = 0;
     ConvLaunch c;
 };
 
 static void make_problem(Problem &P) {
+    const int IW = P.HW * P.stride, Hi = IW + 2;
     const int Hp = P.HW + 2;
-    const size_t per = (size_t)Hp * Hp;
-    std::vector<f16> h(per * P.B * P.cin, (f16)0.f);
+    const size_t per = (size_t)Hp * Hp, per_in = (size_t)Hi * Hi;
+    std::vector<f16> h(per_in * P.B * P.cin, (f16)0.f);
     for (int b = 0; b < P.B; ++b)
-        for (int y = 1; y <= P.HW; ++y)
-            for (int x = 1; x <= P.HW; ++x) {
-                f16 *px = &h[((size_t)(b * Hp + y) * Hp + x) * P.cin];
+        for (int y = 1; y <= IW; ++y)
+            for (int x = 1; x <= IW; ++x) {
+                f16 *px = &h[((size_t)(b * Hi + y) * Hi + x) * P.cin];
                 for (int c = 0; c < P.cin; ++c) px[c] = (f16)(2.f * frand());
             }
     CK(hipMalloc(&P.in, h.size() * 2)); CK(hipMemcpy(P.in, h.data(), h.size() * 2, hipMemcpyHostToDevice));
@@ -52,7 +53,7 @@ static void make_problem(Problem &P) {
         for (auto &v : hr) v = (f16)frand();
         CK(hipMalloc(&P.resbuf, hr.size() * 2)); CK(hipMemcpy(P.resbuf, hr.data(), hr.size() * 2, hipMemcpyHostToDevice));
     }
-    const int cp = (P.cout + 127) / 128 * 128, K = 9 * P.cin;
+    const int cp = (P.cout + 127) / 128 * 128, K = P.ks * P.ks * P.cin;
     std::vector<f16> hw((size_t)cp * K, (f16)0.f);
     const float sc = 2.0f / std::sqrt((float)K);
     for (int n = 0; n < P.cout; ++n)
@@ -61,11 +62,11 @@ static void make_problem(Problem &P) {
     std::vector<float> hb(cp, 0.f);
     for (int n = 0; n < P.cout; ++n) hb[n] = 0.5f * frand();
     CK(hipMalloc(&P.bias, hb.size() * 4)); CK(hipMemcpy(P.bias, hb.data(), hb.size() * 4, hipMemcpyHostToDevice));
-    auto view = [&](f16 *base, int Ct) { TensorView v; v.base = base; v.H = v.W = P.HW; v.C = Ct; v.pad = 1; v.coff = 0; v.c = Ct; return v; };
+    auto view = [&](f16 *base, int Ct, int hw) { TensorView v; v.base = base; v.H = v.W = hw; v.C = Ct; v.pad = 1; v.coff = 0; v.c = Ct; return v; };
     ConvLaunch &c = P.c;
-    c.in = view(P.in, P.cin); c.out = view(P.out, P.cout);
-    if (P.res) c.res = view(P.resbuf, P.cout);
-    c.wt = P.w; c.bias = P.bias; c.B = P.B; c.cin = P.cin; c.cout = P.cout; c.ks = 3; c.stride = 1; c.act = 1; c.kp = K;
+    c.in = view(P.in, P.cin, IW); c.out = view(P.out, P.cout, P.HW);
+    if (P.res) c.res = view(P.resbuf, P.cout, P.HW);
+    c.wt = P.w; c.bias = P.bias; c.B = P.B; c.cin = P.cin; c.cout = P.cout; c.ks = P.ks; c.stride = P.stride; c.act = 1; c.kp = K;
 }
 static void free_problem(Problem &P) {
     hipFree(P.in); hipFree(P.out); hipFree(P.w); hipFree(P.bias); if (P.resbuf) hipFree(P.resbuf);
@@ -156,7 +157,7 @@ int main(int argc, char **argv) {
     CK(hipMalloc(&d_st, (size_t)4096 * 16 * 8));
     CK(hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), &d_st, sizeof(d_st)));
 #endif
-    struct Shape { const char *name; int cin, cout, HW, B; bool res; };
+    struct Shape { const char *name; int cin, cout, HW, B; bool res; int ks = 3, stride = 1; };
     const Shape shapes[] = {
         {"6.m.0.cv1  128->128 @40", 128, 128, 40, 32, false},
         {"6.m.0.cv2  128->128 @40 +res", 128, 128, 40, 32, true},
@@ -168,21 +169,39 @@ int main(int argc, char **argv) {
         {"22.s1 P3   128->128 @80", 128, 128, 80, 32, false},
         {"22.s1 P3b  64->64 @80", 64, 64, 80, 32, false},
         {"small      64->128 @12 B=3", 64, 128, 12, 3, true},
+        {"1x1 4.cv2   256->128 @80", 256, 128, 80, 32, false, 1, 1},
+        {"1x1 15.cv1  384->128 @80", 384, 128, 80, 32, false, 1, 1},
+        {"1x1 15.cv2  192->128 @80", 192, 128, 80, 32, false, 1, 1},
+        {"1x1 6.cv1   256->256 @40", 256, 256, 40, 32, false, 1, 1},
+        {"1x1 6.cv2   512->256 @40", 512, 256, 40, 32, false, 1, 1},
+        {"1x1 12.cv1  768->256 @40", 768, 256, 40, 32, false, 1, 1},
+        {"1x1 8.cv1   512->512 @20", 512, 512, 20, 32, false, 1, 1},
+        {"1x1 9.cv2   1024->512 @20", 1024, 512, 20, 32, false, 1, 1},
+        {"3x3s2 5     128->256 @40", 128, 256, 40, 32, false, 3, 2},
+        {"3x3s2 7     256->512 @20", 256, 512, 20, 32, false, 3, 2},
+        {"3x3s2 16    128->128 @40", 128, 128, 40, 32, false, 3, 2},
+        {"1x1 small   192->72 @13 B=3", 192, 72, 13, 3, false, 1, 1},
+        {"3x3s2 small 64->128 @7 B=5", 64, 128, 7, 5, false, 3, 2},
     };
-    const int tiles[] = {TILE_ROWS_K64_256x64_W8, TILE_ROWS_256x64_W8, TILE_ROWS_K64_128x128_W8, TILE_PT_128x128_S2, TILE_PT_128x64_S2, TILE_K64_128x128_S2_W8, TILE_PP_256x128, TILE_PP_256x64, TILE_PP_256x192};
+    const int tiles3[] = {TILE_ROWS_K64_256x64_W8, TILE_ROWS_256x64_W8, TILE_ROWS_K64_128x128_W8, TILE_PT_128x128_S2, TILE_PT_128x64_S2, TILE_K64_128x128_S2_W8, TILE_PP_256x128, TILE_PP_256x64, TILE_PP_256x192};
+    const int tilesg[] = {TILE_K64_128x128_S3, TILE_K64_128x128_S2_W8, TILE_K64_256x128_S2_W8, TILE_PT_128x128_S2, TILE_PT_128x64_S2, TILE_PPT_256x128, TILE_PPT_256x64};
     for (const Shape &sh : shapes) {
         if (*filter && !strstr(sh.name, filter)) continue;
         std::vector<Problem> ps(1);
-        ps[0].cin = sh.cin; ps[0].cout = sh.cout; ps[0].HW = sh.HW; ps[0].B = sh.B; ps[0].res = sh.res;
+        ps[0].cin = sh.cin; ps[0].cout = sh.cout; ps[0].HW = sh.HW; ps[0].B = sh.B; ps[0].res = sh.res; ps[0].ks = sh.ks; ps[0].stride = sh.stride;
         make_problem(ps[0]);
-        const double gflop = 2.0 * sh.B * sh.HW * sh.HW * (double)sh.cout * 9 * sh.cin * 1e-9;
+        const double gflop = 2.0 * sh.B * sh.HW * sh.HW * (double)sh.cout * sh.ks * sh.ks * sh.cin * 1e-9;
+        const bool s1 = sh.ks == 3 && sh.stride == 1;
+        const int *tiles = s1 ? tiles3 : tilesg;
+        const int ntl = s1 ? (int)(sizeof(tiles3) / sizeof(int)) : (int)(sizeof(tilesg) / sizeof(int));
         printf("%s  (B %d, %.2f GFLOP)\n", sh.name, sh.B, gflop);
         std::vector<f16> ref;
-        for (int t : tiles) {
+        for (int ti = 0; ti < ntl; ++ti) {
+            const int t = tiles[ti];
             if (tile_is_pt(t) && (((long)sh.B * sh.HW * sh.HW) % tile_shape(t).bm != 0 || sh.cout % tile_shape(t).bn != 0)) continue;
             if (t == TILE_PP_256x192 && (sh.cout % 192 != 0 || sh.res)) continue;
 #ifdef RTMODT_STAMP
-            if (!tile_is_pp(t)) continue;
+            if (!tile_is_pp(t) && !tile_is_ppt(t)) continue;
             CK(hipMemset(d_st, 0, (size_t)4096 * 16 * 8));
 #endif
             const float us = time_group(ps, t, iters);
@@ -190,7 +209,7 @@ int main(int argc, char **argv) {
             std::vector<f16> got = fetch(ps[0]);
             if (ref.empty()) ref = got;
             const Cmp c = compare(got, ref);
-            printf("   %-20s %8.2f us  %7.1f TFLOP/s   max|d| %.4g (max|ref| %.3g)  outside tol: %zu of %zu%s\n", tile_name(t), us, gflop / us, c.max_abs, c.max_ref, c.bad, c.n,
+            printf("   %-20s %8.2f us  %7.1f TFLOP/s   max|d| %.4g (max|ref| %.3g)  outside tol: %zu of %zu%s\n", tile_name(t), us, gflop / us * 1e3, c.max_abs, c.max_ref, c.bad, c.n,
                    c.bad ? "   <-- MISMATCH" : "");
 #ifdef RTMODT_STAMP
             print_stamps(256);
@@ -231,7 +250,7 @@ int main(int argc, char **argv) {
                     const Cmp c = compare(got, ref[i]);
                     bad += c.bad; md = std::max(md, c.max_abs);
                 }
-                printf("   %-20s %8.2f us  %7.1f TFLOP/s   max|d| %.4g  outside tol: %zu%s\n", tile_name(t), us, gflop / us, md, bad, bad ? "   <-- MISMATCH" : "");
+                printf("   %-20s %8.2f us  %7.1f TFLOP/s   max|d| %.4g  outside tol: %zu%s\n", tile_name(t), us, gflop / us * 1e3, md, bad, bad ? "   <-- MISMATCH" : "");
             }
             for (auto &p : ps) free_problem(p);
         }
