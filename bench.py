@@ -547,13 +547,15 @@ def main():
             res["roofline"]["at_held_clock"] = {"sclk_mhz": pcw["sclk_mhz_mean"], "peak": round(held, 1), "frac": round(res["roofline"]["achieved"] / held, 4),
                                                 "package_power_w": pcw["package_power_w_mean"], "power_cap_w": pcw["power_cap_w"]}
 
-    tpath = os.path.join(ROOT, "profiles", "traffic_current.json")
-    if os.path.exists(tpath) and not args.host_frames:
-        tj = json.load(open(tpath))
-        if tj.get("workload_key") == f"{args.model}-{size}-{S}x{F}":
-            res["roofline"]["traffic"] = tj["hbm_bytes_per_step"]      # rocprofv3 PMC passes, see profiles/<round>/README.md
-            res["roofline"]["traffic_unit"] = "bytes per step (FETCH_SIZE x2 + WRITE_SIZE over the forward-pass launches)"
-            res["roofline"]["traffic_source"] = tj["source"]
+    if not args.host_frames:
+        # HBM bytes per step come from separate rocprofv3 PMC passes (tools/collect_profiles.sh), so this line can only carry them while they still
+        # describe the kernels it ran: the JSON is stamped with a digest of csrc/, and a tree whose kernels changed since prints null and says why
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        from kernel_digest import csrc_digest, load_traffic
+        traffic, why = load_traffic(os.path.join(ROOT, "profiles", "traffic_current.json"), f"{args.model}-{size}-{S}x{F}", csrc_digest())
+        res["roofline"]["traffic"] = traffic
+        res["roofline"]["traffic_unit"] = "bytes per step (FETCH_SIZE x2 + WRITE_SIZE over the forward-pass launches)"
+        res["roofline"]["traffic_source"] = why
 
     # ---- untimed self-check on one more batch of the SAME detector: NMS survivors, boxes, scores and classes of every image
     # must equal the oracle's non_max_suppression + scale_boxes on the engine's own pre-NMS tensor (the oracle is the checker) ----

@@ -77,7 +77,9 @@ if fetch and write:
     hbm = int((2 * F + W) * 1024)
     cfg = json.loads(open(os.path.join(src, "stats_bench.json")).read().strip().splitlines()[-1])["config"]
     key = f"s-640-{cfg['streams_per_gpu']}x{cfg.get('frames_per_stream_per_step', 1)}"
-    json.dump({"workload_key": key, "hbm_bytes_per_step": hbm, "fetch_size_kb_per_step": round(F, 1),
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from kernel_digest import csrc_digest
+    json.dump({"workload_key": key, "csrc_sha256": csrc_digest(), "hbm_bytes_per_step": hbm, "fetch_size_kb_per_step": round(F, 1),
                "write_size_kb_per_step": round(W, 1),
                "source": dst + "/pmc_per_kernel.csv: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over "
                          "`bench.py --steps 20`; forward-pass launches of the last 10 steps; bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 "
