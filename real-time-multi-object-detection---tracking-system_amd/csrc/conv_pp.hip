@@ -674,8 +674,9 @@ static int launch_tile_pp_bn(const ConvArgs &a, hipStream_t s) {
 }
 
 int launch_conv_tile_pp(const ConvArgs &a, int bn, hipStream_t s) {
-    RT_CHECK(a.cin % 64 == 0 && a.kp == a.K && a.ks * a.ks * (a.cin / 64) >= 3 && !a.out2 && !a.t_wt && !a.res, RTMODT_E_INVALID,
-             "launch_conv: the ping-pong tile kernel runs one conv with cin %% 64 == 0 and K >= 192, no residual, second destination or tail");
+    RT_CHECK(a.cin % 64 == 0 && a.kp == a.K && a.ks * a.ks * (a.cin / 64) >= 3 && !a.out2 && !a.res, RTMODT_E_INVALID,
+             "launch_conv: the ping-pong tile kernel runs one conv with cin %% 64 == 0 and K >= 192, no residual or second destination "
+             "(cin %d, ks %d, kp %d, K %d, residual %d, second destination %d)", a.cin, a.ks, a.kp, a.K, a.res != nullptr, a.out2 != nullptr);      // (a tail attached to the launch is ignored, as by every non-tail tile)
     RT_CHECK(a.cout % 8 == 0 && (uintptr_t)a.out % 16 == 0 && a.out_cs % 8 == 0, RTMODT_E_INVALID,
              "launch_conv: the ping-pong tile kernel stores 16 bytes per lane (cout, channel offsets and strides %% 8 == 0)");
     switch (bn) {
@@ -687,8 +688,8 @@ int launch_conv_tile_pp(const ConvArgs &a, int bn, hipStream_t s) {
 
 int launch_conv3x3_pp(const ConvArgs *a, int n, int bn, hipStream_t s) {
     for (int i = 0; i < n; ++i) {
-        RT_CHECK(a[i].ks == 3 && a[i].stride == 1 && a[i].cin % 64 == 0 && a[i].kp % 64 == 0 && !a[i].in2 && !a[i].out2 && !a[i].t_wt, RTMODT_E_INVALID,
-                 "launch_conv: the ping-pong tile runs 3x3 stride-1 convs with cin %% 64 == 0, no second destination, no tail");
+        RT_CHECK(a[i].ks == 3 && a[i].stride == 1 && a[i].cin % 64 == 0 && a[i].kp % 64 == 0 && !a[i].in2 && !a[i].out2, RTMODT_E_INVALID,
+                 "launch_conv: the ping-pong tile runs 3x3 stride-1 convs with cin %% 64 == 0, no second destination");
         // 16-byte stores (and residual loads): channel offsets and pixel strides in multiples of 8 halves
         RT_CHECK(a[i].cout % 8 == 0 && (uintptr_t)a[i].out % 16 == 0 && a[i].out_cs % 8 == 0 && (!a[i].res || ((uintptr_t)a[i].res % 16 == 0 && a[i].res_cs % 8 == 0)),
                  RTMODT_E_INVALID, "launch_conv: the ping-pong tile stores 16 bytes per lane (cout, channel offsets and strides %% 8 == 0)");

@@ -567,7 +567,7 @@ static int build_graph(rtmodt_detector *d, WeightFile &wf) {
     // a conv that also writes the nearest-2x copy cannot run as the tail of the Bottleneck before it
     auto fold_into_last = [&](const TensorView &up) {
         d->ops.back().conv.out2 = up;
-        if (tile_is_ws(d->ops.back().conv.tile) || tile_is_pt(d->ops.back().conv.tile)) d->ops.back().conv.tile = TILE_K64_128x128_S2;      // (test hook's forced tile: no second destination there)
+        if (tile_is_ws(d->ops.back().conv.tile) || tile_is_pt(d->ops.back().conv.tile) || tile_is_ppt(d->ops.back().conv.tile)) d->ops.back().conv.tile = TILE_K64_128x128_S2;      // (test hook's forced tile: no second destination there)
         d->ops.back().skip = false;
         if (d->ops.size() >= 2) { Op &bn = d->ops[d->ops.size() - 2]; if (bn.kind == OP_BNECK) { bn.bneck.tail_wt = nullptr; bn.tail_on = false; } }
     };
@@ -985,12 +985,12 @@ static bool tile_legal(const ConvLaunch *c, int n, int t) {
         if (tile_shape(t).bn > 128 && c[i].cout % tile_shape(t).bn != 0) return false;
     if (tile_is_pt(t) && (n != 1 || c[0].out2.base || ((long)c[0].B * c[0].out.H * c[0].out.W) % tile_shape(t).bm != 0 ||
                           c[0].cout % tile_shape(t).bn != 0 || c[0].out.coff % 8 != 0 || c[0].out.C % 8 != 0)) return false;
-    if (tile_is_ppt(t) && (n != 1 || c[0].out2.base || c[0].res.base || c[0].tail_wt || c[0].kp != c[0].ks * c[0].ks * c[0].cin || c[0].ks * c[0].ks * (c[0].cin / 64) < 3 ||
+    if (tile_is_ppt(t) && (n != 1 || c[0].out2.base || c[0].res.base || c[0].kp != c[0].ks * c[0].ks * c[0].cin || c[0].ks * c[0].ks * (c[0].cin / 64) < 3 ||
                            c[0].cout % 8 != 0 || c[0].out.coff % 8 != 0 || c[0].out.C % 8 != 0)) return false;
     // the ping-pong 3x3 kernel stores (and reads the shortcut) 16 bytes per lane, has no second destination, and its 192-wide form no shortcut
     if (tile_is_pp(t))
         for (int i = 0; i < n; ++i)
-            if (c[i].out2.base || c[i].in_lo.base || c[i].tail_wt || c[i].cout % 8 != 0 || c[i].out.coff % 8 != 0 || c[i].out.C % 8 != 0 ||
+            if (c[i].out2.base || c[i].in_lo.base || c[i].cout % 8 != 0 || c[i].out.coff % 8 != 0 || c[i].out.C % 8 != 0 ||
                 (c[i].res.base && (c[i].res.coff % 8 != 0 || c[i].res.C % 8 != 0 || tile_shape(t).bn > 128))) return false;
     if (tile_is_ws(t) && (n != 1 || c[0].ks != 1 || c[0].stride != 1 || c[0].in_lo.base || c[0].res.base || c[0].out2.base || !tile_ws_fits(t, c[0].kp) ||
                           ((long)c[0].B * c[0].out.H * c[0].out.W) % 128 != 0 || c[0].cout % tile_shape(t).bn != 0 || c[0].out.coff % 8 != 0 || c[0].out.C % 8 != 0)) return false;
