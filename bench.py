@@ -572,6 +572,8 @@ def main():
     res["roofline"]["conv_kernels_tflops_eager"] = round(sum(fl for _, _, fl in prof) / (conv_ms * 1e-3) / 1e12, 2)
     top = sorted(prof, key=lambda r: -r[1])[:6]
     res["roofline"]["slowest_launches"] = [{"op": n, "ms": round(ms, 4), "tflops": round(fl / (ms * 1e-3) / 1e12, 1) if ms > 0 else 0} for n, ms, fl in top]
+    # every launch of the forward pass alone on the device (eager, HIP events): [op, microseconds, TFLOP/s]
+    res["roofline"]["launches_eager"] = [[n, round(ms * 1e3, 1), round(fl / (ms * 1e-3) / 1e12, 1) if ms > 0 and fl > 0 else 0] for n, ms, fl in prof]
     det.close()
     trk.close()
 

@@ -202,7 +202,7 @@ def upsample2(x):
 # ---------------------------------------------------------------------------
 # network forward
 # ---------------------------------------------------------------------------
-def forward(x, weights: dict, scale="s", nc=80, reg_max=16, taps: dict | None = None, force: dict | None = None):
+def forward(x, weights: dict, scale="s", nc=80, reg_max=16, taps: dict | None = None, force: dict | None = None, only=None):
     """x: (H,W,3) float32 RGB in [0,1].  ``weights[name] = (w, b)``.  Returns the three
     Detect maps ``[(H_i, W_i, 4*reg_max + nc)]`` (box logits first, then class logits).
 
@@ -210,7 +210,11 @@ def forward(x, weights: dict, scale="s", nc=80, reg_max=16, taps: dict | None = 
     second conv: the value AFTER the residual add, which is what the engine stores) and
     every module output by integer index.  ``force[name]`` (optional) replaces that conv's
     output before it is used downstream -- "teacher forcing" with the engine's own
-    activations, so each layer can be checked in isolation with a tight tolerance."""
+    activations, so each layer can be checked in isolation with a tight tolerance.
+    ``only`` (optional set of conv names): ONLY these convs are computed, every other conv's output is taken
+    from ``force`` (which must then hold it) -- teacher-forced checks of a few layers of a large net (YOLOv8m
+    at 1280 x 1280 is 316 GFLOP of NumPy) without running the rest; ``taps`` then holds the computed ones only
+    (and the module outputs they feed, which are NOT meaningful: the Detect maps returned are not to be used)."""
     mods, head = arch(scale, nc, reg_max)
     force = force or {}
 
@@ -222,6 +226,12 @@ def forward(x, weights: dict, scale="s", nc=80, reg_max=16, taps: dict | None = 
 
     def cv(name, t, stride, act, res=None):
         w, b = weights[name]
+        if only is not None and name not in only:          # not asked for: pass the engine's tensor on (or zeros of the right shape when it stored none)
+            f = force.get(name)
+            if f is not None:
+                return np.asarray(f, dtype=F32)
+            k = w.shape[1]
+            return np.zeros(((t.shape[0] + 2 * (k // 2) - k) // stride + 1, (t.shape[1] + 2 * (k // 2) - k) // stride + 1, w.shape[0]), dtype=F32)
         y = conv2d_nhwc(t, w, b, stride=stride, act=act)
         if res is not None:
             y = (res + y).astype(F32)

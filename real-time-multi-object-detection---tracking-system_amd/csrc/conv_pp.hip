@@ -75,6 +75,38 @@ struct PpCfg {
 #define FSTAMP(k)
 #endif
 
+
+// Where output position m (of the launch's position enumeration: `wq` positions per image row, of which the first Wo hold outputs) and channel n go:
+// element offset into the output (and shortcut) tensor, and whether there is anything to store.  One multiply-high + shift per division (FastDiv),
+// 24-bit multiplies (full rate; every factor < 2^24: checked at launch) and ONE combined predicate -- the straightforward form (nested conditions, 32-bit
+// multiplies, 64-bit offsets) was half of the epilogue's 716 instructions per wave (profiles/r04/pp/README.md).
+struct PpOut {
+    int M, HW, wq, Ho, Wo, cout;
+    int o0, o1, o2, ocs;          // output: offset of (b, y, x) = o0 + b * o1 + y * o2 + x * ocs
+    int r0, r1, r2, rcs;          // shortcut tensor, likewise
+    FastDiv d_img, d_row;
+    __device__ __forceinline__ bool index(int m, int n, int &opix, int &rpix) const {
+        const int b = fdiv(m, d_img), rem = m - (int)__umul24((unsigned)b, (unsigned)HW);
+        const int oy = fdiv(rem, d_row), ox = rem - (int)__umul24((unsigned)oy, (unsigned)wq);
+        opix = o0 + (int)__umul24((unsigned)b, (unsigned)o1) + (int)__umul24((unsigned)oy, (unsigned)o2) + (int)__umul24((unsigned)ox, (unsigned)ocs) + n;
+        rpix = r0 + (int)__umul24((unsigned)b, (unsigned)r1) + (int)__umul24((unsigned)oy, (unsigned)r2) + (int)__umul24((unsigned)ox, (unsigned)rcs) + n;
+        return (m < M) & (oy < Ho) & (ox < Wo) & (n < cout);
+    }
+};
+__device__ __forceinline__ PpOut pp_out(const ConvArgs &p, int rows_wq, const FastDiv &d_img, const FastDiv &d_row) {
+    PpOut o;
+    o.M = p.M; o.wq = rows_wq; o.HW = p.Ho * rows_wq; o.Ho = p.Ho; o.Wo = p.Wo; o.cout = p.cout;
+    o.ocs = p.out_cs; o.o2 = p.out_Wp * p.out_cs; o.o1 = p.out_Hp * o.o2; o.o0 = p.out_pad * o.o2 + p.out_pad * p.out_cs;
+    o.rcs = p.res_cs; o.r2 = p.res_Wp * p.res_cs; o.r1 = p.res_Hp * o.r2; o.r0 = p.res_pad * o.r2 + p.res_pad * p.res_cs;
+    o.d_img = d_img; o.d_row = d_row;
+    return o;
+}
+// the host-side condition of PpOut's 24-bit multiplies
+static bool pp_out_fits(const ConvArgs &a) {
+    const long lim = 1L << 24;
+    return (long)a.out_Hp * a.out_Wp * a.out_cs < lim && (!a.res || (long)a.res_Hp * a.res_Wp * a.res_cs < lim) && (long)a.Ho * a.in_Wp < lim && a.M < (1 << 30);
+}
+
 template <int N>
 __device__ __forceinline__ void pp_wait() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
@@ -112,9 +144,11 @@ __global__ __launch_bounds__(512) void conv3x3_pp(ConvGroupArgs g, int total_ids
         const char *in, *wt;                          // of the tile's problem (wave-uniform)
         int z, m0, n0, ns, cin;
         unsigned row_bytes;                           // bytes between two padded input rows (the kh step)
-        unsigned a_off[5], b_off;                     // per lane, bytes: its row of strip piece wave + 8 i (i = 4: piece 32, wave 0 only); its row of weight piece `wave`
-        unsigned b_step;                              // (wave-uniform) bytes from weight piece j to j + 8: 64 cout rows
-    };
+        unsigned b_step;                              // bytes from weight piece j to j + 8: 64 cout rows
+    };                                                // (wave-uniform values only: two of these live in SGPRs)
+    // per lane, bytes, of the tile the DMA stream is feeding: its row of strip piece wave + 8 i (i = 4: piece 32, wave 0 only); its row of weight piece
+    // `wave`.  Worked out when the stream moves on to a tile (lane_offsets), not kept per located tile: the 192-wide tile has no registers for a second set.
+    unsigned ia_off[5], ib_off;
     const int G = gridDim.x;
     auto locate = [&](int id, Tile &t) -> bool {      // launch-linear id -> (problem, tile); false for the alignment fillers between problems
         int z = 0;
@@ -128,14 +162,17 @@ __global__ __launch_bounds__(512) void conv3x3_pp(ConvGroupArgs g, int total_ids
         xcd_tile(gx, gy, bx, by, mt, nt);
         t.z = z; t.m0 = mt * BM; t.n0 = nt * BN; t.ns = 3 * (p.cin / 64);
         t.in = (const char *)p.in; t.wt = (const char *)p.wt; t.cin = p.cin; t.row_bytes = (unsigned)(p.in_Wp * p.in_cs) * 2u;
+        t.b_step = (unsigned)(64 * p.kp) * 2u;
+        return true;
+    };
+    auto lane_offsets = [&](const Tile &t) {
+        const ConvArgs &p = g.p[t.z];
         // positions past the last image are clamped so that position + kh rows stays inside the tensor: two rows above its last pixel, on the (zero)
         // right border column for kh = 0, 1 and on the last (zero) pixel for kh = 2; no enumerated position of a real image reaches that far
         const int clamp = p.last_pos - 2 * p.in_Wp;
 #pragma unroll
-        for (int i = 0; i < 5; ++i) t.a_off[i] = (unsigned)(min(rows_pos(p, t.m0 + (wave + NW * i) * 8 + ld_row), clamp) * p.in_cs + ld_chunk) * 2u;
-        t.b_off = (unsigned)((t.n0 + wave * 8 + ld_row) * p.kp + ld_chunk) * 2u;
-        t.b_step = (unsigned)(64 * p.kp) * 2u;
-        return true;
+        for (int i = 0; i < 5; ++i) ia_off[i] = (unsigned)(min(rows_pos(p, t.m0 + (wave + NW * i) * 8 + ld_row), clamp) * p.in_cs + ld_chunk) * 2u;
+        ib_off = (unsigned)((t.n0 + wave * 8 + ld_row) * p.kp + ld_chunk) * 2u;
     };
     // the j-th tile of this workgroup: from the launch's schedule (pp_lpt_schedule, read through the SCALAR cache: a vector load would sit in the vmcnt
     // queue of the DMA stream), or -- no schedule -- the ids blockIdx.x, + G, ... with the alignment fillers between problems skipped.  false: no more.
@@ -159,12 +196,12 @@ __global__ __launch_bounds__(512) void conv3x3_pp(ConvGroupArgs g, int total_ids
     auto issue_B = [&](const Tile &t, int kh, int kw, int c0, int slot) {
         const char *base = t.wt + (size_t)(((kh * 3 + kw) * t.cin + c0) * 2);
 #pragma unroll
-        for (int j = 0; j < LB; ++j) dma(base + (size_t)j * t.b_step, t.b_off, lds + C::B_OFF + slot * C::BSLOT + (wave + NW * j) * 1024);
+        for (int j = 0; j < LB; ++j) dma(base + (size_t)j * t.b_step, ib_off, lds + C::B_OFF + slot * C::BSLOT + (wave + NW * j) * 1024);
     };
     // strip piece wave + 8 i of (kh, c0) -> strip slot `slot`
     auto issue_A = [&](const Tile &t, int kh, int c0, int slot, int i) {
         const char *base = t.in + ((size_t)kh * t.row_bytes + (size_t)(c0 * 2));
-        dma(base, t.a_off[i], lds + slot * C::ASLOT + (wave + NW * i) * 1024);
+        dma(base, ia_off[i], lds + slot * C::ASLOT + (wave + NW * i) * 1024);
     };
 
     Tile cur, nxt, iss;                               // the tile being multiplied, the one after it, the one the DMA stream is feeding
@@ -172,6 +209,7 @@ __global__ __launch_bounds__(512) void conv3x3_pp(ConvGroupArgs g, int total_ids
     if (!next_tile(tj++, cur)) return;                // (the same for every wave of the workgroup)
     bool have_next = next_tile(tj++, nxt);
     iss = cur;
+    lane_offsets(cur);
 
     // bias of the first tile: requested BEFORE the first DMA piece (older than all of them)
     floatx4 bnext[TN];
@@ -225,7 +263,7 @@ __global__ __launch_bounds__(512) void conv3x3_pp(ConvGroupArgs g, int total_ids
                 // the two take turns: 16 reads ~250 clk, then ~90 clk per piece, profiles/r04/pp/)
                 if (kw == 0) {
                     issue_B(iss, kh, 2, c0, 2);
-                    if (last && have_next) iss = nxt;                       // from here on the stream feeds the next tile
+                    if (last && have_next) { iss = nxt; lane_offsets(nxt); }        // from here on the stream feeds the next tile
                     if (valid) { issue_A(iss, nkh, nc0, aslot ^ 1, 0); issue_A(iss, nkh, nc0, aslot ^ 1, 1); if (w0) issue_A(iss, nkh, nc0, aslot ^ 1, 4); }
                 } else if (kw == 1) {
                     if (valid) { issue_B(iss, nkh, 0, nc0, 0); issue_A(iss, nkh, nc0, aslot ^ 1, 2); issue_A(iss, nkh, nc0, aslot ^ 1, 3); }
@@ -295,31 +333,26 @@ __global__ __launch_bounds__(512) void conv3x3_pp(ConvGroupArgs g, int total_ids
             // the problem's scalars, fetched in ONE batch here: read where they are used (inside the lanes' branches) hipcc fetches them from the kernel
             // argument segment again for every store, a scalar-memory round trip each -- 5 800 of the 8 000 clk this epilogue took (profiles/r04/pp/run5.txt)
             f16 *const e_out = p.out; const f16 *const e_res = p.res;
-            const int e_M = p.M, e_Ho = p.Ho, e_Wo = p.Wo, e_wq = p.rows_wq, e_HW = p.Ho * p.rows_wq, e_cout = p.cout, e_act = p.act, e_wt = p.wthru;
-            const int e_oHp = p.out_Hp, e_oWp = p.out_Wp, e_ocs = p.out_cs, e_opad = p.out_pad, e_rHp = p.res_Hp, e_rWp = p.res_Wp, e_rcs = p.res_cs, e_rpad = p.res_pad;
-            const FastDiv e_dhwp = p.d_hwp, e_dwp = p.d_wp;
-            asm volatile("" ::"s"(e_out), "s"(e_res), "s"(e_M), "s"(e_Ho), "s"(e_Wo), "s"(e_wq), "s"(e_HW), "s"(e_cout), "s"(e_act), "s"(e_wt), "s"(e_oHp), "s"(e_oWp), "s"(e_ocs), "s"(e_opad),
-                         "s"(e_rHp), "s"(e_rWp), "s"(e_rcs), "s"(e_rpad), "s"(e_dhwp.mul), "s"(e_dhwp.shift), "s"(e_dwp.mul), "s"(e_dwp.shift));
-            auto pix_out = [&](int m, int &opix, int &rpix) -> bool {      // element offsets fit 32 bits (checked at launch)
-                if (m >= e_M) return false;
-                const int b = fdiv(m, e_dhwp), rem = m - b * e_HW;
-                const int oy = fdiv(rem, e_dwp), ox = rem - oy * e_wq;
-                if (oy >= e_Ho || ox >= e_Wo) return false;
-                opix = ((b * e_oHp + oy + e_opad) * e_oWp + ox + e_opad) * e_ocs;
-                rpix = ((b * e_rHp + oy + e_rpad) * e_rWp + ox + e_rpad) * e_rcs;
-                return true;
-            };
+            const int e_act = p.act;
+            const PpOut po = pp_out(p, p.rows_wq, p.d_hwp, p.d_wp);
+            asm volatile("" ::"s"(e_out), "s"(e_res), "s"(e_act), "s"(po.M), "s"(po.HW), "s"(po.wq), "s"(po.Ho), "s"(po.Wo), "s"(po.cout), "s"(po.o0), "s"(po.o1), "s"(po.o2),
+                         "s"(po.ocs), "s"(po.r0), "s"(po.r1), "s"(po.r2), "s"(po.rcs), "s"(po.d_img.mul), "s"(po.d_img.shift), "s"(po.d_row.mul), "s"(po.d_row.shift));
             if (!e_res) {
                 constexpr int RS = HB <= 32 ? 64 : (HB <= 64 ? 128 : 256), CH = RS / 16, TR = 4096 / (16 * RS);
                 static_assert(TM % TR == 0 && (TR * 16 * CPR) % 64 == 0, "staging rounds");
 #pragma unroll
                 for (int t0 = 0; t0 < TM; t0 += TR) {
+                    if (e_act && !(ablate & 1)) {
+#pragma unroll
+                        for (int tt = 0; tt < TR; ++tt)
+#pragma unroll
+                            for (int u = 0; u < TN; ++u) { floatx4 &v = acc[t0 + tt][u]; v[0] = silu_f(v[0]); v[1] = silu_f(v[1]); v[2] = silu_f(v[2]); v[3] = silu_f(v[3]); }
+                    }
 #pragma unroll
                     for (int tt = 0; tt < TR; ++tt)
 #pragma unroll
                         for (int u = 0; u < TN; ++u) {
-                            floatx4 v = acc[t0 + tt][u];
-                            if (e_act && !(ablate & 1)) { v[0] = silu_f(v[0]); v[1] = silu_f(v[1]); v[2] = silu_f(v[2]); v[3] = silu_f(v[3]); }
+                            const floatx4 v = acc[t0 + tt][u];
                             const int pl = tt * 16 + r, c = u * 2 + (q >> 1);
                             *(half4 *)(stg + pl * RS + ((c ^ (pl & (CH - 1))) << 4) + (q & 1) * 8) = half4{(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
                         }
@@ -328,8 +361,8 @@ __global__ __launch_bounds__(512) void conv3x3_pp(ConvGroupArgs g, int total_ids
                         const int e = i * 64 + lane, pl = e / CPR, c = e - pl * CPR;
                         const half8 v = *(const half8 *)(stg + pl * RS + ((c ^ (pl & (CH - 1))) << 4));
                         int opix, rpix;
-                        const int n = cur.n0 + wn * HB + c * 8;
-                        if (pix_out(cur.m0 + (wm * TM + t0) * 16 + pl, opix, rpix) && n < e_cout && !(ablate & 2)) store16(e_out, opix + n, v, e_wt);
+                        const bool ok = po.index(cur.m0 + (wm * TM + t0) * 16 + pl, cur.n0 + wn * HB + c * 8, opix, rpix) & !(ablate & 2);
+                        if (ok) *(half8 *)(e_out + opix) = v;
                     }
                 }
             } else if constexpr (HB <= 64) {
@@ -342,11 +375,9 @@ __global__ __launch_bounds__(512) void conv3x3_pp(ConvGroupArgs g, int total_ids
 #pragma unroll
                     for (int i = 0; i < NI; ++i) {
                         const int e = i * 64 + lane, pl = e / CPR, c = e - pl * CPR;
-                        int rpix = 0;
-                        const int n = cur.n0 + wn * HB + c * 8;
-                        okx[i] = pix_out(cur.m0 + (wm * TM + t0) * 16 + pl, opx[i], rpix) && n < e_cout;
-                        opx[i] += n;
-                        rvx[i] = *(const half8 *)(e_res + (okx[i] ? rpix + n : 0));
+                        int rpix;
+                        okx[i] = po.index(cur.m0 + (wm * TM + t0) * 16 + pl, cur.n0 + wn * HB + c * 8, opx[i], rpix);
+                        rvx[i] = *(const half8 *)(e_res + (okx[i] ? rpix : 0));
                     }
                 };
                 request(0, rv[0], op[0], ok[0]);
@@ -354,12 +385,17 @@ __global__ __launch_bounds__(512) void conv3x3_pp(ConvGroupArgs g, int total_ids
                 for (int t0 = 0; t0 < TM; t0 += TR) {
                     const int cb = (t0 / TR) & 1;
                     if (t0 + TR < TM) request(t0 + TR, rv[cb ^ 1], op[cb ^ 1], ok[cb ^ 1]);
+                    if (e_act) {
+#pragma unroll
+                        for (int tt = 0; tt < TR; ++tt)
+#pragma unroll
+                            for (int u = 0; u < TN; ++u) { floatx4 &v = acc[t0 + tt][u]; v[0] = silu_f(v[0]); v[1] = silu_f(v[1]); v[2] = silu_f(v[2]); v[3] = silu_f(v[3]); }
+                    }
 #pragma unroll
                     for (int tt = 0; tt < TR; ++tt)
 #pragma unroll
                         for (int u = 0; u < TN; ++u) {
-                            floatx4 v = acc[t0 + tt][u];
-                            if (e_act) { v[0] = silu_f(v[0]); v[1] = silu_f(v[1]); v[2] = silu_f(v[2]); v[3] = silu_f(v[3]); }
+                            const floatx4 v = acc[t0 + tt][u];
                             const int pl = tt * 16 + r, c = u * 4 + q;
                             *(floatx4 *)(stg + pl * RS + ((c ^ (pl & (CH - 1))) << 4)) = v;
                         }
@@ -371,7 +407,7 @@ __global__ __launch_bounds__(512) void conv3x3_pp(ConvGroupArgs g, int total_ids
                         const half8 x = rv[cb][i];
                         const half8 o = {(f16)(lo[0] + (float)x[0]), (f16)(lo[1] + (float)x[1]), (f16)(lo[2] + (float)x[2]), (f16)(lo[3] + (float)x[3]),
                                          (f16)(hi[0] + (float)x[4]), (f16)(hi[1] + (float)x[5]), (f16)(hi[2] + (float)x[6]), (f16)(hi[3] + (float)x[7])};
-                        if (ok[cb][i]) store16(e_out, op[cb][i], o, e_wt);
+                        if (ok[cb][i]) *(half8 *)(e_out + op[cb][i]) = o;
                     }
                 }
             }
@@ -554,15 +590,20 @@ __global__ __launch_bounds__(512) void conv_tile_pp(ConvArgs p, int n_tiles) {
             constexpr int HB = BN / 2, CPR = HB / 8;
             constexpr int RS = HB <= 32 ? 64 : (HB <= 64 ? 128 : 256), CH = RS / 16, TR = 4096 / (16 * RS);
             static_assert(TM % TR == 0 && (TR * 16 * CPR) % 64 == 0, "staging rounds");
-            const int HoWo = p.Ho * p.Wo;
+            const PpOut po = pp_out(p, p.Wo, p.d_howo, p.d_wo);
 #pragma unroll
             for (int t0 = 0; t0 < TM; t0 += TR) {
+                if (p.act) {
+#pragma unroll
+                    for (int tt = 0; tt < TR; ++tt)
+#pragma unroll
+                        for (int u = 0; u < TN; ++u) { floatx4 &v = acc[t0 + tt][u]; v[0] = silu_f(v[0]); v[1] = silu_f(v[1]); v[2] = silu_f(v[2]); v[3] = silu_f(v[3]); }
+                }
 #pragma unroll
                 for (int tt = 0; tt < TR; ++tt)
 #pragma unroll
                     for (int u = 0; u < TN; ++u) {
-                        floatx4 v = acc[t0 + tt][u];
-                        if (p.act) { v[0] = silu_f(v[0]); v[1] = silu_f(v[1]); v[2] = silu_f(v[2]); v[3] = silu_f(v[3]); }
+                        const floatx4 v = acc[t0 + tt][u];
                         const int pl = tt * 16 + r, c = u * 2 + (q >> 1);
                         *(half4 *)(stg + pl * RS + ((c ^ (pl & (CH - 1))) << 4) + (q & 1) * 8) = half4{(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
                     }
@@ -570,13 +611,8 @@ __global__ __launch_bounds__(512) void conv_tile_pp(ConvArgs p, int n_tiles) {
                 for (int i = 0; i < TR * 16 * CPR / 64; ++i) {
                     const int e = i * 64 + lane, pl = e / CPR, c = e - pl * CPR;
                     const half8 v = *(const half8 *)(stg + pl * RS + ((c ^ (pl & (CH - 1))) << 4));
-                    const int m = cur_m0 + (wm * TM + t0) * 16 + pl, n = cur_n0 + wn * HB + c * 8;
-                    if (m < p.M && n < p.cout) {
-                        const int b = fdiv(m, p.d_howo), rem = m - b * HoWo;
-                        const int oy = fdiv(rem, p.d_wo), ox = rem - oy * p.Wo;
-                        const int opix = ((b * p.out_Hp + oy + p.out_pad) * p.out_Wp + ox + p.out_pad) * p.out_cs;
-                        store16(p.out, opix + n, v, p.wthru);
-                    }
+                    int opix, rpix;
+                    if (po.index(cur_m0 + (wm * TM + t0) * 16 + pl, cur_n0 + wn * HB + c * 8, opix, rpix)) *(half8 *)(p.out + opix) = v;
                 }
             }
         }
@@ -679,6 +715,7 @@ int launch_conv_tile_pp(const ConvArgs &a, int bn, hipStream_t s) {
              "(cin %d, ks %d, kp %d, K %d, residual %d, second destination %d)", a.cin, a.ks, a.kp, a.K, a.res != nullptr, a.out2 != nullptr);      // (a tail attached to the launch is ignored, as by every non-tail tile)
     RT_CHECK(a.cout % 8 == 0 && (uintptr_t)a.out % 16 == 0 && a.out_cs % 8 == 0, RTMODT_E_INVALID,
              "launch_conv: the ping-pong tile kernel stores 16 bytes per lane (cout, channel offsets and strides %% 8 == 0)");
+    RT_CHECK(pp_out_fits(a), RTMODT_E_INVALID, "launch_conv: the ping-pong tile kernel indexes its output with 24-bit multiplies (padded H x W x C of a tensor < 2^24)");
     switch (bn) {
         case 128: return launch_tile_pp_bn<128>(a, s);
         case 64: return launch_tile_pp_bn<64>(a, s);
@@ -694,6 +731,7 @@ int launch_conv3x3_pp(const ConvArgs *a, int n, int bn, hipStream_t s) {
         RT_CHECK(a[i].cout % 8 == 0 && (uintptr_t)a[i].out % 16 == 0 && a[i].out_cs % 8 == 0 && (!a[i].res || ((uintptr_t)a[i].res % 16 == 0 && a[i].res_cs % 8 == 0)),
                  RTMODT_E_INVALID, "launch_conv: the ping-pong tile stores 16 bytes per lane (cout, channel offsets and strides %% 8 == 0)");
         RT_CHECK(!a[i].res || bn <= 128, RTMODT_E_INVALID, "launch_conv: the 192-wide ping-pong tile takes no residual");
+        RT_CHECK(pp_out_fits(a[i]), RTMODT_E_INVALID, "launch_conv: the ping-pong tile indexes its output with 24-bit multiplies (padded H x W x C of a tensor < 2^24)");
     }
     switch (bn) {
         case 128: return launch_pp_bn<128>(a, n, s);

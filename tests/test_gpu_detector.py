@@ -150,8 +150,16 @@ def layer_check(pkg, det, w, frame, scale, size):
         err = float(np.abs(ref - got).max())
         if err / tol > worst[1]:
             worst = (n, err / tol)
-        assert err <= tol, f"layer {n}: max err {err:.4g} > tol {tol:.4g} (ref max {np.abs(ref).max():.3g})"
+        assert err <= tol, f"layer {n}: max err {err:.4g} > tol {tol:.4g} (ref max {np.abs(ref).max():.3g}); launches: {launch_list(det)}"
     return d, heads, pred, worst
+
+
+def launch_list(det):
+    """which kernels ran (tile per launch): printed with every layer failure -- most tests run autotuned tiles, which differ from box to box"""
+    try:
+        return [n for n, _, _ in det.profile(1)]
+    except Exception as e:      # (never hide the real failure behind the report)
+        return f"<profile failed: {e}>"
 
 
 def test_stored_layers_with_sub_batch_chains(pkg, wdir):
@@ -189,10 +197,10 @@ def test_forward_layers_yolov8s_640(pkg, wdir):
     det.close()
 
 
-@pytest.mark.parametrize("scale,size", [("n", 320), ("m", 320), ("s", 320)])
+@pytest.mark.parametrize("scale,size", [("n", 320), ("m", 320), ("s", 320), ("n", 640)])
 def test_forward_layers_other_scales(pkg, wdir, scale, size):
     """n and m have channel counts that are not multiples of 32 (16, 48): the kernel's
-    general K-chunk path."""
+    general K-chunk path.  n at 640 x 640, one frame: BASELINE config 1's workload (synthetic weights: the real checkpoint needs Ultralytics)."""
     det, w = make_detector(pkg, wdir, scale, size)
     frame = pkg.synth.frames(1, size, size, seed=77)[0]
     d, heads, pred, worst = layer_check(pkg, det, w, frame, scale, size)
@@ -351,7 +359,7 @@ def test_end_to_end_vs_fp32_oracle(pkg, wdir, src_hw, seed, autotune):
     frac_all = hit / len(rows) if rows else 1.0
     print(f"  IoU >= 0.99 + same class: {hit}/{len(rows)} = {frac_all:.4f}; score drift {score_drift:.4f}")
     assert len(rows) >= 5
-    assert frac_all >= 0.9, (frac_all, [r for r in rows if r[2] < 0.99][:8], cfg)
+    assert frac_all >= 0.95, (frac_all, [r for r in rows if r[2] < 0.99][:8], cfg)      # (measured 0.977 - 1.0 over 64 frames x 6 configurations: profiles/r03/diag_e2e)
     assert np.all(d.xyxy[:, [0, 2]] >= 0) and np.all(d.xyxy[:, [0, 2]] <= w) and np.all(d.xyxy[:, [1, 3]] <= h)
 
 
@@ -437,6 +445,33 @@ def test_config5_yolov8m_1280_dense_scene(pkg, wdir):
     assert np.abs(t - gpu["2.m.0.cv1"]).max() <= 2e-3 * np.abs(t).max() + 2e-3
     t2 = Y.conv2d_nhwc(gpu["2.m.0.cv1"], *w["2.m.0.cv2"]) + gpu["2.cv1"][..., c:]
     assert np.abs(t2 - gpu["2.m.0.cv2"]).max() <= 2e-3 * np.abs(t2).max() + 2e-3
+    # ... and, teacher-forced with the engine's own tensors, the layers whose tile paths depend on M at this size: the rest of C2f 2, one P4 and one
+    # P5 C2f (persistent-tile ownership, ping-pong tiles at 80 x 80 / 40 x 40 with cin 192 / 288 / 576), SPPF's 9.cv2, and the three Detect stacks
+    # (grouped launches over 160 / 80 / 40 pixel levels) -- about 100 GFLOP of im2col + sgemm instead of the net's 316
+    all_names = [cv.name for cv in pkg.weights.spec("m")]
+    stored = fetch_layers(pkg, det, all_names)
+    want = {"2.m.1.cv1", "2.m.1.cv2", "2.cv2", "6.cv1", "6.m.0.cv1", "6.m.0.cv2", "6.m.3.cv2", "6.cv2", "8.cv1", "8.m.0.cv1", "8.m.0.cv2", "8.m.1.cv2", "8.cv2", "9.cv2"}
+    want |= {f"22.cv{br}.{lvl}.{k}" for br in (2, 3) for lvl in range(3) for k in (0, 1)}
+    want &= set(stored)
+
+    def producers(n):          # the convs whose stored outputs feed conv n (a layer the engine did not store cannot be teacher-forced from)
+        parts = n.split(".")
+        if parts[0] == "22":
+            return [f"22.{parts[1]}.{parts[2]}.0"] if parts[3] == "1" else [{"0": "15.cv2", "1": "18.cv2", "2": "21.cv2"}[parts[2]]]
+        if len(parts) == 4:    # X.m.j.cvK
+            j = int(parts[2])
+            return [f"{parts[0]}.m.{j}.cv1"] if parts[3] == "cv2" else ([f"{parts[0]}.cv1"] if j == 0 else [f"{parts[0]}.m.{j - 1}.cv2"])
+        if parts[1] == "cv2":
+            return [f"{parts[0]}.cv1"] + [m for m in all_names if m.startswith(parts[0] + ".m.") and m.endswith(".cv2")] if parts[0] != "9" else ["9.cv1"]
+        return [str(int(parts[0]) - 1)]      # X.cv1 of the backbone C2f / SPPF modules asked for here: fed by conv X - 1
+    want = {n for n in want if all(q in stored for q in producers(n))}
+    assert {"2.cv2", "6.cv2", "8.cv2", "9.cv2"} <= want and sum(n.startswith("22.") for n in want) >= 6, sorted(want)
+    taps = {}
+    Y.forward(x, w, "m", taps=taps, force=stored, only=want)
+    for n in sorted(want):
+        tol = 2e-3 * np.abs(taps[n]).max() + 2e-3
+        err = float(np.abs(taps[n] - stored[n]).max())
+        assert err <= tol, f"m @ 1280 layer {n}: max err {err:.4g} > tol {tol:.4g}; launches: {launch_list(det)}"
     # decode + NMS on the engine's own tensors: exact
     maps, off = [], 0
     for s_ in (160, 80, 40):
