@@ -1219,7 +1219,7 @@ const char *tile_name(int tile) {
                                             "k64:128x128s2/8w", "k64:128x128s3/8w", "k64:256x128s2/8w", "k64:128x64s3/8w", "k64:256x64s2/8w",
                                             "rows:128x64/8w", "rows:256x64/8w", "rows64:128x128/8w", "rows64:256x64/8w",
                                             "ws:128x128", "ws:128x64", "pt:128x128s2", "pt:128x128s3", "pt:128x64s3", "pt:128x64s2",
-                                            "k64:256x128s3/8w", "k64:256x256s2/8w", "rows-pt:256x64", "rows-pt:128x64", "rows64-pt:256x64", "k64:256x128s3/16w", "pt:256x128s3/16w", "k64pf:128x128s2", "k64pf:256x128s3/8w", "pp:256x128", "pp:256x64", "pp:256x192", "ppt:256x128", "ppt:256x64"};
+                                            "k64:256x128s3/8w", "k64:256x256s2/8w", "rows-pt:256x64", "rows-pt:128x64", "rows64-pt:256x64", "k64:256x128s3/16w", "pt:256x128s3/16w", "k64pf:128x128s2", "k64pf:256x128s3/8w", "pp:256x128", "pp:256x64", "pp:256x192", "ppt:256x128", "ppt:256x64", "pp:512x64"};
     return tile >= 0 && tile < TILE_COUNT ? names[tile] : "?";
 }
 
@@ -1238,7 +1238,7 @@ bool tile_is_tail(int tile) { return tile >= TILE_TAIL_128x64 && tile <= TILE_TA
 // the 64-deep tile kernels (conv_mfma64_body) know how to read channels [0, lo_c) from a half-resolution tensor
 bool tile_reads_lo(int tile) { return (tile >= TILE_K64_128x128_S2 && tile <= TILE_K64_128x128_S2W) || tile_is_w8(tile) || tile_is_pt(tile) || tile_is_pf(tile) || tile_is_ppt(tile); }
 bool tile_is_rows(int tile) { return (tile >= TILE_ROWS_128x64 && tile <= TILE_ROWS_K64_256x64) || (tile >= TILE_ROWS_128x64_W8 && tile <= TILE_ROWS_K64_256x64_W8) || tile_is_rows_pt(tile) || tile_is_pp(tile); }
-bool tile_is_pp(int tile) { return tile == TILE_PP_256x128 || tile == TILE_PP_256x64 || tile == TILE_PP_256x192; }
+bool tile_is_pp(int tile) { return tile == TILE_PP_256x128 || tile == TILE_PP_256x64 || tile == TILE_PP_256x192 || tile == TILE_PP_512x64; }
 bool tile_is_ppt(int tile) { return tile == TILE_PPT_256x128 || tile == TILE_PPT_256x64; }
 bool tile_is_rows_pt(int tile) { return tile >= TILE_ROWS_PT_256x64 && tile <= TILE_ROWS_PT_K64_256x64; }
 
@@ -1296,6 +1296,7 @@ TileShape tile_shape(int tile) {
         case TILE_PP_256x192: return {256, 192};
         case TILE_PPT_256x128: return {256, 128};
         case TILE_PPT_256x64: return {256, 64};
+        case TILE_PP_512x64: return {512, 64};
     }
     return {0, 0};
 }
@@ -1619,6 +1620,7 @@ int launch_conv_group(const ConvLaunch *c, int n, int tile, hipStream_t s) {
         case TILE_PP_256x128: RT_TRY(launch_conv3x3_pp(a, n, 128, s)); break;
         case TILE_PP_256x64: RT_TRY(launch_conv3x3_pp(a, n, 64, s)); break;
         case TILE_PP_256x192: RT_TRY(launch_conv3x3_pp(a, n, 192, s)); break;
+        case TILE_PP_512x64: RT_TRY(launch_conv3x3_pp(a, n, 576, s)); break;
         case TILE_PPT_256x128: RT_CHECK(n == 1, RTMODT_E_INVALID, "launch_conv: the ping-pong tile kernel runs single problems"); RT_TRY(launch_conv_tile_pp(a[0], 128, s)); break;
         case TILE_PPT_256x64: RT_CHECK(n == 1, RTMODT_E_INVALID, "launch_conv: the ping-pong tile kernel runs single problems"); RT_TRY(launch_conv_tile_pp(a[0], 64, s)); break;
         case TILE_WS_128x128: RT_TRY(launch_ws<128>(l, s)); break;

@@ -41,17 +41,25 @@ namespace rtmodt {
 // The DMA schedule of a super-step (issue lists per phase, counted waits): pp_issue / pp_wait_count in tile_math.h, replayed on the host by
 // tests/native/tile_math_check.cpp.
 
-template <int BN>
+// WIDE (the 64-cout layers: C2f bottlenecks at 80 x 80, Detect's box branch): 512 positions x 64 couts per workgroup instead of 256 x BN -- with
+// 64 couts a 256-position tile gives a wave 64 x 32 outputs and a half 256 clk of MFMA per phase, against ~470 clk of reads + DMA issue; here every
+// wave keeps its 64 x 64 outputs (waves 2 wm + wn: positions 256 wn + 64 wm, all 64 couts) and the halves their 512-clk phase, for 8 KiB of weights
+// and 22 KiB of strip per phase.
+template <int BN, bool WIDE = false>
 struct PpCfg {
-    static constexpr int BM = 256, NW = 8;
-    static constexpr int NAP = BM / 8 + 1;          // strip pieces of 8 rows x 128 B: 264 rows >= 256 + 2
+    static constexpr int BM = WIDE ? 512 : 256, NW = 8;
+    static constexpr int NAP = BM / 8 + 1;          // strip pieces of 8 rows x 128 B: BM + 8 rows >= BM + 2
     static constexpr int ASLOT = NAP * 1024;
     static constexpr int NBP = BN / 8;              // weight pieces per tap
     static constexpr int BSLOT = NBP * 1024;
     static constexpr int B_OFF = 2 * ASLOT;
     static constexpr int LDS_BYTES = B_OFF + 3 * BSLOT;
     static constexpr int LB = NBP / NW;             // weight pieces per wave and tap
-    static constexpr int TM = 4, TN = BN / 32;      // a wave owns 64 pixels x BN / 2 couts
+    static constexpr int TM = 4, TN = WIDE ? BN / 16 : BN / 32;      // a wave owns 64 pixels x BN / 2 couts (WIDE: x all BN couts)
+    static constexpr int HB = WIDE ? BN : BN / 2;   // couts per wave
+    static constexpr int LA0 = WIDE ? 4 : 2, LA1 = WIDE ? 4 : 2;      // strip pieces a wave issues in phases kw 0 / kw 1 (wave 0: one more in kw 0, piece NAP - 1)
+    static_assert(NW * (LA0 + LA1) + 1 == NAP, "strip pieces");
+    static_assert(!WIDE || BN == 64, "the wide form is for 64 couts");
     static_assert(NBP % NW == 0, "weight pieces must split evenly over the waves");
     static_assert(LDS_BYTES <= 160 * 1024, "LDS");
 };
@@ -110,10 +118,10 @@ static bool pp_out_fits(const ConvArgs &a) {
 template <int N>
 __device__ __forceinline__ void pp_wait() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int BN>
+template <int BN, bool WIDE>
 __global__ __launch_bounds__(512) void conv3x3_pp(ConvGroupArgs g, int total_ids, const int *sched, int sched_T) {
-    using C = PpCfg<BN>;
-    constexpr int BM = C::BM, NW = C::NW, LB = C::LB, TM = C::TM, TN = C::TN;
+    using C = PpCfg<BN, WIDE>;
+    constexpr int BM = C::BM, NW = C::NW, LB = C::LB, TM = C::TM, TN = C::TN, LA0 = C::LA0, LA1 = C::LA1, XP = LA0 + LA1;      // XP: index of wave 0's extra piece
     constexpr bool BIAS_AHEAD = BN <= 128;
     __shared__ __attribute__((aligned(1024))) unsigned char lds[C::LDS_BYTES];
 
@@ -121,7 +129,8 @@ __global__ __launch_bounds__(512) void conv3x3_pp(ConvGroupArgs g, int total_ids
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r = lane & 15, q = lane >> 4;
     const int half = wave >> 2;                       // 0: waves 0-3, 1: waves 4-7 (one of each per SIMD)
-    const int wm = wave >> 1, wn = wave & 1;          // 4 x 2 waves over 256 pixels x BN couts; half h owns pixel rows [128 h, 128 h + 128)
+    const int row0 = WIDE ? (wave & 1) * 256 + (wave >> 1) * 64 : (wave >> 1) * 64;      // first position of this wave's 64 inside the tile (half h = waves 4 h .. 4 h + 3)
+    const int col0 = WIDE ? 0 : (wave & 1) * (BN / 2);                                   // first cout of this wave inside the tile
     const bool w0 = wave == 0;
 
     // LDS images: rows of 128 B (64 halves = 8 chunks of 16 B), chunk c of row R in slot (c + 2 (R >> 1)) & 7 -- a rotation that keeps
@@ -131,9 +140,9 @@ __global__ __launch_bounds__(512) void conv3x3_pp(ConvGroupArgs g, int total_ids
 #pragma unroll
     for (int kw = 0; kw < 3; ++kw)
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) a_rd[kw][kk] = wm * 64 * 128 + (r + kw) * 128 + slot_of(r + kw, kk * 4 + q);
+        for (int kk = 0; kk < 2; ++kk) a_rd[kw][kk] = row0 * 128 + (r + kw) * 128 + slot_of(r + kw, kk * 4 + q);
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk) b_rd[kk] = C::B_OFF + wn * (BN / 2) * 128 + r * 128 + slot_of(r, kk * 4 + q);
+    for (int kk = 0; kk < 2; ++kk) b_rd[kk] = C::B_OFF + col0 * 128 + r * 128 + slot_of(r, kk * 4 + q);
     const int ld_row = lane >> 3, ld_slot = lane & 7;
     const int ld_chunk = ((ld_slot - 2 * (ld_row >> 1)) & 7) * 8;      // halves: the k-chunk whose slot this DMA lane fills (piece bases are multiples of 8 rows)
 
@@ -148,7 +157,7 @@ __global__ __launch_bounds__(512) void conv3x3_pp(ConvGroupArgs g, int total_ids
     };                                                // (wave-uniform values only: two of these live in SGPRs)
     // per lane, bytes, of the tile the DMA stream is feeding: its row of strip piece wave + 8 i (i = 4: piece 32, wave 0 only); its row of weight piece
     // `wave`.  Worked out when the stream moves on to a tile (lane_offsets), not kept per located tile: the 192-wide tile has no registers for a second set.
-    unsigned ia_off[5], ib_off;
+    unsigned ia_off[XP + 1], ib_off;
     const int G = gridDim.x;
     auto locate = [&](int id, Tile &t) -> bool {      // launch-linear id -> (problem, tile); false for the alignment fillers between problems
         int z = 0;
@@ -171,7 +180,7 @@ __global__ __launch_bounds__(512) void conv3x3_pp(ConvGroupArgs g, int total_ids
         // right border column for kh = 0, 1 and on the last (zero) pixel for kh = 2; no enumerated position of a real image reaches that far
         const int clamp = p.last_pos - 2 * p.in_Wp;
 #pragma unroll
-        for (int i = 0; i < 5; ++i) ia_off[i] = (unsigned)(min(rows_pos(p, t.m0 + (wave + NW * i) * 8 + ld_row), clamp) * p.in_cs + ld_chunk) * 2u;
+        for (int i = 0; i <= XP; ++i) ia_off[i] = (unsigned)(min(rows_pos(p, t.m0 + (wave + NW * i) * 8 + ld_row), clamp) * p.in_cs + ld_chunk) * 2u;
         ib_off = (unsigned)((t.n0 + wave * 8 + ld_row) * p.kp + ld_chunk) * 2u;
     };
     // the j-th tile of this workgroup: from the launch's schedule (pp_lpt_schedule, read through the SCALAR cache: a vector load would sit in the vmcnt
@@ -214,13 +223,15 @@ __global__ __launch_bounds__(512) void conv3x3_pp(ConvGroupArgs g, int total_ids
     // bias of the first tile: requested BEFORE the first DMA piece (older than all of them)
     floatx4 bnext[TN];
 #pragma unroll
-    for (int u = 0; u < TN; ++u) bnext[u] = *(const floatx4 *)(g.p[cur.z].bias + cur.n0 + (wn * TN + u) * 16 + q * 4);
+    for (int u = 0; u < TN; ++u) bnext[u] = *(const floatx4 *)(g.p[cur.z].bias + cur.n0 + col0 + u * 16 + q * 4);
 
     // ---- pipeline fill, in the order the steady state would have issued it: strip 0 (first part), tap 0, strip 0 (rest), tap 1 ----
-    issue_A(cur, 0, 0, 0, 0); issue_A(cur, 0, 0, 0, 1);
-    if (w0) issue_A(cur, 0, 0, 0, 4);
+#pragma unroll
+    for (int i = 0; i < LA0; ++i) issue_A(cur, 0, 0, 0, i);
+    if (w0) issue_A(cur, 0, 0, 0, XP);
     issue_B(cur, 0, 0, 0, 0);
-    issue_A(cur, 0, 0, 0, 2); issue_A(cur, 0, 0, 0, 3);
+#pragma unroll
+    for (int i = LA0; i < XP; ++i) issue_A(cur, 0, 0, 0, i);
     issue_B(cur, 0, 1, 0, 1);
     STAMP(0);
     pp_wait<LB>();                                    // everything but tap 1
@@ -238,7 +249,7 @@ __global__ __launch_bounds__(512) void conv3x3_pp(ConvGroupArgs g, int total_ids
         if constexpr (!BIAS_AHEAD) {                  // (the 192-wide tile has no registers to carry the next tile's bias through the k-loop)
             if (tile_no > 0) {
 #pragma unroll
-                for (int u = 0; u < TN; ++u) bnext[u] = *(const floatx4 *)(p.bias + cur.n0 + (wn * TN + u) * 16 + q * 4);
+                for (int u = 0; u < TN; ++u) bnext[u] = *(const floatx4 *)(p.bias + cur.n0 + col0 + u * 16 + q * 4);
             }
         }
 #pragma unroll
@@ -264,9 +275,17 @@ __global__ __launch_bounds__(512) void conv3x3_pp(ConvGroupArgs g, int total_ids
                 if (kw == 0) {
                     issue_B(iss, kh, 2, c0, 2);
                     if (last && have_next) { iss = nxt; lane_offsets(nxt); }        // from here on the stream feeds the next tile
-                    if (valid) { issue_A(iss, nkh, nc0, aslot ^ 1, 0); issue_A(iss, nkh, nc0, aslot ^ 1, 1); if (w0) issue_A(iss, nkh, nc0, aslot ^ 1, 4); }
+                    if (valid) {
+#pragma unroll
+                        for (int i = 0; i < LA0; ++i) issue_A(iss, nkh, nc0, aslot ^ 1, i);
+                        if (w0) issue_A(iss, nkh, nc0, aslot ^ 1, XP);
+                    }
                 } else if (kw == 1) {
-                    if (valid) { issue_B(iss, nkh, 0, nc0, 0); issue_A(iss, nkh, nc0, aslot ^ 1, 2); issue_A(iss, nkh, nc0, aslot ^ 1, 3); }
+                    if (valid) {
+                        issue_B(iss, nkh, 0, nc0, 0);
+#pragma unroll
+                        for (int i = LA0; i < XP; ++i) issue_A(iss, nkh, nc0, aslot ^ 1, i);
+                    }
                 } else {
                     if (valid) issue_B(iss, nkh, 1, nc0, 1);
                 }
@@ -281,9 +300,9 @@ __global__ __launch_bounds__(512) void conv3x3_pp(ConvGroupArgs g, int total_ids
                 }
                 FSTAMP(2);
                 if (!valid) pp_wait<0>();             // the stream ends here: drain (once per workgroup)
-                else if (kw == 0) { if (w0) pp_wait<pp_wait_count(0, LB, true)>(); else pp_wait<pp_wait_count(0, LB, false)>(); }
-                else if (kw == 1) { if (w0) pp_wait<pp_wait_count(1, LB, true)>(); else pp_wait<pp_wait_count(1, LB, false)>(); }
-                else pp_wait<pp_wait_count(2, LB, false)>();
+                else if (kw == 0) { if (w0) pp_wait<pp_wait_count(0, LB, true, LA0, LA1)>(); else pp_wait<pp_wait_count(0, LB, false, LA0, LA1)>(); }
+                else if (kw == 1) { if (w0) pp_wait<pp_wait_count(1, LB, true, LA0, LA1)>(); else pp_wait<pp_wait_count(1, LB, false, LA0, LA1)>(); }
+                else pp_wait<pp_wait_count(2, LB, false, LA0, LA1)>();
                 FSTAMP(3);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the fragments are in registers: the slots may be refilled behind the barrier
                 __builtin_amdgcn_s_barrier();
@@ -315,7 +334,7 @@ __global__ __launch_bounds__(512) void conv3x3_pp(ConvGroupArgs g, int total_ids
             asm volatile("" : "+v"(nz), "+v"(nn0));
             nz = __builtin_amdgcn_readfirstlane(nz); nn0 = __builtin_amdgcn_readfirstlane(nn0);
 #pragma unroll
-            for (int u = 0; u < TN; ++u) bnext[u] = *(const floatx4 *)(g.p[nz].bias + nn0 + (wn * TN + u) * 16 + q * 4);
+            for (int u = 0; u < TN; ++u) bnext[u] = *(const floatx4 *)(g.p[nz].bias + nn0 + col0 + u * 16 + q * 4);
         }
         // Stores in the accumulator layout are 8 bytes per lane in 32-byte runs of 16 different cache lines per instruction (9 500 clk per tile,
         // 19 000 with the residual read the same way: profiles/r04/pp/run1_stamp.txt).  Each wave therefore turns its 64 x BN/2 outputs round by
@@ -329,7 +348,7 @@ __global__ __launch_bounds__(512) void conv3x3_pp(ConvGroupArgs g, int total_ids
             constexpr int ablate = 0;
 #endif
             unsigned char *stg = lds + (aslot ^ 1) * C::ASLOT + wave * 4096;
-            constexpr int HB = BN / 2, CPR = HB / 8;                     // couts of this wave; 16-byte fp16 chunks per pixel
+            constexpr int HB = C::HB, CPR = HB / 8;                      // couts of this wave; 16-byte fp16 chunks per pixel
             // the problem's scalars, fetched in ONE batch here: read where they are used (inside the lanes' branches) hipcc fetches them from the kernel
             // argument segment again for every store, a scalar-memory round trip each -- 5 800 of the 8 000 clk this epilogue took (profiles/r04/pp/run5.txt)
             f16 *const e_out = p.out; const f16 *const e_res = p.res;
@@ -361,7 +380,7 @@ __global__ __launch_bounds__(512) void conv3x3_pp(ConvGroupArgs g, int total_ids
                         const int e = i * 64 + lane, pl = e / CPR, c = e - pl * CPR;
                         const half8 v = *(const half8 *)(stg + pl * RS + ((c ^ (pl & (CH - 1))) << 4));
                         int opix, rpix;
-                        const bool ok = po.index(cur.m0 + (wm * TM + t0) * 16 + pl, cur.n0 + wn * HB + c * 8, opix, rpix) & !(ablate & 2);
+                        const bool ok = po.index(cur.m0 + row0 + t0 * 16 + pl, cur.n0 + col0 + c * 8, opix, rpix) & !(ablate & 2);
                         if (ok) *(half8 *)(e_out + opix) = v;
                     }
                 }
@@ -376,7 +395,7 @@ __global__ __launch_bounds__(512) void conv3x3_pp(ConvGroupArgs g, int total_ids
                     for (int i = 0; i < NI; ++i) {
                         const int e = i * 64 + lane, pl = e / CPR, c = e - pl * CPR;
                         int rpix;
-                        okx[i] = po.index(cur.m0 + (wm * TM + t0) * 16 + pl, cur.n0 + wn * HB + c * 8, opx[i], rpix);
+                        okx[i] = po.index(cur.m0 + row0 + t0 * 16 + pl, cur.n0 + col0 + c * 8, opx[i], rpix);
                         rvx[i] = *(const half8 *)(e_res + (okx[i] ? rpix : 0));
                     }
                 };
@@ -628,9 +647,9 @@ __global__ __launch_bounds__(512) void conv_tile_pp(ConvArgs p, int n_tiles) {
 }
 
 // ---- host side ----
-template <int BN>
+template <int BN, bool WIDE = false>
 static int launch_pp_bn(const ConvArgs *a, int n, hipStream_t s) {
-    using C = PpCfg<BN>;
+    using C = PpCfg<BN, WIDE>;
     ConvGroupArgs g;
     g.n = n; g.start[0] = 0;
     for (int i = 0; i < n; ++i) {
@@ -656,7 +675,7 @@ static int launch_pp_bn(const ConvArgs *a, int n, hipStream_t s) {
     if (n > 1 && total > G && G <= 1024) {
         int dev = 0;
         RT_HIP(hipGetDevice(&dev));
-        std::string key = std::to_string(dev) + ":" + std::to_string(BN) + ":" + std::to_string(G);
+        std::string key = std::to_string(dev) + ":" + std::to_string(BN) + (WIDE ? "w:" : ":") + std::to_string(G);
         for (int i = 0; i < n; ++i) key += ":" + std::to_string(g.gx[i] * cdiv(a[i].cout, BN)) + "x" + std::to_string(a[i].cin);
         static std::mutex mu;
         static std::map<std::string, std::pair<int *, int>> plans;
@@ -669,7 +688,7 @@ static int launch_pp_bn(const ConvArgs *a, int n, hipStream_t s) {
                 int tiles[MAX_GROUP]; long cost[MAX_GROUP];
                 for (int i = 0; i < n; ++i) {
                     tiles[i] = g.gx[i] * cdiv(a[i].cout, BN);
-                    cost[i] = (long)(9 * (a[i].cin / 64)) * (BN == 64 ? 1000 : (BN == 128 ? 1250 : 1750)) + (BN == 64 ? 3500 : (BN == 128 ? 5500 : 8000));      // phases x clk per phase + epilogue
+                    cost[i] = (long)(9 * (a[i].cin / 64)) * (BN == 64 && !WIDE ? 1000 : (BN <= 128 ? 1250 : 1750)) + (BN == 64 && !WIDE ? 3500 : (BN <= 128 ? 5000 : 8000));      // phases x clk per phase + epilogue
                 }
                 const int max_T = total / (G >= 8 ? 8 : 1) + 1;      // a whole XCD share on one workgroup at worst
                 std::vector<int> wide((size_t)G * max_T);
@@ -688,7 +707,7 @@ static int launch_pp_bn(const ConvArgs *a, int n, hipStream_t s) {
         }
         if (it != plans.end()) { sched = it->second.first; sched_T = it->second.second; }
     }
-    hipLaunchKernelGGL((conv3x3_pp<BN>), dim3(G), dim3(512), 0, s, g, total, sched, sched_T);
+    hipLaunchKernelGGL((conv3x3_pp<BN, WIDE>), dim3(G), dim3(512), 0, s, g, total, sched, sched_T);
     return RTMODT_OK;
 }
 
@@ -730,13 +749,14 @@ int launch_conv3x3_pp(const ConvArgs *a, int n, int bn, hipStream_t s) {
         // 16-byte stores (and residual loads): channel offsets and pixel strides in multiples of 8 halves
         RT_CHECK(a[i].cout % 8 == 0 && (uintptr_t)a[i].out % 16 == 0 && a[i].out_cs % 8 == 0 && (!a[i].res || ((uintptr_t)a[i].res % 16 == 0 && a[i].res_cs % 8 == 0)),
                  RTMODT_E_INVALID, "launch_conv: the ping-pong tile stores 16 bytes per lane (cout, channel offsets and strides %% 8 == 0)");
-        RT_CHECK(!a[i].res || bn <= 128, RTMODT_E_INVALID, "launch_conv: the 192-wide ping-pong tile takes no residual");
+        RT_CHECK(!a[i].res || bn <= 128 || bn == 576, RTMODT_E_INVALID, "launch_conv: the 192-wide ping-pong tile takes no residual");
         RT_CHECK(pp_out_fits(a[i]), RTMODT_E_INVALID, "launch_conv: the ping-pong tile indexes its output with 24-bit multiplies (padded H x W x C of a tensor < 2^24)");
     }
     switch (bn) {
         case 128: return launch_pp_bn<128>(a, n, s);
         case 64: return launch_pp_bn<64>(a, n, s);
         case 192: return launch_pp_bn<192>(a, n, s);
+        case 512 + 64: return launch_pp_bn<64, true>(a, n, s);      // (bn 576 = the wide form: 512 positions x 64 couts)
         default: return fail(RTMODT_E_INVALID, "launch_conv: ping-pong tile with BN %d", bn);
     }
 }

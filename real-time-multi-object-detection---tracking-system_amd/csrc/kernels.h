@@ -73,7 +73,8 @@ enum ConvTile {
     TILE_PP_256x128 = 57, TILE_PP_256x64 = 58, TILE_PP_256x192 = 59,
     // the ping-pong schedule without tap reuse (1x1, 3x3 stride 2): one conv per launch, cin % 64 == 0, K >= 192
     TILE_PPT_256x128 = 60, TILE_PPT_256x64 = 61,
-    TILE_COUNT = 62
+    TILE_PP_512x64 = 62,                            // the 3x3 ping-pong kernel's wide form for 64-cout convs: 512 positions x 64 couts per workgroup
+    TILE_COUNT = 63
 };
 const char *tile_name(int tile);
 bool tile_needs_cin64(int tile);

@@ -121,8 +121,9 @@ inline void bitonic_run(K *keys, int P) {
 //   kw 2 -> A(s+1) and B(s+1, kw 0): only this phase's weight pieces are younger                 N = lb
 // (tests/native/tile_math_check.cpp replays the stream and checks the three counts: never too loose, never tighter than needed)
 struct PpIssue { int nB, nA; };
-RT_HD PpIssue pp_issue(int kw, int lb, bool wave0) { return kw == 0 ? PpIssue{lb, 2 + (wave0 ? 1 : 0)} : (kw == 1 ? PpIssue{lb, 2} : PpIssue{lb, 0}); }
-constexpr int pp_wait_count(int kw, int lb, bool wave0) { return kw == 0 ? lb + 2 + (wave0 ? 1 : 0) : (kw == 1 ? 2 + (wave0 ? 1 : 0) + lb + 2 : lb); }
+// la0 / la1 = strip pieces per wave in kw 0 / kw 1 (2 + 2 for the 256-position tiles, 4 + 4 for the 512-position one)
+RT_HD PpIssue pp_issue(int kw, int lb, bool wave0, int la0 = 2, int la1 = 2) { return kw == 0 ? PpIssue{lb, la0 + (wave0 ? 1 : 0)} : (kw == 1 ? PpIssue{lb, la1} : PpIssue{lb, 0}); }
+constexpr int pp_wait_count(int kw, int lb, bool wave0, int la0 = 2, int la1 = 2) { return kw == 0 ? lb + la0 + (wave0 ? 1 : 0) : (kw == 1 ? la0 + (wave0 ? 1 : 0) + lb + la1 : lb); }
 
 // Which tiles each persistent workgroup of a (grouped) ping-pong launch runs: longest-processing-time-first inside each XCD's share.
 // A launch holds the tiles of up to 6 problems back to back (launch-linear ids, problem z = ids start[z] .. start[z] + tiles[z]), sorted deepest K

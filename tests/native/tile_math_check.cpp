@@ -144,14 +144,15 @@ static int check_nms_math() {
 // 128-byte-row image) are bank-conflict free under ds_read_b128's lane groups.
 static int check_pp_schedule() {
     long cases = 0;
+    for (int la = 2; la <= 4; la += 2)
     for (int lb = 1; lb <= 4; ++lb)
         for (int w0 = 0; w0 < 2; ++w0) {
             std::vector<int> need;                       // need[i] = global phase index (3 s + kw) that first reads piece i; issue order
             const int S = 6;
             // fill: strip 0 (first part), tap 0, strip 0 (rest), tap 1 -- then the fill's wait (all but tap 1)
-            for (int i = 0; i < 2 + w0; ++i) need.push_back(0);
+            for (int i = 0; i < la + w0; ++i) need.push_back(0);
             for (int i = 0; i < lb; ++i) need.push_back(0);
-            for (int i = 0; i < 2; ++i) need.push_back(0);
+            for (int i = 0; i < la; ++i) need.push_back(0);
             for (int i = 0; i < lb; ++i) need.push_back(1);
             auto check_wait = [&](int n_out, int next_phase, const char *where) -> int {
                 const int done = (int)need.size() - n_out;                      // pieces [0, done) have retired
@@ -163,11 +164,11 @@ static int check_pp_schedule() {
             if (check_wait(lb, 0, "fill")) return 1;
             for (int s = 0; s < S; ++s)
                 for (int kw = 0; kw < 3; ++kw) {
-                    const PpIssue is = pp_issue(kw, lb, w0 != 0);
+                    const PpIssue is = pp_issue(kw, lb, w0 != 0, la, la);
                     const int nb_need = kw == 0 ? 3 * s + 2 : (kw == 1 ? 3 * (s + 1) : 3 * (s + 1) + 1);
                     for (int i = 0; i < is.nB; ++i) need.push_back(nb_need);
                     for (int i = 0; i < is.nA; ++i) need.push_back(3 * (s + 1));
-                    if (check_wait(pp_wait_count(kw, lb, w0 != 0), 3 * s + kw + 1, kw == 0 ? "kw 0" : (kw == 1 ? "kw 1" : "kw 2"))) return 1;
+                    if (check_wait(pp_wait_count(kw, lb, w0 != 0, la, la), 3 * s + kw + 1, kw == 0 ? "kw 0" : (kw == 1 ? "kw 1" : "kw 2"))) return 1;
                     ++cases;
                 }
         }
