@@ -1394,11 +1394,12 @@ def test_persistent_tap_reuse_kernel(pkg, wdir, monkeypatch, tile, size, batch, 
 
 
 
-@pytest.mark.parametrize("tile,size,batch,scale", [(57, 320, 32, "s"), (58, 320, 32, "s"), (59, 320, 32, "s"), (57, 288, 3, "s"), (58, 640, 4, "s"), (57, 320, 8, "m"), (58, 320, 5, "n")])
+@pytest.mark.parametrize("tile,size,batch,scale", [(57, 320, 32, "s"), (58, 320, 32, "s"), (59, 320, 32, "s"), (62, 320, 32, "s"), (57, 288, 3, "s"), (58, 640, 4, "s"), (62, 288, 3, "s"), (62, 640, 2, "s"), (57, 320, 8, "m"), (58, 320, 5, "n")])
 def test_ping_pong_3x3_kernel(pkg, wdir, monkeypatch, tile, size, batch, scale):
     """conv3x3_pp (TILE_PP_*, csrc/conv_pp.hip): the 3x3 / stride-1 kernel whose two wave halves run one barrier interval apart, forced onto
     every conv where it is legal -- Bottlenecks with their shortcuts (fp32 staging + 16-byte shortcut reads), the grouped Detect launches (a
-    workgroup walks tiles of several problems; with the balanced schedule of pp_lpt_schedule), the 192-wide form on Detect stage 0 -- at batches
+    workgroup walks tiles of several problems; with the balanced schedule of pp_lpt_schedule), the 192-wide form on Detect stage 0, the 512-position
+    form (tile 62: every wave 64 positions x all 64 couts) -- at batches
     where a workgroup runs several tiles, at 288 x 288 (partial tiles, fewer tiles than workgroups) and on the n / m widths.  Every stored layer
     of the first and the last image against the oracle fed the engine's own inputs."""
     monkeypatch.setenv("RTMODT_BNECK", "0")
