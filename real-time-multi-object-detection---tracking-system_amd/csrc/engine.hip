@@ -168,6 +168,8 @@ struct Op {
 
 using namespace rtmodt;
 
+constexpr int N_EXEC = 4;       // executable instances per captured graph of the plain / chained engines (capture_chain)
+
 struct rtmodt_detector {
     rtmodt_det_cfg cfg{};
     std::string weight_path;
@@ -265,7 +267,7 @@ struct rtmodt_detector {
     int newest = -1, last_fetched = -1;
     uint64_t class_mask[2] = {~0ull, ~0ull};
     // graph
-    std::vector<hipGraph_t> graphs; std::vector<hipGraphExec_t> graph_execs;   // one captured graph per sub-batch chain
+    std::vector<hipGraph_t> graphs; std::vector<hipGraphExec_t> graph_execs;   // one captured graph per sub-batch chain, N_EXEC executable instances of each
     std::vector<hipStream_t> chain_streams;           // [n_chains], chain 0 runs on `stream`
     std::vector<hipEvent_t> chain_fork, chain_join;
     bool want_pred = false;
@@ -1313,9 +1315,12 @@ static int capture_chain(rtmodt_detector *d, int c) {
     hipError_t e = hipStreamEndCapture(main, &d->graphs[c]);
     RT_TRY(rc);
     RT_HIP(e);
-    // two executable instances per graph, used by alternate batches: relaunching ONE instance while
-    // its previous launch is still running makes the runtime wait for it before submitting
-    for (int k = 0; k < 2; ++k) RT_HIP(hipGraphInstantiate(&d->graph_execs[2 * c + k], d->graphs[c], nullptr, nullptr, 0));
+    // N_EXEC executable instances per graph, used round-robin by successive batches, so that an instance is never launched again while an earlier
+    // launch of it can still be running (the caller keeps at most three batches in flight).  Relaunching a running instance makes the runtime wait
+    // for it before submitting -- and under rocprofv3 --kernel-trace it segfaults inside hipGraphLaunch, a race that depends on how far the host runs
+    // ahead: with two alternating instances the 100-step bench crashed at launch ~200-310 three times out of four, with ONE instance every time, and
+    // never with instances that were not in flight (eager launches, the staged engine, re-instantiated executables): profiles/r04/rocprof_plain100/
+    for (int k = 0; k < N_EXEC; ++k) RT_HIP(hipGraphInstantiate(&d->graph_execs[N_EXEC * c + k], d->graphs[c], nullptr, nullptr, 0));
     return RTMODT_OK;
 }
 
@@ -1440,7 +1445,7 @@ static int capture_graph(rtmodt_detector *d) {
     const int C = d->n_chains;
     for (auto g : d->graph_execs) if (g) hipGraphExecDestroy(g);
     for (auto g : d->graphs) if (g) hipGraphDestroy(g);
-    d->graphs.assign(C, nullptr); d->graph_execs.assign(2 * C, nullptr);
+    d->graphs.assign(C, nullptr); d->graph_execs.assign(N_EXEC * C, nullptr);
     RT_TRY(ensure_chain_streams(d));
     bool forks = false;
     for (auto &op : d->ops) forks = forks || op.head_level >= 0;
@@ -1460,7 +1465,17 @@ static int capture_graph(rtmodt_detector *d) {
 
 // stem output -> dense per-anchor candidates of a single-chain detector, on the main stream
 static int forward_graphs(rtmodt_detector *d) {
-    const int inst = getenv("RTMODT_ONE_EXEC") ? 0 : (int)(d->batch_no & 1);   // alternate batches, alternate instances
+    const int inst = getenv("RTMODT_ONE_EXEC") ? 0 : (int)(d->batch_no % N_EXEC);   // successive batches, successive instances
+#ifdef RTMODT_DIAG
+    // diagnostic build (rocprofv3 --kernel-trace segfaults inside hipGraphLaunch on this engine after ~200 launches): which launch
+    // it is, and whether executables that are re-instantiated every N launches get past it (an accumulation per executable in the runtime / profiler)
+    static const int dbg_count = getenv("RTMODT_DEBUG_GRAPH_COUNT") ? 1 : 0, dbg_reinst = getenv("RTMODT_DEBUG_REINST") ? atoi(getenv("RTMODT_DEBUG_REINST")) : 0;
+    if (dbg_count && d->batch_no % 8 == 0) fprintf(stderr, "[graph] launch %lld\n", (long long)d->batch_no);
+    if (dbg_reinst > 0 && d->batch_no > 0 && d->batch_no % dbg_reinst == 0) {
+        RT_HIP(hipStreamSynchronize(d->stream));
+        for (int k = 0; k < N_EXEC; ++k) { RT_HIP(hipGraphExecDestroy(d->graph_execs[k])); RT_HIP(hipGraphInstantiate(&d->graph_execs[k], d->graphs[0], nullptr, nullptr, 0)); }
+    }
+#endif
     RT_HIP(hipGraphLaunch(d->graph_execs[inst], d->stream));
     return run_decode(d);
 }
@@ -1473,7 +1488,7 @@ static int forward_graphs(rtmodt_detector *d) {
 // (needed when the next batch's whole-batch letterbox would overwrite an image tensor a lagging chain still reads).
 static int forward_chains(rtmodt_detector *d, rtmodt_detector::Slot &sl, bool host_frames, bool join_main) {
     const int C = d->n_chains, nb = d->B / C;
-    const int inst = getenv("RTMODT_ONE_EXEC") ? 0 : (int)(d->batch_no & 1);
+    const int inst = getenv("RTMODT_ONE_EXEC") ? 0 : (int)(d->batch_no % N_EXEC);
     for (int c = 0; c < C; ++c) {
         hipStream_t st = d->chain_streams[c];
         if (c > 0) {
@@ -1482,7 +1497,7 @@ static int forward_chains(rtmodt_detector *d, rtmodt_detector::Slot &sl, bool ho
         }
         RT_TRY(run_stem_chain(d, c, d->last_fused, st));
         if (c == 0 && d->last_fused) RT_HIP(hipEventRecord(sl.evp, d->stream));
-        RT_HIP(hipGraphLaunch(d->graph_execs[2 * c + inst], st));
+        RT_HIP(hipGraphLaunch(d->graph_execs[N_EXEC * c + inst], st));
         RT_TRY(run_decode_sub(d, c * nb, nb, st));
         if (c > 0) RT_HIP(hipEventRecord(sl.chain_done[c], st));
     }

@@ -22,13 +22,10 @@ rm -f $O/stats/*/*_kernel_trace.csv
 # the same bench on the PLAIN engine (one stream, one graph): every forward-pass kernel alone on the device, so the per-kernel
 # averages of the trace can be set against the HIP-event times of tools/profile_layers.py and bench.py (in the staged default
 # the kernels of the two stages overlap and each one's duration in the trace includes the time it shared the CUs)
-# (not fatal, and 30 steps: round 3 saw rocprofv3 segfault inside hipGraphLaunch on this one configuration with --steps 100, three times out of three, and
-# pass with --steps 30, also eager and with one graph instance -- tools/ab/r03_rocprof_plain.sh; the staged trace above is the one the bench line is checked against)
-if RTMODT_CHAINS=1 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_chains1 -- $B --steps 30 --warmup 5 > $O/stats_chains1_bench.json 2> $O/stats_chains1.log; then
-    python tools/trace_gaps.py $O/stats_chains1/*/*_kernel_trace.csv 50 > $O/step_gaps_chains1.txt 2>&1
-else
-    echo "[collect] plain-engine kernel trace FAILED (see stats_chains1.log); continuing"
-fi
+# (100 steps again: round 3's segfault inside hipGraphLaunch came from launching a graph executable again while an earlier launch of it was still
+# running, which rocprofv3 --kernel-trace does not survive -- the plain engine now rotates four instances: profiles/r04/rocprof_plain100/)
+RTMODT_CHAINS=1 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_chains1 -- $B --steps 100 --warmup 10 > $O/stats_chains1_bench.json 2> $O/stats_chains1.log || exit 1
+python tools/trace_gaps.py $O/stats_chains1/*/*_kernel_trace.csv 50 > $O/step_gaps_chains1.txt 2>&1
 rm -f $O/stats_chains1/*/*_kernel_trace.csv
 echo "[collect] kernel trace done"
 RTMODT_CHAIN_PROBE=0 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- $B --prewarm 0 --steps 20 --warmup 5 > /dev/null 2> $O/pmc_fetch.log || exit 1
