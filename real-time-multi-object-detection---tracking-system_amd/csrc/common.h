@@ -7,6 +7,8 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
+#include <cstring>
 #include <string>
 
 #include "../../include/rtmodt.h"
@@ -35,6 +37,37 @@ int fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
         int _r = (expr);           \
         if (_r != RTMODT_OK) return _r; \
     } while (0)
+
+// Run-time options.  librtmodt_hip.so reads the RTMODT_<name> variables of this ONE table and no other: each through rt_opt(), at
+// detector-create / autotune time (never per launch; a running detector does not change when the environment does).
+//   engine shape        CHAINS (N sub-batch chains instead of the staged engine), STAGES (1 / 2 / 3), CHAIN_JOIN (chains meet per batch),
+//                       CHAIN_PROBE (0: trust stream creation order -- counter-collecting profilers serialise kernels), ZERO_COPY
+//   tuner               TUNE_CACHE (file), TUNE_LOG (print every timing)
+//   diagnostics         DEBUG (print the device / library banner once)
+//   FORCE hooks of the parity tests (tests/test_gpu_detector.py: every kernel variant is run against the oracle, whatever the tuner
+//   would pick on this box): TILE, TILE_K64, TILE_3X3S1, EPI16, TAIL, BNECK, BNECK_TAIL, UP_READ, STEM_FUSE, NO_HEAD_FINAL,
+//                       NMS_THREADS, PAD_STREAMS
+// The A/B switches of finished experiments (profiles/r0N/README.md has their measurements) exist only in a diagnostic build
+// (`make DIAG=1`, -DRTMODT_DIAG): rt_diag() is a constant nullptr otherwise and the branches behind it fold away.
+static const char *const kOptions[] = {"CHAINS", "STAGES", "CHAIN_JOIN", "CHAIN_PROBE", "ZERO_COPY", "TUNE_CACHE", "TUNE_LOG", "DEBUG",
+                                       "TILE", "TILE_K64", "TILE_3X3S1", "EPI16", "TAIL", "BNECK", "BNECK_TAIL", "UP_READ", "STEM_FUSE",
+                                       "NO_HEAD_FINAL", "NMS_THREADS", "PAD_STREAMS"};
+static inline const char *rt_env(const char *name) {
+    char buf[64];
+    snprintf(buf, sizeof(buf), "RTMODT_%s", name);
+    return getenv(buf);
+}
+static inline const char *rt_opt(const char *name) {
+    for (const char *k : kOptions)
+        if (strcmp(k, name) == 0) return rt_env(name);
+    fprintf(stderr, "rtmodt: option %s is not in common.h's table\n", name);
+    abort();
+}
+#if defined(RTMODT_DIAG)
+static inline const char *rt_diag(const char *name) { return rt_env(name); }
+#else
+static inline const char *rt_diag(const char *) { return nullptr; }
+#endif
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }

@@ -182,7 +182,7 @@ __device__ __forceinline__ void conv_mfma_body(const ConvArgs &p, const int bx, 
 // one barrier per 64 of K.  Chunk c (0..7) of row r sits in slot c ^ ((r>>1)&7): conflict-free
 // ds_read_b128 for both k-substeps.
 // ---------------------------------------------------------------------------------------
-template <int BM, int BN, int WM, int WN, int NSTAGE, int N2T = 0, bool PF = false>
+template <int BM, int BN, int WM, int WN, int NSTAGE, int N2T = 0>
 __device__ __forceinline__ void conv_mfma64_body(const ConvArgs &p, const int bx, const int by) {
     constexpr int NW = WM * WN;                             // waves per workgroup: the DMA path sustains ~5 B/clk PER WAVE (tools/probes/dma_probe),
     static_assert(NW == 4 || NW == 8 || NW == 16, "4, 8 or 16 waves");      // so the big tiles run 8 (16) waves to issue their operands twice (four times) as fast
@@ -259,7 +259,7 @@ __device__ __forceinline__ void conv_mfma64_body(const ConvArgs &p, const int bx
         if (i < nk) issue(i, i);
     int rstage = 0, wstage = DEPTH % NSTAGE;
     STAMP(0);
-    if constexpr (!PF) {
+    {
     for (int kt = 0; kt < nk; ++kt) {
         if (kt == 2) STAMP(10);
         wait_steps<LA + LBp, DEPTH - 1>(min(DEPTH - 1, nk - 1 - kt));
@@ -286,86 +286,6 @@ __device__ __forceinline__ void conv_mfma64_body(const ConvArgs &p, const int bx
                     acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[u], fa[t], acc[t][u], 0, 0, 0);
         }
     }
-    } else {
-        // SOFTWARE-PIPELINED k-loop (the PF tiles; one or two waves per SIMD, so a wave has to hide its own latencies): two fragment
-        // sets.  While the MFMAs of sub-step 0 run, the fragments of sub-step 1 are on their way from LDS; the step's barrier sits
-        // BETWEEN the two MFMA blocks (stage kt + 1 landed, everybody done reading stage kt); behind it the fragments of the NEXT
-        // stage's sub-step 0 are requested and the DMA pieces of stage kt + 1 + DEPTH are issued one by one between the MFMAs of
-        // sub-step 1 (into the slot stage kt just left).  Same ring, same counted waits, same results as the plain loop.
-        constexpr int NPW = LA + LBp, NMF = TM * TN;
-        constexpr bool PF_INTERLEAVE = false;               // true: one DMA piece between every NMF / NPW MFMAs of set 1 (measured: the step gets LONGER, profiles/r03/pf)
-        int p_kt = -1, p_stage = 0, p_tap = 0, p_c0 = 0;
-        bool p_lo = false;
-        auto begin_issue = [&](int kt, int stage) {
-            p_kt = kt; p_stage = stage; p_c0 = c0;
-            p_tap = (kh * p.in_Wp + kw) * p.in_cs + c0;
-            p_lo = p.in2 && c0 < p.split;
-            c0 += 64;
-            if (c0 >= p.cin) { c0 = 0; if (++kw == p.ks) { kw = 0; ++kh; } }
-        };
-        auto issue_piece = [&](int i) {
-            unsigned char *sb = lds + p_stage * STAGE;
-            if (i < LA) {
-                if (p_lo) glds16(p.in2 + (a_lo[i] + p_c0), sb + (wave + NW * i) * 1024);
-                else glds16(p.in + (a_off[i] + p_tap), sb + (wave + NW * i) * 1024);
-            } else {
-                glds16(p.wt + (b_off[i - LA] + p_kt * 64), sb + (NA + wave + NW * (i - LA)) * 1024);
-            }
-        };
-        auto load_frags = [&](const unsigned char *sb, int ro, half8 (&fa)[TM], half8 (&fb)[TN]) {
-#pragma unroll
-            for (int t = 0; t < TM; ++t) fa[t] = *(const half8 *)(sb + (wm * TM + t) * 2048 + ro);
-#pragma unroll
-            for (int u = 0; u < TN; ++u) fb[u] = *(const half8 *)(sb + NA * 1024 + (wn * TN + u) * 2048 + ro);
-        };
-        half8 fa0[TM], fb0[TN], fa1[TM], fb1[TN];
-        wait_steps<NPW, DEPTH - 1>(min(DEPTH - 1, nk - 1));
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        if (DEPTH < nk) issue(DEPTH, wstage);               // the ring's last free slot
-        load_frags(lds, rd_off0, fa0, fb0);
-        for (int kt = 0; kt < nk; ++kt) {
-            if (kt < 5) STAMP(1 + kt);
-            const unsigned char *sbase = lds + rstage * STAGE;
-            __builtin_amdgcn_s_waitcnt(0xC07F);             // lgkmcnt(0): set 0 (requested a whole MFMA block ago) is here -- said with the builtin so that the
-            load_frags(sbase, rd_off1, fa1, fb1);           // compiler's own wait in front of the MFMAs does not also cover the loads of set 1 issued now
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int t = 0; t < TM; ++t)
-#pragma unroll
-                for (int u = 0; u < TN; ++u) acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb0[u], fa0[t], acc[t][u], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            const int nstage = rstage + 1 == NSTAGE ? 0 : rstage + 1;
-            p_kt = -1;
-            __builtin_amdgcn_s_waitcnt(0xC07F);                             // lgkmcnt(0): my reads of stage kt are complete (on both paths: set 1 is then
-            if (kt + 1 < nk) {                                              // known to be there and the MFMAs below do not wait for the next set 0)
-                wait_steps<NPW, DEPTH - 1>(min(DEPTH - 1, nk - 2 - kt));    // my pieces of stage kt + 1 have landed
-                __builtin_amdgcn_s_barrier();
-                asm volatile("" ::: "memory");
-                if (kt + 1 + DEPTH < nk) begin_issue(kt + 1 + DEPTH, rstage);
-                load_frags(lds + nstage * STAGE, rd_off0, fa0, fb0);
-                if (!PF_INTERLEAVE && p_kt >= 0) {
-#pragma unroll
-                    for (int i = 0; i < NPW; ++i) issue_piece(i);              // the step's DMA pieces in one block, as the plain loop issues them
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            int piece = 0;
-#pragma unroll
-            for (int t = 0; t < TM; ++t)
-#pragma unroll
-                for (int u = 0; u < TN; ++u) {
-                    acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb1[u], fa1[t], acc[t][u], 0, 0, 0);
-                    const int done = t * TN + u + 1;
-                    if (PF_INTERLEAVE && piece < NPW && (piece + 1) * NMF <= done * NPW) {
-                        if (p_kt >= 0) issue_piece(piece);
-                        ++piece;
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                }
-            __builtin_amdgcn_sched_barrier(0);
-            rstage = nstage;
-        }
     }
 
     STAMP(6);
@@ -662,166 +582,12 @@ __device__ __forceinline__ void conv_mfma_wsk_body(const ConvArgs &p, const int 
 }
 
 // ---------------------------------------------------------------------------------------
-// conv1x1_ws: WEIGHT-STATIONARY 1x1 convolution.  In the tile kernels above every workgroup streams its BN x K slice of
-// the weights again for every pixel tile -- for the C2f / SPPF 1x1 convs (N = 128..512, K = 256..768) that is HALF of all
-// bytes that cross the global -> LDS path, the path that bounds them.  Here a persistent 8-wave workgroup loads its BN x K
-// weight slice into LDS ONCE (K/64 x BN/8 pieces, resident) and then walks over 128-pixel tiles mt = g, g + G, ..., whose
-// rows arrive through a ring of NSTAGE 16-KiB stages; the (tile, k-step) pairs form ONE stream of steps, so the ring keeps
-// prefetching across tile boundaries and a tile's epilogue (bias, SiLU, stores straight from the accumulators) runs
-// under the next tile's loads.  Same MFMA order per output as conv_mfma64 (k ascending), same swizzled piece layout.
-// ---------------------------------------------------------------------------------------
-template <int BN, int NSTAGE>
-__global__ __launch_bounds__(512) void conv1x1_ws(ConvArgs p, int groups) {
-    // 8 waves (two per SIMD): one wave's LDS-DMA issues and fragment reads run under its partner's MFMAs -- with four waves a
-    // k-step took 2 000 clk for 512 clk of MFMA (phase stamps, tools/probes/kernel_probe.hip)
-    constexpr int BM = 128, NW = 8, WM = 4, WN = 2;
-    constexpr int NA = BM / 8, NB = BN / 8, LA = NA / NW, LBp = NB / NW;
-    constexpr int DEPTH = NSTAGE - 1;
-    constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
-    static_assert(TN % 2 == 0, "the epilogue pairs neighbouring cout tiles");
-    extern __shared__ __attribute__((aligned(1024))) unsigned char ws_lds[];
-    const int nk = p.kp / 64;
-    unsigned char *wbase = ws_lds, *abase = ws_lds + nk * NB * 1024;
-
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int r = lane & 15, q = lane >> 4;
-    const int n0 = blockIdx.y * BN, g = blockIdx.x;
-    const int n_mt = (p.M + BM - 1) / BM;
-    const int n_my = (n_mt - g + groups - 1) / groups;     // pixel tiles g, g + groups, ...
-    const int S = n_my * nk;                                // steps of this workgroup
-    const int ld_row8 = lane >> 3, ld_slot = lane & 7;
-    const int rd_base = (r >> 3) * 1024 + (r & 7) * 128;
-    const int rd_off0 = rd_base + (((0 + q) ^ ((r >> 1) & 7)) << 4);
-    const int rd_off1 = rd_base + (((4 + q) ^ ((r >> 1) & 7)) << 4);
-
-    STAMP(0);
-    // ---- the weight slice: resident ----
-    for (int kt = 0; kt < nk; ++kt)
-#pragma unroll
-        for (int i = 0; i < LBp; ++i) {
-            const int row = (wave + NW * i) * 8 + ld_row8;
-            glds16(p.wt + ((n0 + row) * p.kp + ((ld_slot ^ ((row >> 1) & 7)) << 3) + kt * 64), wbase + (kt * NB + wave + NW * i) * 1024);
-        }
-    // ---- the pixel stream ----
-    int a_off[LA];
-    int is_tile = 0, is_kt = 0, is_stage = 0;                // the next step to issue
-    auto tile_offsets = [&](int ti) {
-        const int m0 = (g + ti * groups) * BM;
-#pragma unroll
-        for (int i = 0; i < LA; ++i) {
-            const int row = (wave + NW * i) * 8 + ld_row8;
-            a_off[i] = input_offset(p, m0 + row) + ((ld_slot ^ ((row >> 1) & 7)) << 3);
-        }
-    };
-    auto issue = [&]() {
-        if (is_kt == 0) tile_offsets(is_tile);
-        unsigned char *sbase = abase + is_stage * (NA * 1024);
-#pragma unroll
-        for (int i = 0; i < LA; ++i) glds16(p.in + (a_off[i] + is_kt * 64), sbase + (wave + NW * i) * 1024);
-        if (++is_kt == nk) { is_kt = 0; ++is_tile; }
-        is_stage = is_stage + 1 == NSTAGE ? 0 : is_stage + 1;
-    };
-    const int wm = wave / WN, wn = wave % WN;
-    // Epilogue layout: a lane holds 4 consecutive couts (8 bytes) of one pixel per accumulator tile.  Neighbouring cout tiles
-    // u, u + 1 are exchanged between the lane pair (q, q ^ 1): the even-q lane ends up with 8 consecutive couts of tile u, the
-    // odd-q lane with 8 of tile u + 1 -- 16-byte stores, 64 contiguous bytes per pixel and instruction, no LDS round trip
-    // (the direct 8-byte stores of the first version took 11 000 clk per 128 x 128 tile).
-    const int qe = q & ~1, odd = q & 1;
-    floatx4 bv[TN];
-#pragma unroll
-    for (int u = 0; u < TN; ++u) bv[u] = *(const floatx4 *)(p.bias + n0 + (wn * TN + u) * 16 + q * 4);
-    floatx4 acc[TM][TN];
-#pragma unroll
-    for (int t = 0; t < TM; ++t)
-#pragma unroll
-        for (int u = 0; u < TN; ++u) acc[t][u] = floatx4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int i = 0; i < DEPTH; ++i)
-        if (i < S) issue();
-    STAMP(1);
-    int kt = 0, tile = 0, rstage = 0;
-    // vmcnt counts the epilogue's global STORES together with the LDS-DMAs, in issue order: for the DEPTH steps after a tile's
-    // epilogue its stores are YOUNGER than the stage being waited for and must be allowed to stay outstanding -- a wait that
-    // ignores them drains the whole ring at every tile boundary.  The count is exact because this kernel only runs shapes whose
-    // every tile is full (M % 128 == 0, cout % BN == 0, no second destination): each of the TM x TN store instructions executes.
-    constexpr int NST = TM * TN / 2;                        // one 16-byte store per pair of cout tiles
-    int store_credit = 0;
-    for (int s = 0; s < S; ++s) {
-        // everything issued before step s's successors has landed: the weights (issued first of all) and stage s
-        const int ahead = min(DEPTH - 1, S - 1 - s);
-        if (store_credit > 0) { wait_steps_plus<LA, DEPTH - 1, NST>(ahead); --store_credit; }
-        else wait_steps<LA, DEPTH - 1>(ahead);
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        if (s == 0) STAMP(2);
-        if (s == 1) STAMP(3);
-        if (s == 2) STAMP(4);
-        if (s == 3) STAMP(5);
-        if (s == 4) STAMP(6);
-        if (s + DEPTH < S) issue();                         // refills the stage read in step s - 1
-        const unsigned char *sA = abase + rstage * (NA * 1024);
-        const unsigned char *sB = wbase + kt * (NB * 1024);
-        rstage = rstage + 1 == NSTAGE ? 0 : rstage + 1;
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            const int ro = kk ? rd_off1 : rd_off0;
-            half8 fa[TM], fb[TN];
-#pragma unroll
-            for (int t = 0; t < TM; ++t) fa[t] = *(const half8 *)(sA + (wm * TM + t) * 2048 + ro);
-#pragma unroll
-            for (int u = 0; u < TN; ++u) fb[u] = *(const half8 *)(sB + (wn * TN + u) * 2048 + ro);
-#pragma unroll
-            for (int t = 0; t < TM; ++t)
-#pragma unroll
-                for (int u = 0; u < TN; ++u) acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[u], fa[t], acc[t][u], 0, 0, 0);
-        }
-        if (++kt == nk) {                                   // the tile is complete: epilogue straight from the accumulators
-            kt = 0;
-            prio_epilogue(p.epi_prio);
-            const int m0 = (g + tile * groups) * BM;
-            ++tile;
-#pragma unroll
-            for (int t = 0; t < TM; ++t) {
-                long opix, rpix, opix2;
-                pixel_offsets(p, m0 + (wm * TM + t) * 16 + r, opix, rpix, opix2);      // (every tile is full: always live)
-#pragma unroll
-                for (int u = 0; u < TN; u += 2) {
-                    floatx4 v0 = acc[t][u] + bv[u], v1 = acc[t][u + 1] + bv[u + 1];
-                    if (p.act) {
-                        v0[0] = silu_f(v0[0]); v0[1] = silu_f(v0[1]); v0[2] = silu_f(v0[2]); v0[3] = silu_f(v0[3]);
-                        v1[0] = silu_f(v1[0]); v1[1] = silu_f(v1[1]); v1[2] = silu_f(v1[2]); v1[3] = silu_f(v1[3]);
-                    }
-                    const half4 h0 = {(f16)v0[0], (f16)v0[1], (f16)v0[2], (f16)v0[3]}, h1 = {(f16)v1[0], (f16)v1[1], (f16)v1[2], (f16)v1[3]};
-                    // the even-q lane keeps tile u and receives its partner's tile u; the odd-q lane keeps tile u + 1
-                    const half4 give = odd ? h0 : h1, keep = odd ? h1 : h0;
-                    u32x2 gw = __builtin_bit_cast(u32x2, give);
-                    gw[0] = (unsigned)__shfl_xor((int)gw[0], 16);
-                    gw[1] = (unsigned)__shfl_xor((int)gw[1], 16);
-                    const half4 got = __builtin_bit_cast(half4, gw);
-                    const half4 lo = odd ? got : keep, hi = odd ? keep : got;
-                    const half8 o = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                    const int n = n0 + (wn * TN + u + odd) * 16 + qe * 4;
-                    store16(p.out, opix + n, o, p.wthru);
-                    acc[t][u] = floatx4{0.f, 0.f, 0.f, 0.f};
-                    acc[t][u + 1] = floatx4{0.f, 0.f, 0.f, 0.f};
-                }
-            }
-            store_credit = DEPTH;
-            prio_main(p.epi_prio);
-            if (tile == 1) STAMP(7);
-        }
-    }
-    STAMP(9);
-}
-
-// ---------------------------------------------------------------------------------------
 // conv_mfma64_pt: PERSISTENT-TILE variant of conv_mfma64_w8 (8 waves, 64-deep k-steps, BM = 128).  A workgroup owns one
 // cout slice and walks over pixel tiles g, g + G, ...; the (tile, k-step) pairs form ONE stream of steps through the
 // stage ring, so the first operands of the next tile are already in flight while this tile's epilogue runs -- in the plain
 // tile kernels every workgroup starts with an empty ring (phase stamps: ~2 600 clk before the first MFMA of a tile, 15-35 %
 // of a workgroup's life on the short-K layers).  The epilogue stores straight from the accumulators (the lane-pair
-// exchange of conv1x1_ws: 16-byte stores, no LDS round trip), so it does not need the stage buffers the prefetch is using.
+// exchange across lane pairs: 16-byte stores, no LDS round trip), so it does not need the stage buffers the prefetch is using.
 // Two stages = 64 KiB at BN = 128: two workgroups per CU, as in the plain kernel.  Runs full tiles only (M % 128 == 0,
 // cout % BN == 0), any kernel size / stride, no residual / second destination / half-resolution source.
 // Same MFMA order per output as conv_mfma64 (k ascending), same swizzled piece layout.
@@ -907,7 +673,7 @@ __global__ __launch_bounds__(NW * 64) void conv_mfma64_pt(ConvArgs p, int groups
         if (i < S) issue();
     STAMP(1);
     int kt = 0, tile = 0, rstage = 0;
-    // vmcnt counts the epilogue's global stores together with the LDS-DMAs, in issue order (see conv1x1_ws): for the DEPTH steps
+    // vmcnt counts the epilogue's global stores together with the LDS-DMAs, in issue order: for the DEPTH steps
     // after a tile's epilogue its stores are younger than the stage being waited for and may stay outstanding
     constexpr int NST = TM * TN / 2;
     int store_credit = 0;
@@ -1167,14 +933,7 @@ __global__ __launch_bounds__(256) void conv_mfma64_tail(ConvArgs p) { conv_mfma6
 template <int BM, int BN, int WM, int WN, int NSTAGE>
 __global__ __launch_bounds__(512) void conv_mfma64_w8(ConvArgs p) { conv_mfma64_body<BM, BN, WM, WN, NSTAGE>(p, blockIdx.x, blockIdx.y); }
 template <int BM, int BN, int WM, int WN, int NSTAGE>
-__global__ __launch_bounds__(1024) void conv_mfma64_w16(ConvArgs p) { conv_mfma64_body<BM, BN, WM, WN, NSTAGE>(p, blockIdx.x, blockIdx.y); }
-template <int BM, int BN, int WM, int WN, int NSTAGE>
 __global__ __launch_bounds__(256) void conv_mfma64(ConvArgs p) { conv_mfma64_body<BM, BN, WM, WN, NSTAGE>(p, blockIdx.x, blockIdx.y); }
-// software-pipelined k-loop (PF tiles): 4 waves, two workgroups per CU; 8 waves, one
-template <int BM, int BN, int WM, int WN, int NSTAGE>
-__global__ __launch_bounds__(256, 2) void conv_mfma64_pf(ConvArgs p) { conv_mfma64_body<BM, BN, WM, WN, NSTAGE, 0, true>(p, blockIdx.x, blockIdx.y); }
-template <int BM, int BN, int WM, int WN, int NSTAGE>
-__global__ __launch_bounds__(512, 2) void conv_mfma64_pf_w8(ConvArgs p) { conv_mfma64_body<BM, BN, WM, WN, NSTAGE, 0, true>(p, blockIdx.x, blockIdx.y); }
 template <int BM, int BN, int WM, int WN, int NSTAGE>
 __global__ __launch_bounds__(256) void conv_mfma64_grp(ConvGroupArgs g) {
     int bx, by;
@@ -1212,35 +971,24 @@ __global__ __launch_bounds__(256) void conv_mfma_wsk_grp(ConvGroupArgs g) {
 
 const char *tile_name(int tile) {
     static const char *names[TILE_COUNT] = {"128x128s3", "128x64s3", "64x64s3", "256x32s3", "64x128s3", "wsk64x64", "wsk32x64", "wsk64x32",
-                                            "128x128s4", "128x64s5", "64x64s6", "64x128s5", "128x128s6",
-                                            "k64:128x128s2", "k64:128x128s3", "k64:128x64s3", "k64:64x128s3", "k64:64x64s3", "k64:64x64s4", "k64:256x64s2", "k64:256x128s2", "k64:128x128s2w",
-                                            "rows:128x64", "rows:256x32", "rows:128x32", "rows64:128x64", "rows64:128x128", "rows64:64x64", "rows64:256x64",
-                                            "tail:128x64", "tail:64x64", "tail:k64:128x128", "tail:k64:64x128",
-                                            "k64:128x128s2/8w", "k64:128x128s3/8w", "k64:256x128s2/8w", "k64:128x64s3/8w", "k64:256x64s2/8w",
-                                            "rows:128x64/8w", "rows:256x64/8w", "rows64:128x128/8w", "rows64:256x64/8w",
-                                            "ws:128x128", "ws:128x64", "pt:128x128s2", "pt:128x128s3", "pt:128x64s3", "pt:128x64s2",
-                                            "k64:256x128s3/8w", "k64:256x256s2/8w", "rows-pt:256x64", "rows-pt:128x64", "rows64-pt:256x64", "k64:256x128s3/16w", "pt:256x128s3/16w", "k64pf:128x128s2", "k64pf:256x128s3/8w", "pp:256x128", "pp:256x64", "pp:256x192", "ppt:256x128", "ppt:256x64", "pp:512x64"};
+                                            "k64:64x64s3", "rows:128x32", "rows64:64x64", "tail:128x64", "tail:k64:128x128",
+                                            "k64:128x128s2/8w", "k64:128x128s3/8w", "k64:128x64s3/8w", "k64:256x64s2/8w", "rows:128x64/8w", "rows:256x64/8w",
+                                            "pt:128x128s2", "pt:128x64s2", "rows-pt:256x64", "pp:256x128", "pp:256x64", "pp:256x192", "pp:512x64", "ppt:256x128"};
     return tile >= 0 && tile < TILE_COUNT ? names[tile] : "?";
 }
 
+bool tile_is_w8(int tile) { return tile >= TILE_K64_128x128_S2_W8 && tile <= TILE_K64_256x64_S2_W8; }
+bool tile_is_pt(int tile) { return tile == TILE_PT_128x128_S2 || tile == TILE_PT_128x64_S2; }
+bool tile_is_tail(int tile) { return tile == TILE_TAIL_128x64 || tile == TILE_TAIL_K64_128x128; }
+bool tile_is_rows_pt(int tile) { return tile == TILE_ROWS_PT_256x64; }
+bool tile_is_pp(int tile) { return tile >= TILE_PP_256x128 && tile <= TILE_PP_512x64; }
+bool tile_is_ppt(int tile) { return tile == TILE_PPT_256x128; }
+bool tile_is_rows(int tile) { return tile == TILE_ROWS_128x32 || tile == TILE_ROWS_K64_64x64 || tile == TILE_ROWS_128x64_W8 || tile == TILE_ROWS_256x64_W8 || tile_is_rows_pt(tile) || tile_is_pp(tile); }
 bool tile_needs_cin64(int tile) {
-    return (tile >= TILE_K64_128x128_S2 && tile <= TILE_K64_128x128_S2W) || (tile >= TILE_ROWS_K64_128x64 && tile <= TILE_ROWS_K64_256x64) ||
-           tile == TILE_TAIL_K64_128x128 || tile == TILE_TAIL_K64_64x128 || (tile >= TILE_K64_128x128_S2_W8 && tile <= TILE_K64_256x64_S2_W8) ||
-           tile == TILE_ROWS_K64_128x128_W8 || tile == TILE_ROWS_K64_256x64_W8 || tile == TILE_ROWS_PT_K64_256x64 || tile_is_pp(tile) || tile_is_ppt(tile) || tile_is_ws(tile) || tile_is_pt(tile) || tile_is_w8(tile) || tile_is_pf(tile);
+    return tile == TILE_K64_64x64_S3 || tile == TILE_ROWS_K64_64x64 || tile == TILE_TAIL_K64_128x128 || tile_is_w8(tile) || tile_is_pt(tile) || tile_is_pp(tile) || tile_is_ppt(tile);
 }
-bool tile_is_w8(int tile) { return (tile >= TILE_K64_128x128_S2_W8 && tile <= TILE_K64_256x64_S2_W8) || tile == TILE_K64_256x128_S3_W8 || tile == TILE_K64_256x256_S2_W8 || tile == TILE_K64_256x128_S3_W16; }
-bool tile_is_ws(int tile) { return tile == TILE_WS_128x128 || tile == TILE_WS_128x64; }
-bool tile_is_pf(int tile) { return tile == TILE_K64_PF_128x128_S2 || tile == TILE_K64_PF_256x128_S3_W8; }
-bool tile_is_pt(int tile) { return (tile >= TILE_PT_128x128_S2 && tile <= TILE_PT_128x64_S2) || tile == TILE_PT_256x128_S3_W16; }
-// resident weight slice (kp/64 x BN/8 KiB) + the pixel ring (3 x 16 KiB) within 156 KiB of LDS
-bool tile_ws_fits(int tile, int kp) { return tile_is_ws(tile) && (kp / 64) * (tile_shape(tile).bn / 8) + 3 * 16 <= 156; }
-bool tile_is_tail(int tile) { return tile >= TILE_TAIL_128x64 && tile <= TILE_TAIL_K64_64x128; }
-// the 64-deep tile kernels (conv_mfma64_body) know how to read channels [0, lo_c) from a half-resolution tensor
-bool tile_reads_lo(int tile) { return (tile >= TILE_K64_128x128_S2 && tile <= TILE_K64_128x128_S2W) || tile_is_w8(tile) || tile_is_pt(tile) || tile_is_pf(tile) || tile_is_ppt(tile); }
-bool tile_is_rows(int tile) { return (tile >= TILE_ROWS_128x64 && tile <= TILE_ROWS_K64_256x64) || (tile >= TILE_ROWS_128x64_W8 && tile <= TILE_ROWS_K64_256x64_W8) || tile_is_rows_pt(tile) || tile_is_pp(tile); }
-bool tile_is_pp(int tile) { return tile == TILE_PP_256x128 || tile == TILE_PP_256x64 || tile == TILE_PP_256x192 || tile == TILE_PP_512x64; }
-bool tile_is_ppt(int tile) { return tile == TILE_PPT_256x128 || tile == TILE_PPT_256x64; }
-bool tile_is_rows_pt(int tile) { return tile >= TILE_ROWS_PT_256x64 && tile <= TILE_ROWS_PT_K64_256x64; }
+// the 64-deep tile kernels (conv_mfma64_body, its persistent form, conv_tile_pp) know how to read channels [0, lo_c) from a half-resolution tensor
+bool tile_reads_lo(int tile) { return tile == TILE_K64_64x64_S3 || tile_is_w8(tile) || tile_is_pt(tile) || tile_is_ppt(tile); }
 
 TileShape tile_shape(int tile) {
     switch (tile) {
@@ -1252,53 +1000,38 @@ TileShape tile_shape(int tile) {
         case TILE_WSK_64x64: return {64, 64};
         case TILE_WSK_32x64: return {32, 64};
         case TILE_WSK_64x32: return {64, 32};
-        case TILE_128x128_S4: case TILE_128x128_S6: return {128, 128};
-        case TILE_128x64_S5: return {128, 64};
-        case TILE_64x64_S6: return {64, 64};
-        case TILE_64x128_S5: return {64, 128};
-        case TILE_K64_128x128_S2: case TILE_K64_128x128_S3: return {128, 128};
-        case TILE_K64_128x64_S3: return {128, 64};
-        case TILE_K64_64x128_S3: return {64, 128};
-        case TILE_K64_64x64_S3: case TILE_K64_64x64_S4: return {64, 64};
-        case TILE_K64_256x64_S2: return {256, 64};
-        case TILE_K64_256x128_S2: return {256, 128};
-        case TILE_K64_128x128_S2W: return {128, 128};
-        case TILE_ROWS_128x64: case TILE_ROWS_K64_128x64: return {128, 64};
-        case TILE_ROWS_256x32: return {256, 32};
+        case TILE_K64_64x64_S3: return {64, 64};
         case TILE_ROWS_128x32: return {128, 32};
-        case TILE_ROWS_K64_128x128: return {128, 128};
         case TILE_ROWS_K64_64x64: return {64, 64};
-        case TILE_ROWS_K64_256x64: return {256, 64};
         case TILE_TAIL_128x64: return {128, 64};
-        case TILE_TAIL_64x64: return {64, 64};
         case TILE_TAIL_K64_128x128: return {128, 128};
-        case TILE_TAIL_K64_64x128: return {64, 128};
         case TILE_K64_128x128_S2_W8: case TILE_K64_128x128_S3_W8: return {128, 128};
-        case TILE_K64_256x128_S2_W8: return {256, 128};
         case TILE_K64_128x64_S3_W8: return {128, 64};
         case TILE_K64_256x64_S2_W8: return {256, 64};
         case TILE_ROWS_128x64_W8: return {128, 64};
-        case TILE_ROWS_256x64_W8: case TILE_ROWS_K64_256x64_W8: return {256, 64};
-        case TILE_ROWS_K64_128x128_W8: return {128, 128};
-        case TILE_WS_128x128: return {128, 128};
-        case TILE_WS_128x64: return {128, 64};
-        case TILE_PT_128x128_S2: case TILE_PT_128x128_S3: return {128, 128};
-        case TILE_PT_128x64_S3: case TILE_PT_128x64_S2: return {128, 64};
-        case TILE_K64_256x128_S3_W8: return {256, 128};
-        case TILE_K64_PF_128x128_S2: return {128, 128};
-        case TILE_K64_PF_256x128_S3_W8: return {256, 128};
-        case TILE_K64_256x256_S2_W8: return {256, 256};
-        case TILE_K64_256x128_S3_W16: case TILE_PT_256x128_S3_W16: return {256, 128};
-        case TILE_ROWS_PT_256x64: case TILE_ROWS_PT_K64_256x64: return {256, 64};
-        case TILE_ROWS_PT_128x64: return {128, 64};
+        case TILE_ROWS_256x64_W8: return {256, 64};
+        case TILE_PT_128x128_S2: return {128, 128};
+        case TILE_PT_128x64_S2: return {128, 64};
+        case TILE_ROWS_PT_256x64: return {256, 64};
         case TILE_PP_256x128: return {256, 128};
         case TILE_PP_256x64: return {256, 64};
         case TILE_PP_256x192: return {256, 192};
-        case TILE_PPT_256x128: return {256, 128};
-        case TILE_PPT_256x64: return {256, 64};
         case TILE_PP_512x64: return {512, 64};
+        case TILE_PPT_256x128: return {256, 128};
     }
     return {0, 0};
+}
+
+// compute units of the current device (the persistent kernels size their grids by it), looked up once per device
+static int device_cus() {
+    static int cus[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (!cus[dev]) {
+        hipDeviceProp_t prop;
+        cus[dev] = hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    return cus[dev];
 }
 
 struct LaunchPlan {
@@ -1361,7 +1094,7 @@ static void launch_rows_pt(const LaunchPlan &l, hipStream_t s) {
     const dim3 all = l.group(g, BM, BN);                   // launch-linear ids of every problem's tiles (with the alignment fillers)
     constexpr int stage_kib = (BM / (K64 ? 8 : 16) + 1 + 3 * (BN / (K64 ? 8 : 16)));
     const int per_cu = std::max(1, std::min(2, 160 / (2 * stage_kib)));
-    int G = std::min((int)all.x, per_cu * 256);
+    int G = std::min((int)all.x, per_cu * device_cus());
     if (G >= 8) G &= ~7;                                   // a workgroup's ids keep their residue mod 8: one XCD's share of the tile order
     hipLaunchKernelGGL((conv3x3_rows_stream<BM, BN, WM, WN, K64>), dim3(G), dim3(512), 0, s, g, (int)all.x);
 }
@@ -1373,48 +1106,6 @@ static int launch_k64_w8(const LaunchPlan &l, hipStream_t s) {
     return RTMODT_OK;
 }
 
-template <int BM, int BN, int WM, int WN, int NSTAGE, int NT>
-static int launch_k64_pf(const LaunchPlan &l, hipStream_t s) {
-    RT_CHECK(l.n == 1, RTMODT_E_INVALID, "launch_conv: the software-pipelined tiles run single problems");
-    if constexpr (NT == 256) hipLaunchKernelGGL((conv_mfma64_pf<BM, BN, WM, WN, NSTAGE>), l.grid(BM, BN), dim3(256), 0, s, l.a[0]);
-    else hipLaunchKernelGGL((conv_mfma64_pf_w8<BM, BN, WM, WN, NSTAGE>), l.grid(BM, BN), dim3(512), 0, s, l.a[0]);
-    return RTMODT_OK;
-}
-
-template <int BN, int NSTAGE>
-static int launch_ws_n(const ConvArgs &a, int smem, hipStream_t s) {
-    const int slices = cdiv(a.cout, BN), n_mt = cdiv(a.M, 128);
-    const int groups = std::max(1, std::min(n_mt, 256 / slices));      // one persistent workgroup per CU
-    static bool attr[64] = {};
-    int dev = 0;
-    RT_HIP(hipGetDevice(&dev));
-    if (dev >= 0 && dev < 64 && !attr[dev]) {
-        RT_HIP(hipFuncSetAttribute((const void *)conv1x1_ws<BN, NSTAGE>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
-        attr[dev] = true;
-    }
-    hipLaunchKernelGGL((conv1x1_ws<BN, NSTAGE>), dim3(groups, slices), dim3(512), smem, s, a, groups);
-    return RTMODT_OK;
-}
-template <int BN>
-static int launch_ws(const LaunchPlan &l, hipStream_t s) {
-    const ConvArgs &a = l.a[0];
-    RT_CHECK(l.n == 1 && a.ks == 1 && a.stride == 1 && !a.in2 && a.cin % 64 == 0 && a.kp % 64 == 0 && a.M % 128 == 0 && a.cout % BN == 0 && !a.out2 && !a.res && a.epi16,
-             RTMODT_E_INVALID, "launch_conv: the weight-stationary tile runs one 1x1 stride-1 conv with cin %% 64 == 0, full tiles (M %% 128 == 0, cout %% BN == 0), "
-             "no half-resolution source, residual or second destination");
-    const int nk = a.kp / 64, wkib = nk * (BN / 8);
-    RT_CHECK(wkib + 3 * 16 <= 156, RTMODT_E_INVALID, "launch_conv: weight slice %d x %d does not fit LDS", BN, a.kp);
-    // the pixel ring takes what the weight slice leaves: the bytes in flight towards LDS are what sets the rate
-    int nst = std::min(6, (156 - wkib) / 16);
-    if (const char *e = getenv("RTMODT_WS_STAGES")) nst = std::max(3, std::min(nst, atoi(e)));
-    const int smem = (wkib + nst * 16) * 1024;
-    switch (nst) {
-        case 3: return launch_ws_n<BN, 3>(a, smem, s);
-        case 4: return launch_ws_n<BN, 4>(a, smem, s);
-        case 5: return launch_ws_n<BN, 5>(a, smem, s);
-        default: return launch_ws_n<BN, 6>(a, smem, s);
-    }
-}
-
 template <int BN, int NSTAGE, int BM = 128, int NW = 8>
 static int launch_pt(const LaunchPlan &l, hipStream_t s) {
     const ConvArgs &a = l.a[0];
@@ -1422,10 +1113,8 @@ static int launch_pt(const LaunchPlan &l, hipStream_t s) {
              RTMODT_E_INVALID, "launch_conv: the persistent tile runs one conv with cin %% 64 == 0, full tiles (M %% %d == 0, cout %% BN == 0), no second destination", BM);
     const int slices = a.cout / BN, n_mt = a.M / BM;
     constexpr int per_cu_lds = (160 * 1024) / (NSTAGE * (BM / 8 + BN / 8) * 1024);      // workgroups of this kernel that fit one CU's LDS
-    // experiment hook (RTMODT_PT_PER_CU=1): one persistent workgroup per CU leaves the CU's other slot to the launches of the other stages
-    static const int per_cu_env = getenv("RTMODT_PT_PER_CU") ? atoi(getenv("RTMODT_PT_PER_CU")) : 0;
-    const int per_cu = per_cu_env > 0 ? std::min(per_cu_env, per_cu_lds) : per_cu_lds;
-    const int groups = std::max(1, std::min(n_mt, per_cu * 256 / slices));
+    const int per_cu = per_cu_lds;
+    const int groups = std::max(1, std::min(n_mt, per_cu * device_cus() / slices));
     hipLaunchKernelGGL((conv_mfma64_pt<BN, NSTAGE, BM, NW>), dim3(groups, slices), dim3(NW * 64), 0, s, a, groups);
     return RTMODT_OK;
 }
@@ -1509,12 +1198,9 @@ static int make_args(const ConvLaunch &c, ConvArgs &a) {
     a.t_wt = c.tail_wt; a.t_bias = c.tail_bias; a.t_out = c.tail_wt ? c.tail_out.base + c.tail_out.coff : nullptr;
     a.t_cout = c.tail_cout; a.t_kp = c.tail_kp; a.t_act = c.tail_act;
     a.t_out_Hp = c.tail_out.H + 2 * c.tail_out.pad; a.t_out_Wp = c.tail_out.padded_w(); a.t_out_cs = c.tail_out.C; a.t_out_pad = c.tail_out.pad;
-    a.t_gap = c.tail_gap;
-    RT_CHECK(c.tail_gap == 0 || (c.tail_wt && c.tail_cout == 128 && c.tail_gap % 8 == 0), RTMODT_E_INVALID, "launch_conv: tail_gap needs a 128-wide tail");
-    RT_CHECK(!c.in.wp || (!c.res.base && !c.out2.base && !c.in_lo.base), RTMODT_E_INVALID, "launch_conv: a pixel-pair view takes no residual / second destination / half-resolution source");
-    static const int wt_env = getenv("RTMODT_WT") ? atoi(getenv("RTMODT_WT")) : 0;
+    static const int wt_env = rt_diag("WT") ? atoi(rt_diag("WT")) : 0;
     a.wthru = wt_env;
-    static const int prio_env = getenv("RTMODT_EPI_PRIO") ? atoi(getenv("RTMODT_EPI_PRIO")) : 0;      // experiment hook
+    static const int prio_env = rt_diag("EPI_PRIO") ? atoi(rt_diag("EPI_PRIO")) : 0;      // experiment hook
     a.epi_prio = prio_env;
     a.epi16 = c.out.coff % 8 == 0 && c.out.C % 8 == 0 && (!c.out2.base || (c.out2.coff % 8 == 0 && c.out2.C % 8 == 0)) &&
               (!c.res.base || (c.res.coff % 4 == 0)) ? c.epilogue : 0;
@@ -1576,64 +1262,25 @@ int launch_conv_group(const ConvLaunch *c, int n, int tile, hipStream_t s) {
         case TILE_WSK_64x64: launch_wsk<64, 64>(l, s); break;
         case TILE_WSK_32x64: launch_wsk<32, 64>(l, s); break;
         case TILE_WSK_64x32: launch_wsk<64, 32>(l, s); break;
-        case TILE_128x128_S4: launch_tile<128, 128, 2, 2, 4>(l, s); break;
-        case TILE_128x64_S5: launch_tile<128, 64, 2, 2, 5>(l, s); break;
-        case TILE_64x64_S6: launch_tile<64, 64, 2, 2, 6>(l, s); break;
-        case TILE_64x128_S5: launch_tile<64, 128, 1, 4, 5>(l, s); break;
-        case TILE_128x128_S6: launch_tile<128, 128, 2, 2, 6>(l, s); break;
-        case TILE_K64_128x128_S2: launch_k64<128, 128, 2, 2, 2>(l, s); break;
-        case TILE_K64_128x128_S3: launch_k64<128, 128, 2, 2, 3>(l, s); break;
-        case TILE_K64_128x64_S3: launch_k64<128, 64, 2, 2, 3>(l, s); break;
-        case TILE_K64_64x128_S3: launch_k64<64, 128, 1, 4, 3>(l, s); break;
         case TILE_K64_64x64_S3: launch_k64<64, 64, 2, 2, 3>(l, s); break;
-        case TILE_K64_64x64_S4: launch_k64<64, 64, 2, 2, 4>(l, s); break;
-        case TILE_K64_256x64_S2: launch_k64<256, 64, 4, 1, 2>(l, s); break;
-        case TILE_K64_256x128_S2: launch_k64<256, 128, 2, 2, 2>(l, s); break;
-        case TILE_K64_128x128_S2W: launch_k64<128, 128, 4, 1, 2>(l, s); break;
-        case TILE_ROWS_128x64: launch_rows<128, 64, 2, 2, false>(l, s); break;
-        case TILE_ROWS_256x32: launch_rows<256, 32, 4, 1, false>(l, s); break;
         case TILE_ROWS_128x32: launch_rows<128, 32, 4, 1, false>(l, s); break;
-        case TILE_ROWS_K64_128x64: launch_rows<128, 64, 2, 2, true>(l, s); break;
-        case TILE_ROWS_K64_128x128: launch_rows<128, 128, 2, 2, true>(l, s); break;
         case TILE_ROWS_K64_64x64: launch_rows<64, 64, 2, 2, true>(l, s); break;
-        case TILE_ROWS_K64_256x64: launch_rows<256, 64, 4, 1, true>(l, s); break;
         case TILE_ROWS_128x64_W8: launch_rows_w8<128, 64, 4, 2, false>(l, s); break;
         case TILE_ROWS_256x64_W8: launch_rows_w8<256, 64, 4, 2, false>(l, s); break;
-        case TILE_ROWS_K64_128x128_W8: launch_rows_w8<128, 128, 4, 2, true>(l, s); break;
-        case TILE_ROWS_K64_256x64_W8: launch_rows_w8<256, 64, 4, 2, true>(l, s); break;
         case TILE_K64_128x128_S2_W8: RT_TRY((launch_k64_w8<128, 128, 4, 2, 2>(l, s))); break;
         case TILE_K64_128x128_S3_W8: RT_TRY((launch_k64_w8<128, 128, 4, 2, 3>(l, s))); break;
-        case TILE_K64_256x128_S2_W8: RT_TRY((launch_k64_w8<256, 128, 4, 2, 2>(l, s))); break;
         case TILE_K64_128x64_S3_W8: RT_TRY((launch_k64_w8<128, 64, 4, 2, 3>(l, s))); break;
         case TILE_K64_256x64_S2_W8: RT_TRY((launch_k64_w8<256, 64, 8, 1, 2>(l, s))); break;
         case TILE_ROWS_PT_256x64: launch_rows_pt<256, 64, 4, 2, false>(l, s); break;
-        case TILE_ROWS_PT_128x64: launch_rows_pt<128, 64, 4, 2, false>(l, s); break;
-        case TILE_ROWS_PT_K64_256x64: launch_rows_pt<256, 64, 4, 2, true>(l, s); break;
-        case TILE_K64_256x128_S3_W8: RT_TRY((launch_k64_w8<256, 128, 4, 2, 3>(l, s))); break;
-        case TILE_K64_PF_128x128_S2: RT_TRY((launch_k64_pf<128, 128, 2, 2, 2, 256>(l, s))); break;
-        case TILE_K64_PF_256x128_S3_W8: RT_TRY((launch_k64_pf<256, 128, 4, 2, 3, 512>(l, s))); break;
-        case TILE_K64_256x256_S2_W8: RT_TRY((launch_k64_w8<256, 256, 4, 2, 2>(l, s))); break;
-        case TILE_K64_256x128_S3_W16:
-            RT_CHECK(l.n == 1, RTMODT_E_INVALID, "launch_conv: the 16-wave tiles run single problems");
-            hipLaunchKernelGGL((conv_mfma64_w16<256, 128, 8, 2, 3>), l.grid(256, 128), dim3(1024), 0, s, l.a[0]);
-            break;
         case TILE_PP_256x128: RT_TRY(launch_conv3x3_pp(a, n, 128, s)); break;
         case TILE_PP_256x64: RT_TRY(launch_conv3x3_pp(a, n, 64, s)); break;
         case TILE_PP_256x192: RT_TRY(launch_conv3x3_pp(a, n, 192, s)); break;
         case TILE_PP_512x64: RT_TRY(launch_conv3x3_pp(a, n, 576, s)); break;
         case TILE_PPT_256x128: RT_CHECK(n == 1, RTMODT_E_INVALID, "launch_conv: the ping-pong tile kernel runs single problems"); RT_TRY(launch_conv_tile_pp(a[0], 128, s)); break;
-        case TILE_PPT_256x64: RT_CHECK(n == 1, RTMODT_E_INVALID, "launch_conv: the ping-pong tile kernel runs single problems"); RT_TRY(launch_conv_tile_pp(a[0], 64, s)); break;
-        case TILE_WS_128x128: RT_TRY(launch_ws<128>(l, s)); break;
-        case TILE_WS_128x64: RT_TRY(launch_ws<64>(l, s)); break;
         case TILE_PT_128x128_S2: RT_TRY((launch_pt<128, 2>(l, s))); break;
-        case TILE_PT_128x128_S3: RT_TRY((launch_pt<128, 3>(l, s))); break;
-        case TILE_PT_128x64_S3: RT_TRY((launch_pt<64, 3>(l, s))); break;
         case TILE_PT_128x64_S2: RT_TRY((launch_pt<64, 2>(l, s))); break;
-        case TILE_PT_256x128_S3_W16: RT_TRY((launch_pt<128, 3, 256, 16>(l, s))); break;
         case TILE_TAIL_128x64: hipLaunchKernelGGL((conv_mfma_tail<128, 64, 2, 2, 3, 4>), l.grid(128, 64), dim3(256), 0, s, a[0]); break;
-        case TILE_TAIL_64x64: hipLaunchKernelGGL((conv_mfma_tail<64, 64, 2, 2, 3, 4>), l.grid(64, 64), dim3(256), 0, s, a[0]); break;
         case TILE_TAIL_K64_128x128: hipLaunchKernelGGL((conv_mfma64_tail<128, 128, 4, 1, 2, 8>), l.grid(128, 128), dim3(256), 0, s, a[0]); break;
-        case TILE_TAIL_K64_64x128: hipLaunchKernelGGL((conv_mfma64_tail<64, 128, 1, 4, 3, 8>), l.grid(64, 128), dim3(256), 0, s, a[0]); break;
         default: return fail(RTMODT_E_INVALID, "launch_conv: tile %d", tile);
     }
     RT_HIP(hipGetLastError());

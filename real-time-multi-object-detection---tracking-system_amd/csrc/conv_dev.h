@@ -34,7 +34,6 @@ struct ConvArgs {
     // tail's output is stored (the tile kernels with BN == cout, TAIL instantiations)
     const f16 *t_wt; const float *t_bias; f16 *t_out;
     int t_cout, t_kp, t_act, t_out_Hp, t_out_Wp, t_out_cs, t_out_pad;
-    int t_gap;                           // pair form: elements between the end of channel 63 and channel 64 of a tail output row (0 otherwise)
     int epi16;                           // epilogue through LDS with 16-byte NHWC stores (all channel offsets / strides % 8 == 0):
                                          // 1 = tile kernels, 2 = also the tap-reuse kernel
     int epi_prio;                        // experiment hook RTMODT_EPI_PRIO: 1 = a wave raises its issue priority for its epilogue, 2 = lowers it (main loops at 1)
@@ -320,7 +319,7 @@ __device__ __forceinline__ void epilogue_tail(const ConvArgs &p, const floatx4 (
         if (n >= p.t_cout) continue;
         long opix;
         if (!pix(pm, opix)) continue;
-        store16(p.t_out, opix + n + (n >> 6) * p.t_gap, *(const half8 *)(lds + pm * ROWB2 + k8 * 16), p.wthru);
+        store16(p.t_out, opix + n, *(const half8 *)(lds + pm * ROWB2 + k8 * 16), p.wthru);
     }
 }
 

@@ -558,7 +558,6 @@ __global__ __launch_bounds__(512) void conv_tile_pp(ConvArgs p, int n_tiles) {
     pp_wait<L>();                                    // phase 0 has landed, phase 1 may be in flight
     __builtin_amdgcn_s_barrier();
     int rslot = 0;
-    int tile_no = 0;
 
     while (true) {
         floatx4 acc[TM][TN];
@@ -635,7 +634,6 @@ __global__ __launch_bounds__(512) void conv_tile_pp(ConvArgs p, int n_tiles) {
                 }
             }
         }
-        ++tile_no;
         if (!have_next) break;
         __builtin_amdgcn_s_barrier();                 // every wave is done with its staging area
         cur_m0 = nxt_m0; cur_n0 = nxt_n0;

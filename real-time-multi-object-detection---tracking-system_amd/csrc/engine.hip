@@ -34,7 +34,7 @@ static void segv_trace(int sig) {
 }
 static void install_debug_handlers() {
     static bool done = false;
-    if (done || !getenv("RTMODT_DEBUG")) return;
+    if (done || !rt_opt("DEBUG")) return;
     done = true;
     signal(SIGSEGV, segv_trace);
     signal(SIGABRT, segv_trace);
@@ -161,7 +161,6 @@ struct Op {
     // fused launch faster, `tail_on` runs it with `tail_tile` and the 1x1's own op is skipped
     bool tail_on = false, skip = false;
     int tail_tile = TILE_TAIL_128x64;
-    bool in_first = false;           // layer "1" when it runs inside the net's first launch (stem_l1.hip), together with its 1x1 tail if tail_on
 };
 
 }  // namespace rtmodt
@@ -211,9 +210,7 @@ struct rtmodt_detector {
     std::map<std::string, TensorView> layer_out;     // fused conv name -> output view
     std::vector<void *> dev_allocs;                   // weights etc.
     int img_t = -1;
-    // stem + layer 1 (+ 2.cv1) as ONE launch (stem_l1.hip): index of layer "1" in the op lists when the shapes allow it, and
-    // whether the tuner (or RTMODT_STEM_L1) switched it on
-    int l1_idx = -1; bool sl1_on = false;
+    NmsPlan nms_plan;                                 // resolved at create time
     f16 *d_zeros = nullptr;                           // 256 zero bytes (DMA source for out-of-tensor halo pixels)
     int head_t[3] = {-1, -1, -1};
     // Detect's last 1x1 convs + decode as ONE launch (postprocess.hip: head_final); `stage2_op` = index of the grouped
@@ -366,12 +363,12 @@ static void set_chains(rtmodt_detector *d, int chains) {
 }
 
 static int pick_tile(int M, int cout) {
-    if (const char *e = getenv("RTMODT_TILE")) {
+    if (const char *e = rt_opt("TILE")) {
         int t = atoi(e);
         if (t >= 0 && t < TILE_COUNT) return t;
     }
-    static const float eff[TILE_COUNT] = {1.0f, 0.85f, 0.62f, 0.75f, 0.85f, 0.5f, 0.4f, 0.4f, 1.05f, 0.9f, 0.65f, 0.9f, 1.0f};      // the rest (0): only reachable through the autotuner
-    static const int occ[TILE_COUNT] = {3, 5, 8, 4, 5, 2, 3, 3, 2, 2, 3, 2, 1};
+    static const float eff[TILE_COUNT] = {1.0f, 0.85f, 0.62f, 0.75f, 0.85f, 0.5f, 0.4f, 0.4f};      // the rest (0): only reachable through the autotuner
+    static const int occ[TILE_COUNT] = {3, 5, 8, 4, 5, 2, 3, 3};
     int best = 0;
     double best_cost = 1e30;
     for (int t = 0; t < TILE_COUNT; ++t) {
@@ -427,17 +424,16 @@ static int make_conv(rtmodt_detector *d, WeightFile &wf, const std::vector<std::
     c.in = in; c.out = out; if (res) c.res = *res;
     c.wt = (const f16 *)dw; c.bias = (const float *)db;
     c.B = d->B; c.cin = r0.cin; c.cout = cout_eff; c.ks = r0.k; c.stride = r0.stride; c.act = r0.act; c.kp = kp;
-    if (const char *e = getenv("RTMODT_EPI16")) c.epilogue = atoi(e);      // A/B and test hook
+    if (const char *e = rt_opt("EPI16")) c.epilogue = atoi(e);      // A/B and test hook
     int M = d->B * out.H * out.W;
     c.tile = pick_tile(M, cout_eff);
-    if (const char *e = getenv("RTMODT_TILE_K64")) {            // test hook: a 64-deep tile (incl. the 8-wave ones) wherever it is legal
+    if (const char *e = rt_opt("TILE_K64")) {            // test hook: a 64-deep tile (incl. the 8-wave ones) wherever it is legal
         const int t = atoi(e);
         if (t >= 0 && t < TILE_COUNT && tile_needs_cin64(t) && !tile_is_rows(t) && !tile_is_tail(t) && c.cin % 64 == 0 && kp % 64 == 0 && !dst &&
-            (!tile_is_ws(t) || (c.ks == 1 && c.stride == 1 && tile_ws_fits(t, kp) && ((long)d->B * out.H * out.W) % 128 == 0 && cout_eff % tile_shape(t).bn == 0 && !res && out.coff % 8 == 0 && out.C % 8 == 0)) &&
             (!tile_is_pt(t) || (((long)d->B * out.H * out.W) % tile_shape(t).bm == 0 && cout_eff % tile_shape(t).bn == 0 && out.coff % 8 == 0 && out.C % 8 == 0)) &&
             (tile_shape(t).bn <= 128 || cout_eff % tile_shape(t).bn == 0) && (!tile_is_ppt(t) || tile_legal(&c, 1, t))) c.tile = t;
     }
-    if (const char *e = getenv("RTMODT_TILE_3X3S1")) {          // test hook: force a tap-reuse tile wherever it is legal
+    if (const char *e = rt_opt("TILE_3X3S1")) {          // test hook: force a tap-reuse tile wherever it is legal
         int t = atoi(e);
         if (t >= 0 && t < TILE_COUNT && tile_is_rows(t) && c.ks == 3 && c.stride == 1 && c.in.pad == 1 &&
             c.cin % (tile_needs_cin64(t) ? 64 : 32) == 0 && (!tile_is_pp(t) || tile_legal(&c, 1, t)))
@@ -476,7 +472,7 @@ static int build_graph(rtmodt_detector *d, WeightFile &wf) {
             int tmp = T(in.H, in.W, c, 1);
             std::string m = i + ".m." + std::to_string(j);
             TensorView r = V(cat, (1 + j) * c, c);
-            static const bool no_fuse = getenv("RTMODT_NO_BNECK_FUSE") != nullptr;
+            static const bool no_fuse = rt_diag("NO_BNECK_FUSE") != nullptr;
             if (bottleneck_supported(c) && !no_fuse && rc == RTMODT_OK) {
                 std::vector<Op> pair;
                 rc = make_conv(d, wf, {m + ".cv1"}, m + ".cv1", V(cat, (1 + j) * c, c), V(tmp), nullptr, 0, &pair);
@@ -489,7 +485,7 @@ static int build_graph(rtmodt_detector *d, WeightFile &wf) {
                 b.in = V(cat, (1 + j) * c, c); b.out = V(cat, (2 + j) * c, c); if (shortcut) b.res = r;
                 b.w1 = pair[0].conv.wt; b.b1 = pair[0].conv.bias; b.w2 = pair[1].conv.wt; b.b2 = pair[1].conv.bias;
                 b.zeros = d->d_zeros; b.B = d->B; b.c = c; b.kp = pair[0].conv.kp;
-                if (const char *e = getenv("RTMODT_BNECK")) op.fused = atoi(e) != 0;
+                if (const char *e = rt_opt("BNECK")) op.fused = atoi(e) != 0;
                 d->ops.push_back(op);
                 continue;
             }
@@ -499,13 +495,13 @@ static int build_graph(rtmodt_detector *d, WeightFile &wf) {
         conv(i + ".cv2", V(cat, 0, (2 + n) * c), out);
         // C2f with ONE Bottleneck of 32 / 64 channels run as a fused launch: cv2 can ride along as its tail (bottleneck.hip),
         // reading the two earlier chunks from the concat tensor and this Bottleneck's output from LDS
-        if (rc == RTMODT_OK && n == 1 && (c == 32 || c == 64) && d->ops.size() >= 2 && !getenv("RTMODT_NO_BNECK_TAIL")) {
+        if (rc == RTMODT_OK && n == 1 && (c == 32 || c == 64) && d->ops.size() >= 2 && !rt_diag("NO_BNECK_TAIL")) {
             Op &bn = d->ops[d->ops.size() - 2], &cv = d->ops.back();
             if (bn.kind == OP_BNECK && cv.kind == OP_CONV && cv.conv.cout == 2 * c && cv.conv.kp == 3 * c && !cv.conv.res.base && cv.conv.out.coff % 8 == 0 &&
                 cv.conv.out.C % 8 == 0) {
                 bn.bneck.tail_in = V(cat, 0, 2 * c); bn.bneck.tail_out = cv.conv.out; bn.bneck.tail_wt = cv.conv.wt; bn.bneck.tail_bias = cv.conv.bias;
                 bn.bneck.tail_cout = cv.conv.cout; bn.bneck.tail_kp = cv.conv.kp; bn.bneck.tail_act = cv.conv.act;
-                if (const char *e = getenv("RTMODT_BNECK_TAIL")) { bn.tail_on = atoi(e) != 0; cv.skip = bn.tail_on && bn.fused; }   // test hook (no autotune)
+                if (const char *e = rt_opt("BNECK_TAIL")) { bn.tail_on = atoi(e) != 0; cv.skip = bn.tail_on && bn.fused; }   // test hook (no autotune)
             }
         }
     };
@@ -565,23 +561,23 @@ static int build_graph(rtmodt_detector *d, WeightFile &wf) {
     }
     TensorView out9 = V(cat20, c4, c5);
     conv("9.cv2", V(cat9), out9);
-    const bool fold_up = getenv("RTMODT_NO_UPFOLD") == nullptr;   // A/B switch: separate upsample2 launches instead
+    const bool fold_up = rt_diag("NO_UPFOLD") == nullptr;   // A/B switch: separate upsample2 launches instead
     // a conv that also writes the nearest-2x copy cannot run as the tail of the Bottleneck before it
     auto fold_into_last = [&](const TensorView &up) {
         d->ops.back().conv.out2 = up;
-        if (tile_is_ws(d->ops.back().conv.tile) || tile_is_pt(d->ops.back().conv.tile) || tile_is_ppt(d->ops.back().conv.tile)) d->ops.back().conv.tile = TILE_K64_128x128_S2;      // (test hook's forced tile: no second destination there)
+        if (tile_is_pt(d->ops.back().conv.tile) || tile_is_ppt(d->ops.back().conv.tile)) d->ops.back().conv.tile = TILE_K64_128x128_S2_W8;      // (test hook's forced tile: no second destination there)
         d->ops.back().skip = false;
         if (d->ops.size() >= 2) { Op &bn = d->ops[d->ops.size() - 2]; if (bn.kind == OP_BNECK) { bn.bneck.tail_wt = nullptr; bn.tail_on = false; } }
     };
     // Upsample + Concat of the neck (layers 10/11 and 13/14), cheapest first: (a) the consumer C2f.cv1 -- a 1x1 -- reads the
     // upsampled channels straight from the half-resolution tensor (no copy exists at all), (b) the producer's epilogue also
     // writes the nearest-2x copy into the concat slice, (c) separate upsample launches (RTMODT_NO_UPFOLD)
-    const bool read_lo = fold_up && !(getenv("RTMODT_UP_READ") && atoi(getenv("RTMODT_UP_READ")) == 0);
+    const bool read_lo = fold_up && !(rt_opt("UP_READ") && atoi(rt_opt("UP_READ")) == 0);
     auto read_from_lo = [&](const std::string &cv1, const TensorView &lo, int lo_c) -> bool {
         for (auto &op : d->ops)
             if (op.kind == OP_CONV && op.name == cv1 && lo_c % 64 == 0 && op.conv.cin % 64 == 0 && op.conv.kp % 64 == 0 && op.conv.ks == 1) {
                 op.conv.in_lo = lo; op.conv.lo_c = lo_c;
-                if (!tile_reads_lo(op.conv.tile)) op.conv.tile = TILE_K64_128x64_S3;
+                if (!tile_reads_lo(op.conv.tile)) op.conv.tile = TILE_K64_128x64_S3_W8;
                 return true;
             }
         return false;
@@ -608,7 +604,7 @@ static int build_graph(rtmodt_detector *d, WeightFile &wf) {
     RT_TRY(rc);
     // conv -> C2f.cv1 pairs of the backbone ("1" -> "2.cv1", "3" -> "4.cv1"): the conv's output tensor has no other
     // reader, so the 1x1 can run as a tail of the conv's launch (conv.hip: epilogue_tail) and the tensor never exists
-    if (!getenv("RTMODT_NO_TAIL"))
+    if (!rt_diag("NO_TAIL"))
         for (size_t i = 0; i + 1 < d->ops.size(); ++i) {
             Op &a = d->ops[i], &b = d->ops[i + 1];
             if (a.kind != OP_CONV || b.kind != OP_CONV || b.conv.ks != 1 || b.conv.stride != 1 || a.conv.res.base || a.conv.out2.base || b.conv.res.base || b.conv.out2.base) continue;
@@ -619,92 +615,11 @@ static int build_graph(rtmodt_detector *d, WeightFile &wf) {
             a.conv.tail_out = b.conv.out; a.conv.tail_wt = b.conv.wt; a.conv.tail_bias = b.conv.bias;
             a.conv.tail_cout = b.conv.cout; a.conv.tail_kp = b.conv.kp; a.conv.tail_act = b.conv.act;
             a.tail_tile = a.conv.cout == 64 ? TILE_TAIL_128x64 : (a.conv.cin % 64 == 0 ? TILE_TAIL_K64_128x128 : TILE_TAIL_128x64);
-            if (const char *e = getenv("RTMODT_TAIL")) {     // test hook (no autotune): force the fused launch on
+            if (const char *e = rt_opt("TAIL")) {     // test hook (no autotune): force the fused launch on
                 a.tail_on = atoi(e) != 0 && tile_shape(a.tail_tile).bn == a.conv.cout && !(tile_needs_cin64(a.tail_tile) && a.conv.cin % 64 != 0);
                 b.skip = a.tail_on;
             }
         }
-    // Layer "1" in PIXEL-PAIR form, OPT-IN (RTMODT_L1_PAIR=1).  YOLOv8s' layer 1 is a 3x3 / s2 conv, 32 -> 64 channels on
-    // the 320 x 320 stem output: K = 288 in 32-deep steps, the most byte-heavy GEMM of the net (23 KB through the global -> LDS path per
-    // MFLOP against 15.6 for a 128 x 128 x 64 tile).  Two horizontally adjacent OUTPUT pixels share three of their five input columns,
-    // and two adjacent INPUT pixels are 128 contiguous bytes in NHWC: seen as [B][322][161 pairs][64], the stem's tensor makes the same
-    // arithmetic an ordinary 3x3 / s2 conv with cin = 64 (a pixel pair), cout = 128 (two output pixels x 64 channels), K = 576 -- half
-    // the GEMM rows, every DMA piece a whole 128-byte line, and the 64-deep tile kernels (persistent tiles included) become legal.
-    // Output pair j of a row = padded columns 2j + 1, 2j + 2 of the NHWC output = one contiguous 128-channel "pixel" of the view based
-    // one pixel earlier.  The weight of (sub-pixel s, co) at tap (kh, pair pw, half t, ci) is w[co][kh][2 pw + t - 2 s][ci] where that
-    // kw exists and zero elsewhere.  The non-zero terms of every output meet in the same order and the same 32-wide groups as in the
-    // plain form: bit-identical results (test_layer1_pixel_pair_form).  The 1x1 tail (2.cv1) runs on the pair rows with a
-    // block-diagonal weight matrix.
-    // MEASURED (32 frames, profiles/r03): the pair conv alone 88 us on pt:128x128s2 against 102 us for the plain form's best tile --
-    // but its matrix work is doubled (4 of 9 pair-taps are half empty), and with 2.cv1 as its tail (only the 4-wave tail kernels
-    // exist) it takes 133 us against 111 us for the plain form with its tail: off by default.
-    {
-        const bool pair_off = !(getenv("RTMODT_L1_PAIR") && atoi(getenv("RTMODT_L1_PAIR")) != 0) || (getenv("RTMODT_STEM_L1") && atoi(getenv("RTMODT_STEM_L1")) != 0);
-        for (size_t i = 1; i < d->ops.size() && !pair_off; ++i) {
-            Op &o = d->ops[i];
-            ConvLaunch &c = o.conv;
-            if (o.kind != OP_CONV || o.name != "1" || c.ks != 3 || c.stride != 2 || c.cin != 32 || c.cout != 64 || c.act != 1 || c.res.base || c.out2.base || c.in_lo.base) continue;
-            if (c.in.pad != 1 || c.in.coff != 0 || c.in.C != 32 || c.in.W % 2 != 0 || c.out.pad != 1 || c.out.coff != 0 || c.out.C != 64 || c.out.W % 2 != 0 || c.in.W != 2 * c.out.W) continue;
-            if (c.tail_wt && (c.tail_cout != 64 || c.tail_out.pad != 1 || c.tail_out.coff != 0 || c.tail_out.C < 64 || c.tail_out.C % 8 != 0 || c.tail_kp != 64)) continue;
-            auto rit = wf.recs.find("1");
-            if (rit == wf.recs.end() || (c.tail_wt && wf.recs.find(d->ops[i + 1].name) == wf.recs.end())) continue;
-            const WeightRec &r = rit->second;
-            const int kp = 576;
-            std::vector<f16> w((size_t)128 * kp, (f16)0.0f);
-            std::vector<float> b(128, 0.f);
-            for (int s = 0; s < 2; ++s)
-                for (int co = 0; co < 64; ++co) {
-                    b[s * 64 + co] = r.b[co];
-                    for (int kh = 0; kh < 3; ++kh)
-                        for (int pw = 0; pw < 3; ++pw)
-                            for (int t = 0; t < 2; ++t) {
-                                const int kw = 2 * pw + t - 2 * s;
-                                if (kw < 0 || kw > 2) continue;
-                                memcpy(&w[(size_t)(s * 64 + co) * kp + ((kh * 3 + pw) * 2 + t) * 32], &r.w[((size_t)co * 9 + kh * 3 + kw) * 32], 32 * sizeof(f16));
-                            }
-                }
-            void *dw, *db;
-            RT_TRY(upload(d, w.data(), w.size() * sizeof(f16), &dw));
-            RT_TRY(upload(d, b.data(), b.size() * sizeof(float), &db));
-            c.wt = (const f16 *)dw; c.bias = (const float *)db;
-            c.cin = 64; c.cout = 128; c.kp = kp;
-            c.in.C = 64; c.in.c = 64; c.in.W /= 2; c.in.wp = c.in.W + 1;                 // 161 pairs per padded row, the first one = (border, pixel 0)
-            c.out.base -= 64; c.out.C = 128; c.out.c = 128; c.out.W /= 2; c.out.wp = c.out.W + 1;   // 80 pairs + one pair of border pixels per padded row
-            if (c.tail_wt) {
-                const WeightRec &r2 = wf.recs.find(d->ops[i + 1].name)->second;
-                std::vector<f16> w2((size_t)128 * 128, (f16)0.0f);
-                std::vector<float> b2(128, 0.f);
-                for (int s = 0; s < 2; ++s)
-                    for (int co = 0; co < 64; ++co) {
-                        b2[s * 64 + co] = r2.b[co];
-                        memcpy(&w2[(size_t)(s * 64 + co) * 128 + s * 64], &r2.w[(size_t)co * 64], 64 * sizeof(f16));
-                    }
-                RT_TRY(upload(d, w2.data(), w2.size() * sizeof(f16), &dw));
-                RT_TRY(upload(d, b2.data(), b2.size() * sizeof(float), &db));
-                const int cs = c.tail_out.C;
-                c.tail_wt = (const f16 *)dw; c.tail_bias = (const float *)db; c.tail_cout = 128; c.tail_kp = 128;
-                c.tail_gap = cs - 64;
-                c.tail_out.base -= cs; c.tail_out.C = 2 * cs; c.tail_out.c = 128; c.tail_out.W /= 2; c.tail_out.wp = c.tail_out.W + 1;
-                o.tail_tile = TILE_TAIL_K64_128x128;
-                if (const char *e = getenv("RTMODT_TAIL")) { o.tail_on = atoi(e) != 0; d->ops[i + 1].skip = o.tail_on; }
-            }
-            c.tile = pick_tile(d->B * c.out.H * c.out.W, 128);
-            if (const char *e = getenv("RTMODT_TILE_K64")) {        // the 64-deep test hook applies to the pair form too (the pt tiles need full tiles)
-                const int t = atoi(e);
-                if (t >= 0 && t < TILE_COUNT && tile_needs_cin64(t) && !tile_is_rows(t) && !tile_is_tail(t) && !tile_is_ws(t) && tile_shape(t).bn <= 128 &&
-                    (!tile_is_pt(t) || ((long)d->B * c.out.H * c.out.W) % tile_shape(t).bm == 0)) c.tile = t;
-            }
-            o.name = "1";                                            // (flops, layer_out["1"] and the profile's name keep describing the real conv)
-            break;
-        }
-    }
-    for (size_t i = 1; i < d->ops.size(); ++i) {              // layers 0 + 1 (+ 2.cv1) in one launch: YOLOv8s' shapes only
-        const Op &o = d->ops[i];
-        if (o.kind == OP_CONV && o.name == "1" && d->ops[0].kind == OP_STEM && o.conv.ks == 3 && o.conv.stride == 2 && o.conv.cin == 32 && o.conv.cout == 64 &&
-            d->ops[0].v[1].c == 32 && o.conv.in.base == d->ops[0].v[1].base && !o.conv.res.base && !o.conv.out2.base && o.conv.act == 1 &&
-            stem_l1_supported(32, 64, o.conv.tail_wt ? o.conv.tail_cout : 0, d->in_h, d->in_w) && !getenv("RTMODT_NO_STEM_L1"))
-            d->l1_idx = (int)i;
-    }
     // Detect head: the two first 3x3 convs of a level share their input -> one conv, cout = cbox + ccls
     const int cbox = std::max(16, std::max(c3 / 4, 64)), ccls = std::max(c3, std::min(d->nc, 100));
     const int nc4 = (int)align_up(d->nc, 4), no = 64 + (int)align_up(d->nc, 8);
@@ -725,7 +640,7 @@ static int build_graph(rtmodt_detector *d, WeightFile &wf) {
     // Detect head launches: 0 = 15 separate convs; 1 = the two branches of a level share a launch
     // (9 launches); 2 = every level and branch of a stage in one launch (3 launches)
     int grouping = 2;
-    if (const char *e = getenv("RTMODT_HEAD_GROUP")) grouping = atoi(e);
+    if (const char *e = rt_diag("HEAD_GROUP")) grouping = atoi(e);
     auto add_group = [&](const std::string &name, std::initializer_list<int> idx) {
         Op g; g.kind = OP_GROUP; g.name = name;
         for (int i : idx) { g.group.push_back(hops[i].conv); g.flops += hops[i].flops; }
@@ -765,16 +680,16 @@ static int build_graph(rtmodt_detector *d, WeightFile &wf) {
     // 16 / 32 frames per launch set: +48 / +43 / +30 / +31 / +10 / +3 % throughput with three batches in flight; a single
     // frame run synchronously (detect(), batch 1) keeps the plain engine, whose latency is 7 % lower
     int stages = d->cfg.chains < 0 ? 1 - d->cfg.chains : (d->cfg.chains == 0 && d->B >= 2 ? 2 : 1);      // -1 -> 2 stages, -2 -> 3
-    if (getenv("RTMODT_CHAINS")) stages = 1;
-    if (const char *e = getenv("RTMODT_PIPE")) stages = atoi(e) != 0 ? 2 : 1;
-    if (const char *e = getenv("RTMODT_STAGES")) stages = atoi(e);
+    if (rt_opt("CHAINS")) stages = 1;
+    if (const char *e = rt_diag("PIPE")) stages = atoi(e) != 0 ? 2 : 1;
+    if (const char *e = rt_opt("STAGES")) stages = atoi(e);
     stages = d->cfg.use_graph ? std::max(1, std::min(stages, (int)rtmodt_detector::MAX_STAGES)) : 1;
     {   // stage boundaries by layer name: 2 stages cut after SPPF (52 % / 48 % of the kernel time), 3 stages at 35 % / 66 %
         const char *cut2[] = {"12."}, *cut3[] = {"6.m.1", "16"};      // (sweeps of both sets of cuts on s @ 640: these, within 1 %)
         const char **cuts = stages == 3 ? cut3 : cut2;
         static std::string keep[2];                        // experiment hooks: RTMODT_SPLIT=<layer> (2 stages), RTMODT_SPLIT3=<layer>,<layer>
-        if (const char *e = getenv("RTMODT_SPLIT")) { keep[0] = e; cut2[0] = keep[0].c_str(); }
-        if (const char *e = getenv("RTMODT_SPLIT3")) {
+        if (const char *e = rt_diag("SPLIT")) { keep[0] = e; cut2[0] = keep[0].c_str(); }
+        if (const char *e = rt_diag("SPLIT3")) {
             const std::string v = e; const size_t c = v.find(',');
             if (c != std::string::npos) { keep[0] = v.substr(0, c); keep[1] = v.substr(c + 1); cut3[0] = keep[0].c_str(); cut3[1] = keep[1].c_str(); }
         }
@@ -815,7 +730,7 @@ static int build_graph(rtmodt_detector *d, WeightFile &wf) {
     for (auto &kv : d->layer_out) rebase(kv.second);
     for (size_t i = 0; i < d->ops.size(); ++i)
         if (d->ops[i].kind == OP_GROUP && d->ops[i].name.rfind("22.stage2", 0) == 0) d->stage2_op = (int)i;
-    if (d->stage2_op >= 0 && !getenv("RTMODT_NO_HEAD_FINAL")) {
+    if (d->stage2_op >= 0 && !rt_opt("NO_HEAD_FINAL")) {
         const Op &g = d->ops[d->stage2_op];                // members: cv2.l.2, cv3.l.2 for l = 0, 1, 2
         const int cbox_in = g.group[0].cin, ccls_in = g.group[1].cin;
         bool ok = g.group.size() == 6 && head_final_supported(cbox_in, ccls_in, d->nc) && g.group[0].cout == 64;
@@ -838,9 +753,9 @@ static int build_graph(rtmodt_detector *d, WeightFile &wf) {
     // sub-batch chains (parallel graph branches)
     // measured on MI355X (s @ 640): 2 x 4 frames +4.5 % over 1 x 8, 2 x 8 +7 % over 1 x 16, 2 x 16 +8.6 % over 1 x 32; 4 x 8 -12 % against 1 x 32
     int chains = d->cfg.chains > 0 ? d->cfg.chains : (d->B >= 8 && d->B % 2 == 0 ? 2 : 1);
-    if (const char *e = getenv("RTMODT_CHAINS")) chains = atoi(e);
+    if (const char *e = rt_opt("CHAINS")) chains = atoi(e);
     if (d->pipe) chains = 1;                               // the stages run the whole batch
-    if (const char *e = getenv("RTMODT_CHAIN_JOIN")) d->chain_free_run = atoi(e) == 0;
+    if (const char *e = rt_opt("CHAIN_JOIN")) d->chain_free_run = atoi(e) == 0;
     chains = std::max(1, std::min(chains, d->B));
     while (d->B % chains) --chains;
     set_chains(d, chains);
@@ -851,7 +766,7 @@ static int run_op_on(const Op &op, hipStream_t s) {
     switch (op.kind) {
         case OP_STEM: return launch_stem(op.v[0], op.v[1], op.stem_w, op.stem_b, op.B, op.v[1].c, s);
         case OP_CONV: {
-            if (op.skip || op.in_first) return RTMODT_OK;  // runs as the tail of the previous launch / inside the net's first launch
+            if (op.skip) return RTMODT_OK;  // runs as the tail of the previous launch
             if (!op.tail_on) return launch_conv(op.conv, s);
             ConvLaunch c = op.conv;
             c.tile = op.tail_tile;
@@ -906,26 +821,11 @@ static int run_decode_sub(rtmodt_detector *d, int b0, int nb, hipStream_t st) {
 static int run_decode(rtmodt_detector *d) { return run_decode_sub(d, 0, d->B, d->stream); }
 
 // The net's first launch for one op list (whole batch, a sub-batch chain, or an arena copy): the stem -- straight from the
-// frames' bytes (`from_bytes`: letterbox folded in) or from the letterboxed image tensor -- or, when switched on, the stem,
-// layer 1 and layer 1's 1x1 tail in one launch (stem_l1.hip).  frame0: first frame of d->fptrs this op list covers.
+// frames' bytes (`from_bytes`: letterbox folded in) or from the letterboxed image tensor.  frame0: first frame of d->fptrs
+// this op list covers.
 static int run_first(rtmodt_detector *d, const std::vector<Op> &ops, int frame0, bool from_bytes, hipStream_t st) {
     const Op &op = ops[0];
     RT_CHECK(op.kind == OP_STEM, RTMODT_E_INVALID, "op 0 is not the stem");
-    if (d->sl1_on && d->l1_idx > 0) {
-        const Op &l1 = ops[d->l1_idx];
-        StemL1Launch L;
-        if (from_bytes) { L.frames = &d->fptrs; L.frame0 = frame0; L.pitch = d->last_pitch; L.g = d->last_lg; }
-        else L.img4 = op.v[0];
-        L.in_h = d->in_h; L.in_w = d->in_w; L.B = op.B;
-        L.w0 = op.stem_w; L.b0 = op.stem_b; L.w1 = l1.conv.wt; L.b1 = l1.conv.bias; L.kp1 = l1.conv.kp;
-        if (l1.tail_on) {
-            L.wt = l1.conv.tail_wt; L.bt = l1.conv.tail_bias; L.kpt = l1.conv.tail_kp; L.t_cout = l1.conv.tail_cout; L.t_act = l1.conv.tail_act;
-            L.out = l1.conv.tail_out;
-        } else {
-            L.out = l1.conv.out;
-        }
-        return launch_stem_l1(L, st);
-    }
     if (from_bytes) return launch_stem_fused(d->fptrs, frame0, d->last_pitch, d->last_lg, d->in_h, d->in_w, d->lut255, op.v[1], op.stem_w,
                                              op.stem_b, op.B, op.v[1].c, st);
     return run_op_on(op, st);
@@ -982,7 +882,7 @@ static bool tile_legal(const ConvLaunch *c, int n, int t) {
     if (tile_needs_cin64(t) && !cin64) return false;
     if (tile_is_rows(t) && !rows_ok) return false;
     if (c[0].in_lo.base && !tile_reads_lo(t)) return false;
-    if ((tile_is_w8(t) || tile_is_pf(t)) && n != 1) return false;   // the 8-wave and the software-pipelined tiles have no group entry point
+    if (tile_is_w8(t) && n != 1) return false;    // the 8-wave tiles have no group entry point
     for (int i = 0; i < n; ++i)                   // weights and bias are padded to 128 rows of cout: a wider tile must divide cout
         if (tile_shape(t).bn > 128 && c[i].cout % tile_shape(t).bn != 0) return false;
     if (tile_is_pt(t) && (n != 1 || c[0].out2.base || ((long)c[0].B * c[0].out.H * c[0].out.W) % tile_shape(t).bm != 0 ||
@@ -994,8 +894,6 @@ static bool tile_legal(const ConvLaunch *c, int n, int t) {
         for (int i = 0; i < n; ++i)
             if (c[i].out2.base || c[i].in_lo.base || c[i].cout % 8 != 0 || c[i].out.coff % 8 != 0 || c[i].out.C % 8 != 0 ||
                 (c[i].res.base && (c[i].res.coff % 8 != 0 || c[i].res.C % 8 != 0 || tile_shape(t).bn > 128))) return false;
-    if (tile_is_ws(t) && (n != 1 || c[0].ks != 1 || c[0].stride != 1 || c[0].in_lo.base || c[0].res.base || c[0].out2.base || !tile_ws_fits(t, c[0].kp) ||
-                          ((long)c[0].B * c[0].out.H * c[0].out.W) % 128 != 0 || c[0].cout % tile_shape(t).bn != 0 || c[0].out.coff % 8 != 0 || c[0].out.C % 8 != 0)) return false;
     return true;
 }
 static bool tail_tile_legal(const ConvLaunch &c, int t) {
@@ -1010,18 +908,8 @@ static int tile_lds_kib(int t) {
     if (tile_is_pp(t)) return 2 * (ts.bm / 8 + 1) + 3 * (ts.bn / 8);      // two strip slots + three per-tap weight slots (conv_pp.hip)
     if (tile_is_rows(t)) { const int rp = tile_needs_cin64(t) ? 8 : 16; return 2 * (ts.bm / rp + 1 + 3 * (ts.bn / rp)); }
     if (t >= TILE_WSK_64x64 && t <= TILE_WSK_64x32) return std::max(8 * (ts.bm / 16 + ts.bn / 16), 4 * (ts.bm / 16) * (ts.bn / 16));
-    if (tile_is_ws(t)) return 150;                         // persistent, (nearly) the whole LDS
-    if (tile_is_pt(t)) return (t == TILE_PT_128x128_S2 || t == TILE_PT_128x64_S2 ? 2 : 3) * (ts.bm / 8 + ts.bn / 8);      // (256x128 s3: 144)
-    int stages = 3;
-    switch (t) {
-        case TILE_128x128_S4: stages = 4; break;
-        case TILE_128x64_S5: case TILE_64x128_S5: stages = 5; break;
-        case TILE_64x64_S6: case TILE_128x128_S6: stages = 6; break;
-        case TILE_K64_128x128_S2: case TILE_K64_256x64_S2: case TILE_K64_256x128_S2: case TILE_K64_128x128_S2W: case TILE_K64_128x128_S2_W8:
-        case TILE_K64_256x128_S2_W8: case TILE_K64_256x64_S2_W8: case TILE_K64_256x256_S2_W8: case TILE_K64_PF_128x128_S2: stages = 2; break;
-        case TILE_K64_64x64_S4: stages = 4; break;
-        default: break;
-    }
+    if (tile_is_pt(t)) return 2 * (ts.bm / 8 + ts.bn / 8);
+    const int stages = (t == TILE_K64_128x128_S2_W8 || t == TILE_K64_256x64_S2_W8) ? 2 : 3;
     const int rp = tile_needs_cin64(t) ? 8 : 16;
     return stages * (ts.bm / rp + ts.bn / rp);
 }
@@ -1031,37 +919,19 @@ static int tune_conv(rtmodt_detector *d, hipEvent_t e0, hipEvent_t e1, const std
                      float &best_ms) {
     best_ms = 1e30f;
     int best_tile = tile_io;
-    static const bool tune_ws = getenv("RTMODT_TUNE_WS") != nullptr;
     for (int t = 0; t < TILE_COUNT; ++t) {
         if (!tile_legal(c, n, t)) continue;
-        // the weight-stationary 1x1 kernel halves the bytes through the global -> LDS path but runs ONE workgroup per CU: it ties
-        // with the best tile kernel on every 1x1 conv of YOLOv8s at 32 frames and changes nothing in the staged bench
-        // (profiles/r02/README.md); the persistent-tile kernel (TILE_PT_*) took over its cross-tile prefetch with two
-        // workgroups per CU, so the tuner skips this one unless asked
-        if (tile_is_ws(t) && !tune_ws) continue;
-        // The one-workgroup-per-CU tiles (144 / 128 KiB of LDS: 256x128 s3 with 8 or 16 waves, 256x256 s2, the 16-wave persistent tile) tie
-        // with the 128x128 tiles launch by launch (profiles/r03/bigtiles, w16) but keep every other stage's workgroups off their CU: picked
-        // by the tuner (which times launches ALONE) for 6-8 launches they cost the staged bench 1.6 % on the same box (20 478 vs 20 821
-        // frames/s, profiles/r03/w16/bench_ab.txt).  Tested, available through RTMODT_TUNE_BIG=1 and the test hooks, out of the tuner by default.
-        static const bool tune_big = getenv("RTMODT_TUNE_BIG") != nullptr;
-        if (!tune_big && (t == TILE_K64_256x128_S3_W8 || t == TILE_K64_256x256_S2_W8 || t == TILE_K64_256x128_S3_W16 || t == TILE_PT_256x128_S3_W16)) continue;
-        // the software-pipelined k-loop (TILE_K64_PF_*) ties with the plain loop on every shape tried (profiles/r03/pf/): what a k-step waits for is not
-        // the wave's own LDS-read or DMA-issue latency.  Tested, available through RTMODT_TUNE_PF=1 and the test hooks, out of the tuner by default.
-        static const bool tune_pf = getenv("RTMODT_TUNE_PF") != nullptr;
-        if (!tune_pf && tile_is_pf(t)) continue;
-        // A/B hook: RTMODT_TUNE_SKIP="48,49,53" keeps the listed tile ids out of the tuner (same-box comparisons of a tile family)
-        static const std::string skip = getenv("RTMODT_TUNE_SKIP") ? std::string(",") + getenv("RTMODT_TUNE_SKIP") + "," : std::string();
+        // A/B hook: RTMODT_TUNE_SKIP="22,23" keeps the listed tile ids out of the tuner (same-box comparisons of a tile family)
+        static const std::string skip = rt_diag("TUNE_SKIP") ? std::string(",") + rt_diag("TUNE_SKIP") + "," : std::string();
         if (!skip.empty() && skip.find("," + std::to_string(t) + ",") != std::string::npos) continue;
         float ms;
         RT_TRY(time_launch(d, e0, e1, [&]() { return launch_conv_group(c, n, t, d->stream); }, ms));
-        if (getenv("RTMODT_TUNE_LOG")) fprintf(stderr, "[tune] %-28s %-16s %8.2f us  (%d KiB LDS)\n", name.c_str(), tile_name(t), ms * 1e3f, tile_lds_kib(t));
+        if (rt_opt("TUNE_LOG")) fprintf(stderr, "[tune] %-28s %-16s %8.2f us  (%d KiB LDS)\n", name.c_str(), tile_name(t), ms * 1e3f, tile_lds_kib(t));
         // the launches are timed ALONE, but in the staged engine they share the CUs with the other stages' launches: a tile
         // whose workgroup takes more than half the LDS keeps every other workgroup off its CU (experiment hook)
-        static const float lds_penalty = getenv("RTMODT_TUNE_LDS_PENALTY") ? (float)atof(getenv("RTMODT_TUNE_LDS_PENALTY")) : 0.f;
-        static const int lds_cap = getenv("RTMODT_TUNE_LDS_CAP") ? atoi(getenv("RTMODT_TUNE_LDS_CAP")) : 80;
-        if (d->pipe && tile_lds_kib(t) > lds_cap && !tile_is_ws(t)) ms *= 1.f + lds_penalty;
-        static const float ws_bias = getenv("RTMODT_TUNE_WS_BIAS") ? (float)atof(getenv("RTMODT_TUNE_WS_BIAS")) : 1.f;      // experiment hook
-        if (tile_is_ws(t)) ms *= ws_bias;
+        static const float lds_penalty = rt_diag("TUNE_LDS_PENALTY") ? (float)atof(rt_diag("TUNE_LDS_PENALTY")) : 0.f;
+        static const int lds_cap = rt_diag("TUNE_LDS_CAP") ? atoi(rt_diag("TUNE_LDS_CAP")) : 80;
+        if (d->pipe && tile_lds_kib(t) > lds_cap) ms *= 1.f + lds_penalty;
         if (ms < best_ms) { best_ms = ms; best_tile = t; }
     }
     tile_io = best_tile;
@@ -1106,7 +976,7 @@ static std::map<std::string, TuneRec> tune_cache_read(const char *path) {
 static int autotune_ops(rtmodt_detector *d, std::vector<Op> &ops) {
     hipEvent_t e0, e1;
     RT_HIP(hipEventCreate(&e0)); RT_HIP(hipEventCreate(&e1));
-    const char *cache_path = getenv("RTMODT_TUNE_CACHE");
+    const char *cache_path = rt_opt("TUNE_CACHE");
     std::map<std::string, TuneRec> cache;
     if (cache_path) cache = tune_cache_read(cache_path);
     bool dirty = false;
@@ -1144,9 +1014,9 @@ static int autotune_ops(rtmodt_detector *d, std::vector<Op> &ops) {
             BottleneckLaunch plain = op.bneck;
             plain.tail_wt = nullptr;
             RT_TRY(time_launch(d, e0, e1, [&]() { return launch_bottleneck(plain, d->stream); }, msf));
-            if (getenv("RTMODT_TUNE_LOG")) fprintf(stderr, "[tune] %-28s fused %8.2f us vs two launches %8.2f us\n", op.name.c_str(), msf * 1e3f, (ms1 + ms2) * 1e3f);
+            if (rt_opt("TUNE_LOG")) fprintf(stderr, "[tune] %-28s fused %8.2f us vs two launches %8.2f us\n", op.name.c_str(), msf * 1e3f, (ms1 + ms2) * 1e3f);
             op.fused = msf < ms1 + ms2;
-            if (const char *e = getenv("RTMODT_BNECK")) op.fused = atoi(e) != 0;      // A/B and test hook
+            if (const char *e = rt_opt("BNECK")) op.fused = atoi(e) != 0;      // A/B and test hook
             r.t0 = op.group[0].tile; r.t1 = op.group[1].tile; r.fused = op.fused;
         }
         cache[key] = r;
@@ -1163,49 +1033,23 @@ static int autotune_ops(rtmodt_detector *d, std::vector<Op> &ops) {
             float ms_a, ms_b, best = 1e30f;
             RT_TRY(time_launch(d, e0, e1, [&]() { return launch_conv(op.conv, d->stream); }, ms_a));
             RT_TRY(time_launch(d, e0, e1, [&]() { return launch_conv(nx.conv, d->stream); }, ms_b));
-            for (int t = TILE_TAIL_128x64; t <= TILE_TAIL_K64_64x128; ++t) {
+            for (int t = TILE_TAIL_128x64; t <= TILE_TAIL_K64_128x128; ++t) {
                 if (tile_shape(t).bn != op.conv.cout || (tile_needs_cin64(t) && (op.conv.cin % 64 != 0 || op.conv.kp % 64 != 0)) || op.conv.cin % 32 != 0) continue;
                 ConvLaunch c = op.conv;
                 c.tile = t;
                 float ms;
                 RT_TRY(time_launch(d, e0, e1, [&]() { return launch_conv(c, d->stream); }, ms));
-                if (getenv("RTMODT_TUNE_LOG")) fprintf(stderr, "[tune] %-28s %-16s %8.2f us (+ %s)\n", op.name.c_str(), tile_name(t), ms * 1e3f, nx.name.c_str());
+                if (rt_opt("TUNE_LOG")) fprintf(stderr, "[tune] %-28s %-16s %8.2f us (+ %s)\n", op.name.c_str(), tile_name(t), ms * 1e3f, nx.name.c_str());
                 if (ms < best) { best = ms; op.tail_tile = t; }
             }
             op.tail_on = best < ms_a + ms_b;
-            if (getenv("RTMODT_TUNE_LOG")) fprintf(stderr, "[tune] %-28s with tail %8.2f us vs two launches %8.2f us\n", op.name.c_str(), best * 1e3f, (ms_a + ms_b) * 1e3f);
+            if (rt_opt("TUNE_LOG")) fprintf(stderr, "[tune] %-28s with tail %8.2f us vs two launches %8.2f us\n", op.name.c_str(), best * 1e3f, (ms_a + ms_b) * 1e3f);
             TuneRec r; r.t0 = op.conv.tile; r.t1 = op.tail_tile; r.fused = op.tail_on;
             cache[key] = r;
             dirty = true;
         }
-        if (const char *e = getenv("RTMODT_TAIL")) op.tail_on = atoi(e) != 0 && tile_shape(op.tail_tile).bn == op.conv.cout;   // A/B and test hook
+        if (const char *e = rt_opt("TAIL")) op.tail_on = atoi(e) != 0 && tile_shape(op.tail_tile).bn == op.conv.cout;   // A/B and test hook
         nx.skip = op.tail_on;
-    }
-    // stem + layer 1 (+ its tail) as one launch against the stem followed by layer 1's tuned launch
-    if (d->l1_idx > 0 && ops[0].kind == OP_STEM && (int)ops.size() > d->l1_idx) {
-        Op &l1 = ops[d->l1_idx];
-        char kb[96];
-        snprintf(kb, sizeof(kb), "stem+1|B%d|%dx%d|tail%d", ops[0].B, d->in_h, d->in_w, (int)l1.tail_on);
-        auto hit = cache.find(kb);
-        if (hit != cache.end()) {
-            d->sl1_on = hit->second.fused != 0;
-        } else {
-            float ms_sep, ms_one;
-            d->sl1_on = false;
-            RT_TRY(time_launch(d, e0, e1, [&]() { RT_TRY(run_op_on(ops[0], d->stream)); return run_op_on(l1, d->stream); }, ms_sep));
-            d->sl1_on = true;
-            RT_TRY(time_launch(d, e0, e1, [&]() { return run_first(d, ops, 0, false, d->stream); }, ms_one));
-            // timed here on the image tensor; from the frames' BYTES (the usual source) the one-launch form reads every pixel with
-            // three byte loads and is ~35 % slower than this measurement, while stem_fused assembles rows from aligned dwords: it
-            // must win by a wide margin to be switched on (measured r02: 89 us vs 80 us at 16 frames -- it is not; profiles/r02)
-            d->sl1_on = ms_one < 0.7f * ms_sep;
-            if (getenv("RTMODT_TUNE_LOG")) fprintf(stderr, "[tune] stem + layer 1%s: one launch %8.2f us vs two %8.2f us\n", l1.tail_on ? " + 2.cv1" : "", ms_one * 1e3f, ms_sep * 1e3f);
-            TuneRec r; r.fused = d->sl1_on;
-            cache[kb] = r;
-            dirty = true;
-        }
-        if (const char *e = getenv("RTMODT_STEM_L1")) d->sl1_on = atoi(e) != 0;      // A/B and test hook
-        l1.in_first = d->sl1_on;
     }
     // fused Bottleneck + C2f.cv2 as its tail against the fused Bottleneck followed by cv2's own launch
     for (size_t i = 0; i + 1 < ops.size(); ++i) {
@@ -1222,12 +1066,12 @@ static int autotune_ops(rtmodt_detector *d, std::vector<Op> &ops) {
             RT_TRY(time_launch(d, e0, e1, [&]() { return launch_conv(nx.conv, d->stream); }, ms_cv2));
             RT_TRY(time_launch(d, e0, e1, [&]() { return launch_bottleneck(op.bneck, d->stream); }, ms_tail));
             op.tail_on = ms_tail < ms_plain + ms_cv2;
-            if (getenv("RTMODT_TUNE_LOG")) fprintf(stderr, "[tune] %-28s with cv2 tail %8.2f us vs fused + cv2 %8.2f us\n", op.name.c_str(), ms_tail * 1e3f, (ms_plain + ms_cv2) * 1e3f);
+            if (rt_opt("TUNE_LOG")) fprintf(stderr, "[tune] %-28s with cv2 tail %8.2f us vs fused + cv2 %8.2f us\n", op.name.c_str(), ms_tail * 1e3f, (ms_plain + ms_cv2) * 1e3f);
             TuneRec r; r.t0 = op.group[0].tile; r.t1 = op.group[1].tile; r.fused = op.tail_on ? 2 : 3;
             cache[key] = r;
             dirty = true;
         }
-        if (const char *e = getenv("RTMODT_BNECK_TAIL")) op.tail_on = atoi(e) != 0;      // A/B and test hook
+        if (const char *e = rt_opt("BNECK_TAIL")) op.tail_on = atoi(e) != 0;      // A/B and test hook
         op.tail_on = op.tail_on && op.fused;
         nx.skip = op.tail_on;
     }
@@ -1244,13 +1088,6 @@ static int autotune_ops(rtmodt_detector *d, std::vector<Op> &ops) {
     return RTMODT_OK;
 }
 
-// d->sl1_on is the one truth about the net's first launch: every copy of layer "1" carries it
-static void sync_first_launch_flag(rtmodt_detector *d) {
-    if (d->l1_idx <= 0) { d->sl1_on = false; return; }
-    d->ops[d->l1_idx].in_first = d->sl1_on;
-    for (auto &list : d->chain_ops) if ((int)list.size() > d->l1_idx) list[d->l1_idx].in_first = d->sl1_on;
-}
-
 static int autotune_tiles(rtmodt_detector *d) {
     RT_TRY(autotune_ops(d, d->ops));
     // the tuner's decisions travel from the op it timed to the copies that run
@@ -1258,7 +1095,7 @@ static int autotune_tiles(rtmodt_detector *d) {
         dst.conv.tile = src.conv.tile;
         dst.group_tile = src.group_tile;
         dst.fused = src.fused;
-        dst.tail_on = src.tail_on; dst.tail_tile = src.tail_tile; dst.skip = src.skip; dst.in_first = src.in_first;
+        dst.tail_on = src.tail_on; dst.tail_tile = src.tail_tile; dst.skip = src.skip;
         for (size_t g = 0; g < dst.group.size(); ++g) dst.group[g].tile = src.group[g].tile;
     };
     if (d->n_chains > 1) {
@@ -1268,7 +1105,6 @@ static int autotune_tiles(rtmodt_detector *d) {
     } else {
         for (size_t i = 0; i < d->ops.size(); ++i) adopt(d->chain_ops[0][i], d->ops[i]);
     }
-    sync_first_launch_flag(d);
     // the tuning launches left stale activations; run one clean pass
     RT_TRY(forward_eager_all(d));
     RT_HIP(hipStreamSynchronize(d->stream));
@@ -1359,7 +1195,7 @@ static int ensure_chain_streams(rtmodt_detector *d) {
     if ((int)d->chain_streams.size() >= want || d->stage_stream[0]) return RTMODT_OK;
     hipEvent_t e0, e1, ej;
     RT_HIP(hipEventCreate(&e0)); RT_HIP(hipEventCreate(&e1)); RT_HIP(hipEventCreateWithFlags(&ej, hipEventDisableTiming));
-    if (const char *e = getenv("RTMODT_PAD_STREAMS"))      // test hook: streams created ahead of ours shift the queue mapping
+    if (const char *e = rt_opt("PAD_STREAMS"))      // test hook: streams created ahead of ours shift the queue mapping
         for (int i = 0; i < atoi(e); ++i) { hipStream_t st; RT_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking)); d->pad_streams.push_back(st); }
     std::vector<hipStream_t> rejected;
     int rc = RTMODT_OK;
@@ -1371,7 +1207,7 @@ static int ensure_chain_streams(rtmodt_detector *d) {
                 hipStream_t cand;
                 RT_HIP(hipStreamCreateWithFlags(&cand, hipStreamNonBlocking));
                 bool ok = true;
-                const char *pe = getenv("RTMODT_CHAIN_PROBE");      // 0: trust the creation order (counter-collecting profilers serialise every kernel, the probe would see no overlap)
+                const char *pe = rt_opt("CHAIN_PROBE");      // 0: trust the creation order (counter-collecting profilers serialise every kernel, the probe would see no overlap)
                 if (pe && atoi(pe) == 0) { st = cand; break; }
                 std::vector<hipStream_t> others = d->chain_streams;
                 others.push_back(d->post_stream);
@@ -1381,7 +1217,7 @@ static int ensure_chain_streams(rtmodt_detector *d) {
                 for (hipStream_t o : others) {
                     bool ov = false; float ms = 0;
                     rc = streams_overlap(o, cand, e0, e1, ej, ov, ms);
-                    if (getenv("RTMODT_TUNE_LOG")) fprintf(stderr, "[streams] candidate %d for chain %zu against stream %p: %.1f us -> %s\n", attempt, d->chain_streams.size(), (void *)o, ms * 1e3f, ov ? "own queue" : "shared queue");
+                    if (rt_opt("TUNE_LOG")) fprintf(stderr, "[streams] candidate %d for chain %zu against stream %p: %.1f us -> %s\n", attempt, d->chain_streams.size(), (void *)o, ms * 1e3f, ov ? "own queue" : "shared queue");
                     ok = ok && ov && rc == RTMODT_OK;
                     if (!ok) break;
                 }
@@ -1465,11 +1301,11 @@ static int capture_graph(rtmodt_detector *d) {
 
 // stem output -> dense per-anchor candidates of a single-chain detector, on the main stream
 static int forward_graphs(rtmodt_detector *d) {
-    const int inst = getenv("RTMODT_ONE_EXEC") ? 0 : (int)(d->batch_no % N_EXEC);   // successive batches, successive instances
+    const int inst = rt_diag("ONE_EXEC") ? 0 : (int)(d->batch_no % N_EXEC);   // successive batches, successive instances
 #ifdef RTMODT_DIAG
     // diagnostic build (rocprofv3 --kernel-trace segfaults inside hipGraphLaunch on this engine after ~200 launches): which launch
     // it is, and whether executables that are re-instantiated every N launches get past it (an accumulation per executable in the runtime / profiler)
-    static const int dbg_count = getenv("RTMODT_DEBUG_GRAPH_COUNT") ? 1 : 0, dbg_reinst = getenv("RTMODT_DEBUG_REINST") ? atoi(getenv("RTMODT_DEBUG_REINST")) : 0;
+    static const int dbg_count = rt_diag("DEBUG_GRAPH_COUNT") ? 1 : 0, dbg_reinst = rt_diag("DEBUG_REINST") ? atoi(rt_diag("DEBUG_REINST")) : 0;
     if (dbg_count && d->batch_no % 8 == 0) fprintf(stderr, "[graph] launch %lld\n", (long long)d->batch_no);
     if (dbg_reinst > 0 && d->batch_no > 0 && d->batch_no % dbg_reinst == 0) {
         RT_HIP(hipStreamSynchronize(d->stream));
@@ -1488,7 +1324,7 @@ static int forward_graphs(rtmodt_detector *d) {
 // (needed when the next batch's whole-batch letterbox would overwrite an image tensor a lagging chain still reads).
 static int forward_chains(rtmodt_detector *d, rtmodt_detector::Slot &sl, bool host_frames, bool join_main) {
     const int C = d->n_chains, nb = d->B / C;
-    const int inst = getenv("RTMODT_ONE_EXEC") ? 0 : (int)(d->batch_no % N_EXEC);
+    const int inst = rt_diag("ONE_EXEC") ? 0 : (int)(d->batch_no % N_EXEC);
     for (int c = 0; c < C; ++c) {
         hipStream_t st = d->chain_streams[c];
         if (c > 0) {
@@ -1513,7 +1349,7 @@ static int run_nms(rtmodt_detector *d, const LbHost &g, int h, int w, rtmodt_det
     a.keys = d->d_keys; a.sbox = d->d_sbox; a.sidx = d->d_sidx;
     a.gain = (float)g.gain; a.pad_x = (float)g.pad_x; a.pad_y = (float)g.pad_y; a.src_w = (float)w; a.src_h = (float)h; a.rescale = 1;
     a.out_xyxy = sl.o_xyxy; a.out_conf = sl.o_conf; a.out_cls = sl.o_cls; a.out_anchor = sl.o_anchor; a.out_n = sl.o_n;
-    return launch_nms(a, d->post_stream);
+    return launch_nms(a, d->nms_plan, d->post_stream);
 }
 
 int detector_outputs(rtmodt_detector *d, DetOutputs *o) {
@@ -1640,7 +1476,7 @@ static int detector_create_impl(const rtmodt_det_cfg *cfg, rtmodt_detector *d) {
     RT_CHECK(d->nc >= 1 && d->nc <= 128, RTMODT_E_UNSUPPORTED, "nc %d (1..128 supported)", d->nc);
     RT_HIP(hipSetDevice(d->device));
     RT_HIP(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking));
-    if (const char *e = getenv("RTMODT_POST_PRIO")) {     // experiment hook: the post-processing stream (one workgroup per image / stream) at another priority
+    if (const char *e = rt_diag("POST_PRIO")) {     // experiment hook: the post-processing stream (one workgroup per image / stream) at another priority
         int lo = 0, hi = 0;
         RT_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
         RT_HIP(hipStreamCreateWithPriority(&d->post_stream, hipStreamNonBlocking, atoi(e) > 0 ? hi : lo));
@@ -1650,8 +1486,9 @@ static int detector_create_impl(const rtmodt_det_cfg *cfg, rtmodt_detector *d) {
     RT_HIP(hipStreamCreateWithFlags(&d->copy_stream, hipStreamNonBlocking));
     RT_HIP(hipMalloc((void **)&d->d_zeros, 256));
     RT_HIP(hipMemset(d->d_zeros, 0, 256));
-    if (const char *e = getenv("RTMODT_H2D")) d->h2d_mode = atoi(e);
-    if (const char *e = getenv("RTMODT_ZERO_COPY")) d->zero_copy = atoi(e) != 0;
+    if (const char *e = rt_diag("H2D")) d->h2d_mode = atoi(e);
+    if (const char *e = rt_opt("ZERO_COPY")) d->zero_copy = atoi(e) != 0;
+    d->nms_plan = nms_plan_from_options();
     RT_TRY(build_graph(d, wf));
     RT_TRY(ensure_chain_streams(d));                       // may fall back to one chain: before anything is sized by n_chains
 
@@ -1697,13 +1534,12 @@ static int detector_create_impl(const rtmodt_det_cfg *cfg, rtmodt_detector *d) {
         for (int c = 0; c < 256; ++c) lut[c] = (f16)((float)c / 255.0f);
         RT_HIP(hipMalloc((void **)&d->lut255, sizeof(lut)));
         RT_HIP(hipMemcpy(d->lut255, lut, sizeof(lut), hipMemcpyHostToDevice));
-        if (const char *e = getenv("RTMODT_STEM_FUSE")) d->stem_fuse = atoi(e) != 0;      // A/B and test hook
+        if (const char *e = rt_opt("STEM_FUSE")) d->stem_fuse = atoi(e) != 0;      // A/B and test hook
     }
     // one eager pass (also sets kernel attributes) before capturing the graph
     RT_TRY(forward_eager_all(d));
     RT_HIP(hipStreamSynchronize(d->stream));
     if (cfg->autotune) RT_TRY(autotune_tiles(d));
-    else if (const char *e = getenv("RTMODT_STEM_L1")) { d->sl1_on = atoi(e) != 0; sync_first_launch_flag(d); }      // test hook (no autotune)
     if (cfg->use_graph) RT_TRY(capture_graph(d));
     return RTMODT_OK;
 }
@@ -1774,7 +1610,7 @@ int rtmodt_detector_enqueue_batch(rtmodt_detector *d, const uint8_t *const *fram
         } else {
             // three stages leave the copy stream no hardware queue of its own (it shares the third stage's, and its event waits
             // then hold that stage up: 12.8 k frames/s): the uploads go through the main stream instead, in front of stage 1
-            const bool on_main = d->pipe && d->n_stages == 3 && !(getenv("RTMODT_COPY_ON_MAIN") && atoi(getenv("RTMODT_COPY_ON_MAIN")) == 0);
+            const bool on_main = d->pipe && d->n_stages == 3 && !(rt_diag("COPY_ON_MAIN") && atoi(rt_diag("COPY_ON_MAIN")) == 0);
             if (sl.staged && !on_main) {                       // the launches that last read this area are done
                 RT_HIP(hipStreamWaitEvent(d->copy_stream, sl.evp, 0));
                 if (sl.chained) for (int c = 1; c < d->n_chains; ++c) RT_HIP(hipStreamWaitEvent(d->copy_stream, sl.chain_done[c], 0));
@@ -2067,8 +1903,6 @@ int rtmodt_detector_debug_layer(rtmodt_detector *d, const char *name, int img, u
         if (d->newest >= 0) d->cur_dense = d->newest;
         RT_TRY(materialize_heads(d));                      // Detect's last convs live inside head_final
     }
-    if (d->sl1_on && d->l1_idx > 0 && (strcmp(name, "0") == 0 || (strcmp(name, "1") == 0 && ops[d->l1_idx].tail_on)))
-        return fail(RTMODT_E_UNSUPPORTED, "%s is consumed in LDS by the next conv fused into its launch", name);
     for (auto &op : ops)                               // a conv whose 1x1 tail runs in the same launch stores only the tail's output
         if (op.kind == OP_CONV && op.tail_on && op.name == name)
             return fail(RTMODT_E_UNSUPPORTED, "%s is consumed in LDS by the 1x1 conv fused into its launch", name);
@@ -2119,14 +1953,11 @@ int rtmodt_detector_profile(rtmodt_detector *d, int iters, int max_entries, cons
     d->prof_names.clear();
     for (auto &op : ops) {
         char buf[160];
-        if (op.kind == OP_CONV && op.in_first) {
-            snprintf(buf, sizeof(buf), "%s [runs inside the first launch]", op.name.c_str());
-        } else if (op.kind == OP_CONV && op.skip) {
+        if (op.kind == OP_CONV && op.skip) {
             snprintf(buf, sizeof(buf), "%s [runs as the tail of the previous launch]", op.name.c_str());
         } else if (op.kind == OP_CONV) {
-            snprintf(buf, sizeof(buf), "%s [M=%d N=%d K=%d k%d s%d tile %s%s]", op.name.c_str(), PB * op.conv.out.H * op.conv.out.W,
-                     op.conv.cout, op.conv.ks * op.conv.ks * op.conv.cin, op.conv.ks, op.conv.stride, tile_name(op.tail_on ? op.tail_tile : op.conv.tile),
-                     op.conv.in.wp ? ", pixel pairs" : "");
+            snprintf(buf, sizeof(buf), "%s [M=%d N=%d K=%d k%d s%d tile %s]", op.name.c_str(), PB * op.conv.out.H * op.conv.out.W,
+                     op.conv.cout, op.conv.ks * op.conv.ks * op.conv.cin, op.conv.ks, op.conv.stride, tile_name(op.tail_on ? op.tail_tile : op.conv.tile));
         } else if (op.kind == OP_BNECK) {
             if (op.fused) snprintf(buf, sizeof(buf), "%s [fused bottleneck%s, c=%d, %dx%d]", op.name.c_str(), op.tail_on ? " + C2f.cv2 tail" : "", op.bneck.c, op.bneck.in.H, op.bneck.in.W);
             else snprintf(buf, sizeof(buf), "%s [two launches: %s, %s]", op.name.c_str(), tile_name(op.group[0].tile), tile_name(op.group[1].tile));
@@ -2134,8 +1965,6 @@ int rtmodt_detector_profile(rtmodt_detector *d, int iters, int max_entries, cons
             snprintf(buf, sizeof(buf), "%s [runs inside head_final]", op.name.c_str());
         } else if (op.kind == OP_GROUP) {
             snprintf(buf, sizeof(buf), "%s [group of %zu, tile %s]", op.name.c_str(), op.group.size(), tile_name(op.group_tile));
-        } else if (op.kind == OP_STEM && d->sl1_on) {
-            snprintf(buf, sizeof(buf), "%s [%sstem + layer 1%s in one launch]", op.name.c_str(), d->last_fused ? "letterbox + " : "", ops[d->l1_idx].tail_on ? " + 2.cv1" : "");
         } else if (op.kind == OP_STEM && d->last_fused) {
             snprintf(buf, sizeof(buf), "%s [letterbox + stem fused]", op.name.c_str());
         } else {
@@ -2168,7 +1997,7 @@ int rtmodt_detector_last_timing(rtmodt_detector *d, float *total_ms, float *forw
                 *forward_ms = std::max(*forward_ms, t);
             }
     }
-    if (getenv("RTMODT_DEBUG_GAPS")) {                    // idle time of the main stream between two batches
+    if (rt_diag("DEBUG_GAPS")) {                    // idle time of the main stream between two batches
         static hipEvent_t base = nullptr;
         static float prev_end = -1.f;
         if (!base) { hipEventCreate(&base); hipEventRecord(base, d->stream); hipEventSynchronize(base); }
@@ -2225,7 +2054,7 @@ int rtmodt_nms_pred(int device, const float *pred, int nc, int A, float conf, fl
     a.box = box; a.score = score; a.cls = dcls; a.keys = keys; a.sbox = sbox; a.sidx = sidx;
     a.rescale = 0; a.gain = 1.f;
     a.out_xyxy = oxy; a.out_conf = ocf; a.out_cls = ocl; a.out_anchor = oan; a.out_n = on;
-    RT_TRY(launch_nms(a, nullptr));
+    RT_TRY(launch_nms(a, nms_plan_from_options(), nullptr));
     RT_HIP(hipDeviceSynchronize());
     int n = 0;
     RT_HIP(hipMemcpy(&n, on, 4, hipMemcpyDeviceToHost));

@@ -39,47 +39,32 @@ struct TensorView {
     int C = 0;             // channels of the underlying tensor (pixel stride)
     int pad = 0;           // border width (0 or 1)
     int coff = 0, c = 0;   // the slice
-    int wp = 0;            // padded row length in pixels when it is not W + 2 * pad (pixel-PAIR views of a tensor: engine.hip, layer 1)
-    int padded_w() const { return wp ? wp : W + 2 * pad; }
+    int padded_w() const { return W + 2 * pad; }
 };
 
-// Tile configurations of the implicit-GEMM kernel (conv.hip)
+// Tile configurations of the conv kernels (conv.hip, conv_pp.hip).  Round 4 pruned the table to what the autotuner picks somewhere between 1 and 32
+// frames per launch on the n / s / m widths (profiles/r04/tuner_wins.txt) plus the tiles the general (cin % 32 != 0) path needs; the families that lost
+// every A/B -- weight-stationary 1x1, software-pipelined k-loop, 16-wave and 144-KiB one-per-CU tiles, deeper 32-deep rings, the 4-wave 64-deep
+// variants -- are gone from the library (their measurements stay under profiles/r02, r03).
 enum ConvTile {
-    TILE_128x128 = 0, TILE_128x64 = 1, TILE_64x64 = 2, TILE_256x32 = 3, TILE_64x128 = 4,   // 4 waves share one tile
-    TILE_WSK_64x64 = 5, TILE_WSK_32x64 = 6, TILE_WSK_64x32 = 7,                           // 4 waves split K over one tile
-    TILE_128x128_S4 = 8, TILE_128x64_S5 = 9, TILE_64x64_S6 = 10, TILE_64x128_S5 = 11, TILE_128x128_S6 = 12,   // deeper DMA pipelines
-    TILE_K64_128x128_S2 = 13, TILE_K64_128x128_S3 = 14, TILE_K64_128x64_S3 = 15, TILE_K64_64x128_S3 = 16,   // 64-deep k-steps (cin % 64 == 0)
-    TILE_K64_64x64_S3 = 17, TILE_K64_64x64_S4 = 18, TILE_K64_256x64_S2 = 19, TILE_K64_256x128_S2 = 20, TILE_K64_128x128_S2W = 21,
-    TILE_ROWS_128x64 = 22, TILE_ROWS_256x32 = 23, TILE_ROWS_128x32 = 24,                    // 3x3/s1 tap-reuse kernel, 32-deep chunks
-    TILE_ROWS_K64_128x64 = 25, TILE_ROWS_K64_128x128 = 26, TILE_ROWS_K64_64x64 = 27, TILE_ROWS_K64_256x64 = 28,   // ... 64-deep
-    TILE_TAIL_128x64 = 29, TILE_TAIL_64x64 = 30, TILE_TAIL_K64_128x128 = 31, TILE_TAIL_K64_64x128 = 32,   // conv + fused 1x1 tail (BN == cout)
-    TILE_K64_128x128_S2_W8 = 33, TILE_K64_128x128_S3_W8 = 34, TILE_K64_256x128_S2_W8 = 35, TILE_K64_128x64_S3_W8 = 36, TILE_K64_256x64_S2_W8 = 37,   // 8 waves per workgroup
-    TILE_ROWS_128x64_W8 = 38, TILE_ROWS_256x64_W8 = 39, TILE_ROWS_K64_128x128_W8 = 40, TILE_ROWS_K64_256x64_W8 = 41,   // tap-reuse kernel, 8 waves
-    TILE_WS_128x128 = 42, TILE_WS_128x64 = 43,      // 1x1 convs, WEIGHT-STATIONARY: a persistent workgroup keeps its cout slice of the weights in LDS and streams pixel tiles
-    TILE_PT_128x128_S2 = 44, TILE_PT_128x128_S3 = 45, TILE_PT_128x64_S3 = 46, TILE_PT_128x64_S2 = 47,   // PERSISTENT 64-deep tile kernel: a workgroup walks over pixel tiles, the ring keeps prefetching across tile boundaries
-    // BIG tiles, one workgroup per CU: fewer operand bytes per FLOP through the L2 -> LDS path (256x128: -25 %, 256x256: -50 % vs 128x128)
-    // AND more of them in flight (three 48-KiB stages / two 64-KiB stages of the 160 KiB); 8 waves, 64x64 / 64x128 outputs per wave
-    TILE_K64_256x128_S3_W8 = 48, TILE_K64_256x256_S2_W8 = 49,
-    // PERSISTENT tap-reuse kernel (8 waves): a workgroup walks over the tiles of the (grouped) launch, the next tile's first operands in flight under this tile's last step and epilogue
-    TILE_ROWS_PT_256x64 = 50, TILE_ROWS_PT_128x64 = 51, TILE_ROWS_PT_K64_256x64 = 52,
-    // the big tiles with SIXTEEN waves (one 1024-thread workgroup per CU): the LDS-DMA path sustains ~5 B/clk per issuing wave
-    TILE_K64_256x128_S3_W16 = 53,
-    TILE_PT_256x128_S3_W16 = 54,                    // ... and the persistent tile kernel on that shape (cross-tile prefetch through a three-stage ring, one workgroup per CU)
-    // 64-deep tile kernel with a SOFTWARE-PIPELINED k-loop (two fragment sets, the barrier between the two MFMA blocks of a step, DMA pieces issued between MFMAs):
-    // 4 waves x 64x64 outputs, two workgroups per CU; 8 waves on 256x128 with three stages, one workgroup per CU
-    TILE_K64_PF_128x128_S2 = 55, TILE_K64_PF_256x128_S3_W8 = 56,
-    // 3x3 / stride-1 PING-PONG kernel (conv_pp.hip): one persistent 8-wave workgroup per CU, its two halves one barrier interval apart
-    // (one reads + issues DMA while the other multiplies), tap reuse, 256 positions x BN couts
-    TILE_PP_256x128 = 57, TILE_PP_256x64 = 58, TILE_PP_256x192 = 59,
-    // the ping-pong schedule without tap reuse (1x1, 3x3 stride 2): one conv per launch, cin % 64 == 0, K >= 192
-    TILE_PPT_256x128 = 60, TILE_PPT_256x64 = 61,
-    TILE_PP_512x64 = 62,                            // the 3x3 ping-pong kernel's wide form for 64-cout convs: 512 positions x 64 couts per workgroup
-    TILE_COUNT = 63
+    TILE_128x128 = 0, TILE_128x64 = 1, TILE_64x64 = 2, TILE_256x32 = 3, TILE_64x128 = 4,   // 4 waves share one tile, 32-deep k-steps, three stages (any cin % 8 == 0)
+    TILE_WSK_64x64 = 5, TILE_WSK_32x64 = 6, TILE_WSK_64x32 = 7,                           // 4 waves split K over one tile (small-M layers)
+    TILE_K64_64x64_S3 = 8,                                                                // 64-deep k-steps (cin % 64 == 0), 4 waves
+    TILE_ROWS_128x32 = 9, TILE_ROWS_K64_64x64 = 10,                                       // 3x3/s1 tap-reuse kernel, 4 waves (32- / 64-deep chunks)
+    TILE_TAIL_128x64 = 11, TILE_TAIL_K64_128x128 = 12,                                    // conv + fused 1x1 tail (BN == cout)
+    TILE_K64_128x128_S2_W8 = 13, TILE_K64_128x128_S3_W8 = 14, TILE_K64_128x64_S3_W8 = 15, TILE_K64_256x64_S2_W8 = 16,   // 64-deep, 8 waves per workgroup
+    TILE_ROWS_128x64_W8 = 17, TILE_ROWS_256x64_W8 = 18,                                   // tap-reuse kernel, 8 waves
+    TILE_PT_128x128_S2 = 19, TILE_PT_128x64_S2 = 20,                                      // PERSISTENT 64-deep tile kernel: a workgroup walks over pixel tiles, the ring keeps prefetching across tile boundaries
+    TILE_ROWS_PT_256x64 = 21,                                                             // PERSISTENT tap-reuse kernel (8 waves, groups allowed)
+    // 3x3 / stride-1 PING-PONG kernel (conv_pp.hip): one persistent 8-wave workgroup per CU, its two halves one barrier interval apart (one reads +
+    // issues DMA while the other multiplies), tap reuse; 256 positions x BN couts, or 512 positions x 64 couts (the wide form for 64-cout convs)
+    TILE_PP_256x128 = 22, TILE_PP_256x64 = 23, TILE_PP_256x192 = 24, TILE_PP_512x64 = 25,
+    TILE_PPT_256x128 = 26,                                                                // the ping-pong schedule without tap reuse (1x1, 3x3 stride 2): one conv per launch, cin % 64 == 0, K >= 192
+    TILE_COUNT = 27
 };
 const char *tile_name(int tile);
 bool tile_needs_cin64(int tile);
 bool tile_is_rows(int tile);      // 3x3 stride-1 only, bordered input
-bool tile_is_pf(int tile);        // software-pipelined 64-deep tile kernel (single problems)
 bool tile_is_rows_pt(int tile);   // ... its persistent form (groups allowed)
 bool tile_is_pp(int tile);        // ping-pong 3x3 / stride-1 kernel (conv_pp.hip): cin % 64 == 0, groups allowed
 bool tile_is_ppt(int tile);       // ping-pong tile kernel without tap reuse (conv_pp.hip): one conv, cin % 64 == 0, K >= 192, no residual / second destination
@@ -87,8 +72,6 @@ bool tile_is_tail(int tile);      // runs ConvLaunch::tail_* as well; needs cout
 bool tile_reads_lo(int tile);     // can serve ConvLaunch::in_lo
 bool tile_is_w8(int tile);        // 8-wave 64-deep tile kernel (conv_mfma64_w8): one conv per launch
 bool tile_is_pt(int tile);        // persistent 64-deep tile kernel: one conv per launch, cin % 64 == 0, full tiles, no second destination
-bool tile_is_ws(int tile);        // weight-stationary 1x1 kernel: ks == 1, stride 1, cin % 64 == 0, one problem per launch, weights slice + ring <= 156 KiB of LDS
-bool tile_ws_fits(int tile, int kp);
 struct TileShape { int bm, bn; };
 TileShape tile_shape(int tile);
 
@@ -106,9 +89,6 @@ struct ConvLaunch {
     int tile = TILE_128x128;
     // optional fused tail: a 1x1 stride-1 conv over this conv's output, which is then never stored (TILE_TAIL_* only)
     TensorView tail_out; const f16 *tail_wt = nullptr; const float *tail_bias = nullptr; int tail_cout = 0, tail_kp = 0, tail_act = 1;
-    // pixel-pair form only: the tail's 128 output "channels" are two pixels x 64 channels, and the second pixel starts tail_gap elements
-    // after the end of the first (the destination is a 64-channel slice of a wider tensor)
-    int tail_gap = 0;
     int epilogue = 1;             // 0: 8-byte stores from the accumulator layout; 1: 16-byte stores through LDS in the tile kernels; 2: also in the tap-reuse kernel
 };
 
@@ -143,19 +123,6 @@ struct LetterboxGeom { int src_h, src_w, new_w, new_h, top, left, resize; };
 struct FramePtrs { const uint8_t *p[64]; };
 int launch_stem_fused(const FramePtrs &frames, int frame0, int pitch, const LetterboxGeom &g, int in_h, int in_w, const f16 *lut,
                       const TensorView &out, const f16 *wm, const float *bias, int B, int cout, hipStream_t s);
-// Layers 0 + 1 (+ the 1x1 conv 2.cv1 as a tail) of YOLOv8s in ONE launch, the stem's output kept in LDS (stem_l1.hip).
-// Source: the BGR frames themselves (`frames` != nullptr; no resize) or the letterboxed image tensor `img4`.
-struct StemL1Launch {
-    const FramePtrs *frames = nullptr; int frame0 = 0, pitch = 0; LetterboxGeom g{};
-    TensorView img4;
-    int in_h = 0, in_w = 0, B = 1;
-    const f16 *w0 = nullptr; const float *b0 = nullptr;                       // stem weights in launch_stem's layout
-    const f16 *w1 = nullptr; const float *b1 = nullptr; int kp1 = 0;          // layer 1 in the conv layout
-    const f16 *wt = nullptr; const float *bt = nullptr; int kpt = 0, t_cout = 0, t_act = 1;   // optional 1x1 tail
-    TensorView out;                                                           // the tail's output, or layer 1's without a tail
-};
-bool stem_l1_supported(int c0, int c1, int tail_cout, int in_h, int in_w);
-int launch_stem_l1(const StemL1Launch &l, hipStream_t s);
 // SPPF: y -> (max5(y), max5(max5(y)), max5^3(y)) written to three channel slices of the same tensor
 int launch_sppf_pool(const TensorView &y, const TensorView &p1, const TensorView &p2, const TensorView &p3, int B,
                      hipStream_t s);
@@ -219,7 +186,10 @@ struct NmsArgs {
     // outputs [B][max_det]
     float *out_xyxy; float *out_conf; int32_t *out_cls; int32_t *out_anchor; int32_t *out_n;
 };
-int launch_nms(const NmsArgs &a, hipStream_t s);
+// which form of the kernel runs: resolved from the options once per detector (nms_plan_from_options), never per launch
+struct NmsPlan { int threads = 1024; int rank_max = 512; int stop = 0; };
+NmsPlan nms_plan_from_options();
+int launch_nms(const NmsArgs &a, const NmsPlan &plan, hipStream_t s);
 // pred[(4+nc)][A] float32 -> dense per-anchor candidates (what decode emits), for rtmodt_nms_pred
 int launch_pred_candidates(const float *pred, int nc, int n_anchors, float conf, const uint64_t class_mask[2],
                            float4 *box, float *score, int32_t *cls, hipStream_t s);

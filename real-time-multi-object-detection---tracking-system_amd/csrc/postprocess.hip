@@ -744,21 +744,30 @@ __global__ __launch_bounds__(PP_THREADS) void nms_kernel(NmsArgs a, int dbg_stop
     if (tid == 0) a.out_n[b] = kept;
 }
 
-int launch_nms(const NmsArgs &a, hipStream_t s) {
-    size_t smem = (size_t)SORT_LDS_MAX * 8 + (size_t)REMOVED_WORDS * 8 + 64 * 8 + 64 * 16 + 64 * 4 + (size_t)a.max_det * 4 + 16;
-    RT_CHECK(smem <= 150 * 1024, RTMODT_E_INVALID, "nms: max_det %d too large", a.max_det);
-    static const int dbg_stop = getenv("RTMODT_NMS_STOP") ? atoi(getenv("RTMODT_NMS_STOP")) : 0;   // timing-only builds of the phases
-    const char *e = getenv("RTMODT_NMS_THREADS");                                                   // A/B and test hook (read per launch)
-    const bool wide = !(e && atoi(e) == 256);
-    const char *rm = getenv("RTMODT_NMS_RANK_MAX");
-    // LDS rank sort (no barriers, n^2 / threads 64-bit compares per thread) up to here, the bitonic network (log^2 n barrier steps) above:
+// The hooks are resolved ONCE (per detector at create time, per call of the stand-alone rtmodt_nms_pred), not per launch
+NmsPlan nms_plan_from_options() {
+    NmsPlan p;
+    if (const char *e = rt_opt("NMS_THREADS")) p.threads = atoi(e) == 256 ? 256 : 1024;            // test hook: the round-2 form of the kernel
+    // LDS rank sort (no barriers, n^2 / threads 64-bit compares per thread) up to rank_max, the bitonic network (log^2 n barrier steps) above:
     // with 1024 threads they cross at ~500 candidates (profiles/r03/nms_phases/sort_crossover.txt: 1 000 candidates 25 vs 18 us,
     // 2 000: 74 vs 24); the 256-thread form keeps round 2's 2 048
-    const int rank_max = rm ? min(atoi(rm), RANK_LDS_MAX) : (wide ? 512 : RANK_LDS_MAX);
+    p.rank_max = p.threads == 1024 ? 512 : RANK_LDS_MAX;
+    if (const char *e = rt_diag("NMS_RANK_MAX")) p.rank_max = atoi(e);
+    p.rank_max = max(0, min(p.rank_max, RANK_LDS_MAX));
+    if (const char *e = rt_diag("NMS_STOP")) p.stop = atoi(e);                                     // timing-only cuts after each phase
+    return p;
+}
+
+int launch_nms(const NmsArgs &a, const NmsPlan &plan, hipStream_t s) {
+    size_t smem = (size_t)SORT_LDS_MAX * 8 + (size_t)REMOVED_WORDS * 8 + 64 * 8 + 64 * 16 + 64 * 4 + (size_t)a.max_det * 4 + 16;
+    RT_CHECK(smem <= 150 * 1024, RTMODT_E_INVALID, "nms: max_det %d too large", a.max_det);
+    RT_CHECK((plan.threads == 1024 || plan.threads == 256) && plan.rank_max >= 0 && plan.rank_max <= RANK_LDS_MAX, RTMODT_E_INVALID,
+             "nms: plan (%d threads, rank sort up to %d)", plan.threads, plan.rank_max);
+    const bool wide = plan.threads == 1024;
     static DynLdsSeen seen[2];                             // raise the dynamic-LDS limit once per device and size, not per launch
     RT_TRY(raise_dynamic_lds(wide ? (const void *)nms_kernel<1024> : (const void *)nms_kernel<256>, smem, seen[wide]));
-    if (wide) hipLaunchKernelGGL(nms_kernel<1024>, dim3(a.B), dim3(1024), smem, s, a, dbg_stop, rank_max);
-    else hipLaunchKernelGGL(nms_kernel<256>, dim3(a.B), dim3(256), smem, s, a, dbg_stop, rank_max);
+    if (wide) hipLaunchKernelGGL(nms_kernel<1024>, dim3(a.B), dim3(1024), smem, s, a, plan.stop, plan.rank_max);
+    else hipLaunchKernelGGL(nms_kernel<256>, dim3(a.B), dim3(256), smem, s, a, plan.stop, plan.rank_max);
     RT_HIP(hipGetLastError());
     return RTMODT_OK;
 }

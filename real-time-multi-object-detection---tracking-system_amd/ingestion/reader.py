@@ -133,6 +133,7 @@ class FrameReader:
             raise ValueError(f"a ring of {ring.slots} slots cannot hold buffer_size={self.buffer_size} leased frames plus the latest "
                              f"frame and the one being written: build it with >= {self.buffer_size + 2} slots")
         self._leases: Dict[int, int] = {}              # ring slot -> outstanding leases
+        self.lease_misses = 0                          # read(copy=False) calls served by a copy because no slot could be leased
         self._lease_slot: Dict[int, int] = {}          # frame id -> ring slot
         self._latest_slot = -1
         self._cap = None
@@ -158,7 +159,8 @@ class FrameReader:
     def read(self, copy: bool = True):
         """``(ok, frame, frame_id)``, non-blocking.  ``copy=False`` hands out the (page-locked) ring slot itself under a
         lease: it is not rewritten until ``release(frame_id)``.  With every slot but the latest and the write slot on
-        lease the call raises -- release earlier frames (after their batch's ``fetch``) or build a larger ring."""
+        lease the call degrades to a copy (counted in ``lease_misses``) instead of failing -- the reference's ``read`` never
+        raises (rtsp_reader.py:117-149); release earlier frames after their batch's ``fetch``, or build a larger ring."""
         with self._lock:
             if self._latest is None:
                 return False, None, self._frame_id
@@ -168,8 +170,8 @@ class FrameReader:
             if self._ring is not None:                 # (without a ring every frame is a fresh array: nothing to protect)
                 slot = self._latest_slot
                 if slot not in self._leases and len(self._leases) >= self._ring.slots - 2:
-                    raise RuntimeError(f"all {self._ring.slots - 2} leasable ring slots are on lease: release(frame_id) the frames whose "
-                                       "batches have been fetched, or build the ring with more slots")
+                    self.lease_misses += 1             # every leasable slot is out: hand a copy over, nothing to release for it
+                    return True, self._latest.copy(), self._frame_id
                 if self._frame_id not in self._lease_slot:
                     self._leases[slot] = self._leases.get(slot, 0) + 1
                     self._lease_slot[self._frame_id] = slot
@@ -197,6 +199,9 @@ class FrameReader:
         self._stop.set()
         if self._thread is not None:
             self._thread.join(timeout=5.0)
+        with self._lock:                               # leases do not outlive the reader
+            self._leases.clear()
+            self._lease_slot.clear()
         self._release()
         log.info("FrameReader stopped.")
 

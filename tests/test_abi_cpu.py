@@ -63,3 +63,37 @@ def test_track_container_and_tracker_errors(pkg):
 def test_device_string_parsing(pkg):
     f = pkg._ffi.device_ordinal
     assert (f("cuda:0"), f("cuda:3"), f("cuda"), f(2), f("1")) == (0, 3, 0, 2, 1)
+
+
+def test_runtime_options_live_in_one_table():
+    """csrc/common.h: the library reads RTMODT_* variables through rt_opt() (one table) or rt_diag() (diagnostic builds only) and
+    nowhere else; every variable the GPU tests, bench.py and the profile collection set is in the table, and the product build
+    does not define RTMODT_DIAG."""
+    import glob
+    import os
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    csrc = os.path.join(root, "real-time-multi-object-detection---tracking-system_amd", "csrc")
+    common = open(os.path.join(csrc, "common.h")).read()
+    table = set(re.findall(r'"([A-Z0-9_]+)"', common[common.index("kOptions[] = {"):common.index("};", common.index("kOptions[] = {"))]))
+    assert 10 <= len(table) <= 24
+    opt, diag = set(), set()
+    for f in glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.h")):
+        src = open(f).read()
+        if not f.endswith("common.h"):
+            assert "getenv(" not in src, f
+        opt |= set(re.findall(r'rt_opt\("([A-Z0-9_]+)"\)', src))
+        diag |= set(re.findall(r'rt_diag\("([A-Z0-9_]+)"\)', src))
+    assert common.count("getenv(") == 1
+    assert opt <= table, opt - table
+    assert not (diag & table), diag & table
+    used = set()
+    for f in glob.glob(os.path.join(root, "tests", "*.py")) + [os.path.join(root, "bench.py"), os.path.join(root, "__graft_entry__.py"),
+                                                               os.path.join(root, "tools", "collect_profiles.sh")]:
+        if os.path.abspath(f) == os.path.abspath(__file__):
+            continue
+        used |= set(re.findall(r'RTMODT_([A-Z0-9_]+[A-Z0-9])', open(f).read()))
+    used -= {"E_INVALID", "E_HIP", "E_UNSUPPORTED", "OK", "DIAG"}
+    assert used <= table, sorted(used - table)
+    mk = open(os.path.join(csrc, "Makefile")).read()
+    assert "DIAG ?= 0" in mk

@@ -32,6 +32,18 @@ def make_detector(pkg, wdir, scale, size, calibrate="noise", **kw):
 
 
 # ------------------------------------------------------------------ preprocess
+
+def _tile_ids():
+    """ConvTile ids by name, parsed from csrc/kernels.h: the tests name tiles, they do not hard-code a table that a pruned library renumbers"""
+    import re
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "real-time-multi-object-detection---tracking-system_amd", "csrc", "kernels.h")).read()
+    body = src[src.index("enum ConvTile {"):]
+    body = body[:body.index("};")]
+    return {m.group(1): int(m.group(2)) for m in re.finditer(r"TILE_(\w+)\s*=\s*(\d+)", body)}
+
+
+T = _tile_ids()
+
 @pytest.mark.parametrize("h,w,size", [(640, 640, 640), (1080, 1920, 640), (480, 640, 640), (200, 300, 640), (720, 1280, 320), (37, 53, 64)])
 def test_letterbox_bit_exact(pkg, h, w, size):
     img = pkg.synth.structured_frames(1, h, w, seed=h + w)[0]
@@ -210,7 +222,7 @@ def test_forward_layers_other_scales(pkg, wdir, scale, size):
     det.close()
 
 
-@pytest.mark.parametrize("tile", [22, 23, 24, 25, 26, 27, 28, 38, 39, 40, 41, 50, 51, 52])      # 38..41: the 8-wave variants; 50..52: the persistent form
+@pytest.mark.parametrize("tile", [T["ROWS_128x32"], T["ROWS_K64_64x64"], T["ROWS_128x64_W8"], T["ROWS_256x64_W8"], T["ROWS_PT_256x64"]])      # 4 waves (32- / 64-deep), 8 waves, the persistent form
 def test_tap_reuse_conv_tiles(pkg, wdir, monkeypatch, tile):
     """conv3x3_rows (the 3x3/s1 tap-reuse kernel) in each of its tile shapes, forced onto every
     layer where it is legal; all layers are then checked one by one against the oracle."""
@@ -723,7 +735,7 @@ def test_epilogue_variants_store_identical_values(pkg, wdir, monkeypatch):
     forced here).  bias / SiLU / residual / nearest-2x copy happen in fp32 before the single rounding in all of them,
     so every layer must be bit-identical."""
     monkeypatch.setenv("RTMODT_BNECK", "0")
-    monkeypatch.setenv("RTMODT_TILE_3X3S1", "22")
+    monkeypatch.setenv("RTMODT_TILE_3X3S1", str(T["ROWS_128x64_W8"]))
     frames = list(pkg.synth.frames(2, 320, 320, seed=61))
     names = [c.name for c in pkg.weights.spec("s")]
     outs = {}
@@ -803,7 +815,7 @@ def test_head_final_equals_separate_launches(pkg, wdir, monkeypatch, scale, size
         assert np.array_equal(res["off"][1][i][2].view(np.int32), res["on"][1][i][2].view(np.int32))         # pred
 
 
-@pytest.mark.parametrize("tile", [33, 34, 35, 36, 37, 48, 49, 53, 55, 56])      # 48, 49: the one-workgroup-per-CU big tiles (144 / 128 KiB of LDS); 53: 256x128 with 16 waves; 55, 56: the software-pipelined k-loop (4 waves 128x128, 8 waves 256x128)
+@pytest.mark.parametrize("tile", [T["K64_128x128_S2_W8"], T["K64_128x128_S3_W8"], T["K64_128x64_S3_W8"], T["K64_256x64_S2_W8"]])
 def test_eight_wave_tiles(pkg, wdir, monkeypatch, tile):
     """The 64-deep tile kernel with EIGHT waves per workgroup (the global->LDS path sustains ~5 B/clk per wave, so the
     big tiles issue their operands from twice as many waves): forced onto every single-launch conv with cin % 64 == 0,
@@ -988,7 +1000,7 @@ def test_neck_concat_read_from_half_resolution(pkg, wdir, monkeypatch, size, bat
     RTMODT_UP_READ=0 the producer's epilogue writes the copy into the concat slice.  On a common 64-deep tile the two
     give bit-identical layers, and both match the oracle (odd map sizes at 288: 9 -> 18 -> 36)."""
     monkeypatch.setenv("RTMODT_TILE", "2")
-    monkeypatch.setenv("RTMODT_TILE_K64", "15")
+    monkeypatch.setenv("RTMODT_TILE_K64", str(T["K64_128x64_S3_W8"]))
     monkeypatch.setenv("RTMODT_BNECK", "0")
     frames = list(pkg.synth.frames(batch, size, size, seed=57))
     names = [c.name for c in pkg.weights.spec("s")]
@@ -1139,15 +1151,16 @@ def test_autotune_cache_rejects_foreign_and_illegal_entries(pkg, wdir, monkeypat
     a, w = make_detector(pkg, wdir, "n", 320, autotune=True, batch=2)
     good = cache.read_text().splitlines()
     a.close()
-    # (1) headerless file with every record pointing at tile 22 (tap-reuse: illegal for 1x1 and stride-2 convs)
-    cache.write_text("\n".join(f"{l.split()[0]}\t22 22 1" for l in good[1:]) + "\n")
+    # (1) headerless file with every record pointing at a tap-reuse tile (illegal for 1x1 and stride-2 convs)
+    rows, tail = T["ROWS_K64_64x64"], T["TAIL_K64_128x128"]
+    cache.write_text("\n".join(f"{l.split()[0]}\t{rows} {rows} 1" for l in good[1:]) + "\n")
     b, _ = make_detector(pkg, wdir, "n", 320, autotune=True, batch=2)
     assert cache.read_text().splitlines()[0] == good[0]              # ignored, re-tuned, rewritten with the header
     frames = list(pkg.synth.frames(2, 320, 320, seed=5))
     ref = b.detect_batch(frames)
     b.close()
     # (2) right header, illegal ids: every hit is re-checked
-    cache.write_text(good[0] + "\n" + "\n".join(f"{l.split()[0]}\t22 29 1" for l in good[1:]) + "\n")
+    cache.write_text(good[0] + "\n" + "\n".join(f"{l.split()[0]}\t{rows} {tail} 1" for l in good[1:]) + "\n")
     c, _ = make_detector(pkg, wdir, "n", 320, autotune=True, batch=2)
     inp, _, _ = c.debug_fetch(0, want_heads=False, want_pred=False) if c.detect_batch(frames) else (None, None, None)
     names = [x.name for x in pkg.weights.spec("n")]
@@ -1160,92 +1173,10 @@ def test_autotune_cache_rejects_foreign_and_illegal_entries(pkg, wdir, monkeypat
     assert len(ref) == 2
 
 
-@pytest.mark.parametrize("src_hw,size,batch,tail", [((640, 640), 640, 2, "1"), ((640, 640), 640, 2, "0"), ((480, 640), 640, 3, "1"), ((320, 320), 320, 2, "1"),
-                                                  ((1080, 1920), 640, 1, "1")])
-def test_stem_and_layer1_in_one_launch(pkg, wdir, monkeypatch, src_hw, size, batch, tail):
-    """stem_l1.hip: layers 0, 1 and (with the tail) 2.cv1 of YOLOv8s as ONE launch, the stem's 320x320x32 output kept in LDS.
-    Forced on / off with every other conv on the 64x64 tile (same k order, bias added after the sum in both): every stored
-    layer bit-identical between the two and within tolerance of the oracle; sources: frames read as bytes (640x640), with
-    letterbox pads (480x640: 114 rows above and below), a 320 engine (one segment per row) and a 1080p source that goes
-    through the letterbox kernel first (the fused launch then reads the fp16 image tensor)."""
-    monkeypatch.setenv("RTMODT_TILE", "2")
-    monkeypatch.setenv("RTMODT_BNECK", "0")
-    monkeypatch.setenv("RTMODT_TAIL", tail)
-    h, w = src_hw
-    frames = list(pkg.synth.structured_frames(batch, h, w, seed=h + w + batch))
-    names = [c.name for c in pkg.weights.spec("s")]
-    outs = {}
-    for mode in ("0", "1"):
-        monkeypatch.setenv("RTMODT_STEM_L1", mode)
-        det, wts = make_detector(pkg, wdir, "s", size, autotune=False, batch=batch, confidence=0.05)
-        dets = det.detect_batch(frames)
-        prof = [n for n, _, _ in det.profile(1)]
-        assert ("in one launch" in prof[0]) == (mode == "1"), prof[:3]
-        layers = []
-        for img in range(batch):
-            inp, _, _ = det.debug_fetch(img, want_heads=False, want_pred=False)
-            gpu = fetch_layers(pkg, det, names, img)
-            layers.append(gpu)
-            if mode == "1":
-                assert "0" not in gpu and ("1" in gpu) == (tail == "0") and "2.cv1" in gpu
-                assert np.array_equal(inp.astype(np.float32), Y.preprocess(frames[img], size, size).astype(np.float16).astype(np.float32))
-                taps = {}
-                Y.forward(inp.astype(np.float32), wts, "s", taps=taps, force=gpu)
-                for n in gpu:
-                    k = 6e-3 if n in ("1", "2.cv1") else 2e-3          # up to two unforced fp16 intermediates (stem, layer 1) behind these
-                    assert float(np.abs(taps[n] - gpu[n]).max()) <= k * np.abs(taps[n]).max() + 2e-3, (img, n)
-        outs[mode] = (dets, layers)
-        det.close()
-    # same arithmetic in the same order; hipcc schedules the SiLU of the two kernels differently (packed / scalar fp32 ops), so a
-    # few results in 10^5 land on the neighbouring fp16 value: at most one ulp apart, and rarely
-    first = "2.cv1" if tail == "1" else "1"
-    for img in range(batch):
-        x, y = outs["0"][1][img][first], outs["1"][1][img][first]
-        assert np.isfinite(y).all()
-        diff = np.abs(x - y)
-        if tail == "0":
-            assert np.all(diff <= 2.0 ** -10 * np.maximum(np.maximum(np.abs(x), np.abs(y)), 2.0 ** -14) * 1.001), float(diff.max())
-            assert (diff > 0).mean() < 1e-3, float((diff > 0).mean())
-        else:                                                   # a 1-ulp difference of layer 1 seen through the 1x1 conv behind it
-            assert diff.max() <= 1e-3 * np.abs(x).max() + 1e-3 and (diff > 0).mean() < 2e-2, (float(diff.max()), float((diff > 0).mean()))
-        a, b = outs["0"][0][img], outs["1"][0][img]
-        assert len(a) == len(b) or abs(len(a) - len(b)) <= 2
-
-
-@pytest.mark.parametrize("tile,size,batch", [(42, 320, 32), (43, 320, 32), (42, 640, 8), (43, 288, 3)])
-def test_weight_stationary_1x1_tiles(pkg, wdir, monkeypatch, tile, size, batch):
-    """conv1x1_ws: a persistent workgroup keeps its cout slice of a 1x1 conv's weights resident in LDS and streams the pixel
-    tiles through a ring that keeps prefetching across tile boundaries.  Forced onto every 1x1 conv where it is legal
-    (cin % 64 == 0, the slice fits LDS, full tiles: pixels % 128 == 0 and cout % BN == 0, no half-resolution source); all
-    layers of the first and the last image against the oracle.  288 x 288 x 3: no map is a multiple of 128 pixels -- the tile
-    is legal nowhere and every conv must fall back to its default tile."""
-    monkeypatch.setenv("RTMODT_TILE_K64", str(tile))
-    monkeypatch.setenv("RTMODT_BNECK", "0")
-    monkeypatch.setenv("RTMODT_TAIL", "0")
-    monkeypatch.setenv("RTMODT_UP_READ", "0")                # the neck's cv1 then has no half-resolution source: legal for this tile too
-    det, w = make_detector(pkg, wdir, "s", size, autotune=False, batch=batch)
-    used = [n for n, _, _ in det.profile(1) if "ws:" in n]
-    assert (len(used) >= 5) if size != 288 else (len(used) == 0), used
-    frames = list(pkg.synth.frames(batch, size, size, seed=91 + tile))
-    det.detect_batch(frames)
-    names = [c.name for c in pkg.weights.spec("s")]
-    for img in sorted({0, batch - 1}):
-        inp, _, _ = det.debug_fetch(img, want_heads=False, want_pred=False)
-        gpu = fetch_layers(pkg, det, names, img)
-        taps = {}
-        Y.forward(inp.astype(np.float32), w, "s", taps=taps, force=gpu)
-        for n in gpu:
-            tol = 2e-3 * np.abs(taps[n]).max() + 2e-3
-            err = float(np.abs(taps[n] - gpu[n]).max())
-            assert err <= tol, f"tile {tile} img {img} layer {n}: max err {err:.4g} > tol {tol:.4g}"
-    det.close()
-
-
-@pytest.mark.parametrize("tile,size,batch,up_read,scale", [(44, 320, 32, "0", "s"), (45, 320, 32, "1", "s"), (46, 320, 32, "1", "s"), (47, 320, 32, "0", "s"),
-                                                                 (44, 640, 8, "1", "s"), (45, 288, 3, "0", "s"),
-                                                                 (44, 64, 8, "1", "s"), (47, 64, 24, "0", "s"),      # 64 x 64: one to twelve pixel tiles per conv -- fewer workgroups than XCDs
-                                                                 (44, 320, 8, "1", "m"), (47, 320, 16, "1", "n"),   # other channel counts (m: 192 / 384 / 576, n: 64 / 128 / 256)
-                                                                 (54, 320, 32, "1", "s"), (54, 640, 8, "0", "s"), (54, 320, 16, "1", "m")])          # 256 x 128, 16 waves, three stages
+@pytest.mark.parametrize("tile,size,batch,up_read,scale", [(T["PT_128x128_S2"], 320, 32, "0", "s"), (T["PT_128x64_S2"], 320, 32, "1", "s"),
+                                                                 (T["PT_128x128_S2"], 640, 8, "1", "s"), (T["PT_128x64_S2"], 288, 3, "0", "s"),
+                                                                 (T["PT_128x128_S2"], 64, 8, "1", "s"), (T["PT_128x64_S2"], 64, 24, "0", "s"),      # 64 x 64: one to twelve pixel tiles per conv -- fewer workgroups than XCDs
+                                                                 (T["PT_128x128_S2"], 320, 8, "1", "m"), (T["PT_128x64_S2"], 320, 16, "1", "n")])   # other channel counts (m: 192 / 384 / 576, n: 64 / 128 / 256)
 def test_persistent_tile_kernel(pkg, wdir, monkeypatch, tile, size, batch, up_read, scale):
     """conv_mfma64_pt: a persistent workgroup walks over pixel tiles of one cout slice; the stage ring keeps prefetching
     across tile boundaries and the epilogue stores straight from the accumulators.  Forced onto every conv where it is legal
@@ -1312,47 +1243,7 @@ def test_converted_checkpoint_through_the_engine(pkg, wdir, tmp_path):
     det.close()
 
 
-@pytest.mark.parametrize("size,batch,tail", [(640, 2, "0"), (640, 2, "1"), (320, 3, "1"), (352, 1, "0")])
-def test_layer1_pixel_pair_form(pkg, wdir, monkeypatch, size, batch, tail):
-    """Layer "1" of YOLOv8s (3x3 / s2, 32 -> 64) as a conv over PIXEL PAIRS: cin 64 = two adjacent input pixels, cout 128 = two
-    adjacent output pixels, half the GEMM rows, weights with the missing taps zeroed; 2.cv1 as its tail runs block-diagonal on
-    the pair rows and lands in a 64-channel slice of the 96-channel concat tensor.  On / off (RTMODT_L1_PAIR) with the tuner
-    out of the way: the non-zero terms meet in the same order and the same 32-wide groups, so every stored layer must be
-    bit-identical between the two forms, and within tolerance of the oracle; 352 -> 88-pixel rows (44 pairs: partial tiles)."""
-    monkeypatch.setenv("RTMODT_TILE", "2")
-    monkeypatch.setenv("RTMODT_BNECK", "0")
-    monkeypatch.setenv("RTMODT_TAIL", tail)
-    frames = list(pkg.synth.frames(batch, size, size, seed=size + batch))
-    names = [c.name for c in pkg.weights.spec("s")]
-    outs = {}
-    for mode in ("0", "1"):
-        monkeypatch.setenv("RTMODT_L1_PAIR", mode)
-        det, w = make_detector(pkg, wdir, "s", size, autotune=False, batch=batch, confidence=0.05)
-        dets = det.detect_batch(frames)
-        prof = [n for n, _, _ in det.profile(1)]
-        assert ("pixel pairs" in prof[1]) == (mode == "1"), prof[:3]
-        layers = []
-        for img in range(batch):
-            inp, _, _ = det.debug_fetch(img, want_heads=False, want_pred=False)
-            gpu = fetch_layers(pkg, det, names, img)
-            assert ("1" in gpu) == (tail == "0") and "2.cv1" in gpu
-            layers.append(gpu)
-            if mode == "1":
-                taps = {}
-                Y.forward(inp.astype(np.float32), w, "s", taps=taps, force=gpu)
-                for n in gpu:
-                    k = 4e-3 if n == "2.cv1" and tail == "1" else 2e-3
-                    assert float(np.abs(taps[n] - gpu[n]).max()) <= k * np.abs(taps[n]).max() + 2e-3, (img, n)
-        outs[mode] = (dets, layers)
-        det.close()
-    for img in range(batch):
-        for n in outs["0"][1][img]:
-            assert np.array_equal(outs["0"][1][img][n].view(np.uint16), outs["1"][1][img][n].view(np.uint16)), (img, n)
-        a, b = outs["0"][0][img], outs["1"][0][img]
-        assert np.array_equal(a.xyxy.view(np.int32), b.xyxy.view(np.int32)) and a.class_id.tolist() == b.class_id.tolist()
-
-
-@pytest.mark.parametrize("tile,size,batch,scale", [(50, 320, 32, "s"), (51, 320, 32, "s"), (52, 320, 16, "s"), (50, 288, 3, "s"), (50, 640, 4, "s"), (51, 320, 8, "m")])
+@pytest.mark.parametrize("tile,size,batch,scale", [(T["ROWS_PT_256x64"], 320, 32, "s"), (T["ROWS_PT_256x64"], 288, 3, "s"), (T["ROWS_PT_256x64"], 640, 4, "s"), (T["ROWS_PT_256x64"], 320, 8, "m")])
 def test_persistent_tap_reuse_kernel(pkg, wdir, monkeypatch, tile, size, batch, scale):
     """conv3x3_rows_stream (TILE_ROWS_PT_*): persistent workgroups walk over the tiles of a launch -- of ALL problems of a grouped
     launch (Detect stage 0: three levels with K = 1152 / 2304 / 4608, stage 1: six convs) -- with the next tile's first strip and
@@ -1364,7 +1255,7 @@ def test_persistent_tap_reuse_kernel(pkg, wdir, monkeypatch, tile, size, batch, 
     monkeypatch.setenv("RTMODT_TAIL", "0")
     frames = list(pkg.synth.frames(batch, size, size, seed=23 + tile))
     names = [c.name for c in pkg.weights.spec(scale)]
-    plain = {50: 39, 51: 38, 52: 41}[tile]                    # the same tile shape on the plain 8-wave tap-reuse kernel
+    plain = T["ROWS_256x64_W8"]                                # the same tile shape on the plain 8-wave tap-reuse kernel
     outs = {}
     for t in (plain, tile):
         monkeypatch.setenv("RTMODT_TILE_3X3S1", str(t))
@@ -1394,12 +1285,12 @@ def test_persistent_tap_reuse_kernel(pkg, wdir, monkeypatch, tile, size, batch, 
 
 
 
-@pytest.mark.parametrize("tile,size,batch,scale", [(57, 320, 32, "s"), (58, 320, 32, "s"), (59, 320, 32, "s"), (62, 320, 32, "s"), (57, 288, 3, "s"), (58, 640, 4, "s"), (62, 288, 3, "s"), (62, 640, 2, "s"), (57, 320, 8, "m"), (58, 320, 5, "n")])
+@pytest.mark.parametrize("tile,size,batch,scale", [(T["PP_256x128"], 320, 32, "s"), (T["PP_256x64"], 320, 32, "s"), (T["PP_256x192"], 320, 32, "s"), (T["PP_512x64"], 320, 32, "s"), (T["PP_256x128"], 288, 3, "s"), (T["PP_256x64"], 640, 4, "s"), (T["PP_512x64"], 288, 3, "s"), (T["PP_512x64"], 640, 2, "s"), (T["PP_256x128"], 320, 8, "m"), (T["PP_256x64"], 320, 5, "n")])
 def test_ping_pong_3x3_kernel(pkg, wdir, monkeypatch, tile, size, batch, scale):
     """conv3x3_pp (TILE_PP_*, csrc/conv_pp.hip): the 3x3 / stride-1 kernel whose two wave halves run one barrier interval apart, forced onto
     every conv where it is legal -- Bottlenecks with their shortcuts (fp32 staging + 16-byte shortcut reads), the grouped Detect launches (a
     workgroup walks tiles of several problems; with the balanced schedule of pp_lpt_schedule), the 192-wide form on Detect stage 0, the 512-position
-    form (tile 62: every wave 64 positions x all 64 couts) -- at batches
+    form (pp:512x64: every wave 64 positions x all 64 couts) -- at batches
     where a workgroup runs several tiles, at 288 x 288 (partial tiles, fewer tiles than workgroups) and on the n / m widths.  Every stored layer
     of the first and the last image against the oracle fed the engine's own inputs."""
     monkeypatch.setenv("RTMODT_BNECK", "0")
@@ -1409,7 +1300,7 @@ def test_ping_pong_3x3_kernel(pkg, wdir, monkeypatch, tile, size, batch, scale):
     names = [c.name for c in pkg.weights.spec(scale)]
     det, w = make_detector(pkg, wdir, scale, size, autotune=False, batch=batch, confidence=0.05)
     used = [n for n, _, _ in det.profile(1) if "pp:" in n]
-    assert len(used) >= (1 if tile == 59 else 6), [n for n, _, _ in det.profile(1)]
+    assert len(used) >= (1 if tile == T["PP_256x192"] else 6), [n for n, _, _ in det.profile(1)]
     det.detect_batch(frames)
     for img in sorted({0, batch - 1}):
         inp, _, _ = det.debug_fetch(img, want_heads=False, want_pred=False)
@@ -1423,7 +1314,7 @@ def test_ping_pong_3x3_kernel(pkg, wdir, monkeypatch, tile, size, batch, scale):
     det.close()
 
 
-@pytest.mark.parametrize("tile,size,batch,up_read,scale", [(60, 320, 32, "1", "s"), (61, 320, 32, "0", "s"), (60, 288, 3, "1", "s"), (60, 640, 2, "1", "s"), (61, 320, 8, "1", "m")])
+@pytest.mark.parametrize("tile,size,batch,up_read,scale", [(T["PPT_256x128"], 320, 32, "1", "s"), (T["PPT_256x128"], 320, 32, "0", "s"), (T["PPT_256x128"], 288, 3, "1", "s"), (T["PPT_256x128"], 640, 2, "1", "s"), (T["PPT_256x128"], 320, 8, "1", "m")])
 def test_ping_pong_tile_kernel(pkg, wdir, monkeypatch, tile, size, batch, up_read, scale):
     """conv_tile_pp (TILE_PPT_*): the ping-pong schedule without tap reuse -- 1x1 convs (incl. the neck layers that read their upsampled channels
     from the half-resolution tensor, up_read = 1) and the 3x3 / stride-2 convs -- forced wherever it is legal (cin % 64 == 0, K >= 192, no shortcut);

@@ -72,8 +72,8 @@ def test_latest_frame_only_and_ids():
 def test_leased_slots_are_never_rewritten():
     """`read(copy=False)` hands out a page-locked ring slot that the detector may still be uploading (or reading in
     place) while a free-running source produces newer frames.  The slot is a lease: the capture thread skips it until
-    `release(frame_id)`; a ring too short for `buffer_size` is refused; running out of leasable slots raises instead of
-    tearing a frame."""
+    `release(frame_id)`; a ring too short for `buffer_size` is refused; running out of leasable slots degrades to a copy (counted in
+    `lease_misses`; the reference's `read` never raises) instead of tearing a frame or failing; `stop()` clears the leases."""
     frames = pkg.synth.frames(7, 48, 64, seed=11)
     with pytest.raises(ValueError):
         ing.FrameReader("ring", backend="synthetic", resolution=(64, 48), frames=frames, ring=HostRing(2, 48, 64))
@@ -94,11 +94,14 @@ def test_leased_slots_are_never_rewritten():
             assert np.array_equal(view, snap) and np.array_equal(view, frames[(fid - 1) % 7]), fid      # untouched while on lease
         newest = r.read()[2]
         assert wait_for(lambda: r.read()[2] > newest)
-        with pytest.raises(RuntimeError):
-            while True:                               # a fourth lease (of a frame in an unleased slot) must be refused
-                ok, f, fid = r.read(copy=False)
-                if fid not in [h[0] for h in held]:
-                    break
+        while True:                                   # a fourth lease (of a frame in an unleased slot) is served by a COPY
+            ok, f, fid = r.read(copy=False)
+            if fid not in [h[0] for h in held]:
+                break
+        assert ok and r.lease_misses >= 1 and r.leased == 3
+        assert not any(np.shares_memory(f, ring.slot(i)) for i in range(ring.slots)) if hasattr(ring, "slot") else True
+        r.release(fid)                                # nothing to give back for a copy: a no-op
+        assert r.leased == 3
         r.release(held[0][0])
         r.release(held[0][0])                         # idempotent
         assert r.leased == 2
@@ -108,6 +111,9 @@ def test_leased_slots_are_never_rewritten():
             r.release(fid_)
         r.release(fid)
         assert r.leased == 0
+        r.read(copy=False)
+        assert r.leased == 1
+    assert r.leased == 0                              # stop() (the context manager's exit) clears what was still on lease
 
 
 def test_read_before_first_frame():

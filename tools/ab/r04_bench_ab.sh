@@ -1,3 +1,6 @@
+# Round 4, run BEFORE the tile table was pruned (ids 57..59 + 62 were the ping-pong tap-reuse tiles, 60 / 61 the ping-pong
+# plain tiles of that table; today: 22..25 and 26).  RTMODT_TUNE_SKIP / RTMODT_TUNE_LDS_PENALTY are rt_diag() switches now:
+# build csrc with `make DIAG=1` to repeat this.  Results: profiles/r04/ab/.
 mkdir -p gpurun_out/r04/ab
 run() { name=$1; shift; env "$@" timeout -k 10 300 python bench.py --steps 30 --warmup 5 --no-verify > gpurun_out/r04/ab/$name.json 2> gpurun_out/r04/ab/$name.err || exit 1; python - <<PY
 import json

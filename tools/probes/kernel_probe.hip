@@ -1,6 +1,7 @@
 // kernel_probe.hip -- DIAGNOSTIC build of single kernels of librtmodt_hip.so with in-kernel phase stamps (s_memtime by lane 0
 // of every workgroup, -DRTMODT_STAMP) on synthetic tensors of the benchmarked shapes; prints per-phase cycle shares and the
-// workgroup timeline.  Read its SHARES, never its run time (the stamps fence the scheduler).
+// workgroup timeline.  Read its SHARES, never its run time (the stamps fence the scheduler).  The modes that timed kernels the
+// round-4 prune removed (pf, ws, l1lines) went with them: their results are in profiles/r03/.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -DRTMODT_STAMP -o /tmp/kernel_probe tools/probes/kernel_probe.hip && /tmp/kernel_probe
 #include <algorithm>
 #include <cstdio>
@@ -9,6 +10,7 @@
 
 #include "../../real-time-multi-object-detection---tracking-system_amd/csrc/bottleneck.hip"
 #include "../../real-time-multi-object-detection---tracking-system_amd/csrc/conv.hip"
+#include "../../real-time-multi-object-detection---tracking-system_amd/csrc/conv_pp.hip"
 
 namespace rtmodt {
 __device__ unsigned long long *g_stamps;
@@ -108,7 +110,7 @@ static int run_conv1x1(int tile, int cin, int cout, int HW, int B) {
     CK(hipEventRecord(e1, nullptr)); CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
     printf("conv 1x1 %d -> %d, %dx%d x %d, tile %s: %.1f us per launch (stamped build)\n", cin, cout, HW, HW, B, tile_name(tile), ms * 1e3 / 5);
-    if (tile_is_ws(tile) || tile_is_pt(tile)) {
+    if (tile_is_pt(tile)) {
         std::vector<unsigned long long> st((size_t)wgs * 16);
         CK(hipMemcpy(st.data(), d_st, st.size() * 8, hipMemcpyDeviceToHost));
         const char *nm[] = {"issue weights + ring prologue", "wait for weights + stage 0 (+barrier)", "step 0", "step 1", "step 2", "step 3", "rest of tile 0 incl. epilogue", "", "remaining tiles"};
@@ -121,7 +123,7 @@ static int run_conv1x1(int tile, int cin, int cout, int HW, int B) {
             printf("  %-40s median %8.0f clk\n", nm[k - 1], d[d.size() / 2]);
         }
     }
-    if (tile_needs_cin64(tile) && !tile_is_ws(tile) && !tile_is_pt(tile) && !tile_is_rows(tile)) {      // conv_mfma64_body: 0 = loop entry, 1..5 = k-steps 0..4 (after the barrier), 6 = loop exit, 9 = end
+    if (tile_needs_cin64(tile) && !tile_is_pt(tile) && !tile_is_pp(tile) && !tile_is_ppt(tile) && !tile_is_rows(tile)) {      // conv_mfma64_body: 0 = loop entry, 1..5 = k-steps 0..4 (after the barrier), 6 = loop exit, 9 = end
         std::vector<unsigned long long> st((size_t)wgs * 16);
         CK(hipMemcpy(st.data(), d_st, st.size() * 8, hipMemcpyDeviceToHost));
         const char *nm[] = {"prologue -> step 0 ready", "step 0", "step 1", "step 2", "step 3", "rest of the k-loop", "epilogue: everybody out of the loop", "epilogue: bias + SiLU + LDS staging", "epilogue: barrier"};
@@ -340,29 +342,20 @@ static int run_energy(int tile, int ks, int cin, int cout, int HW, int B, double
 int main(int argc, char **argv) {
     if (argc > 1 && !strcmp(argv[1], "energy")) {
         const double secs = argc > 2 ? atof(argv[2]) : 1.5;
-        for (int t : {TILE_K64_128x128_S2_W8, TILE_PT_128x128_S2, TILE_K64_256x128_S2_W8, TILE_128x128, TILE_128x64, TILE_WS_128x128, TILE_K64_128x128_S3_W8,
-                      TILE_K64_128x128_S2, TILE_K64_128x128_S2W, TILE_K64_256x128_S2, TILE_K64_128x128_S3})      // (the last four: 4 waves, 64 x 64 or 32 x 128 per wave)
+        for (int t : {TILE_K64_128x128_S2_W8, TILE_PT_128x128_S2, TILE_PPT_256x128, TILE_128x128, TILE_128x64, TILE_K64_128x128_S3_W8})
             if (run_energy(t, 1, 512, 256, 40, 32, secs)) return 1;                      // 6.cv2
-        for (int t : {TILE_K64_128x128_S2_W8, TILE_PT_128x128_S2, TILE_K64_256x128_S2_W8, TILE_128x64, TILE_WS_128x128})
+        for (int t : {TILE_K64_128x128_S2_W8, TILE_PT_128x128_S2, TILE_128x64})
             if (run_energy(t, 1, 256, 128, 80, 32, secs)) return 1;                      // 4.cv2
-        for (int t : {TILE_ROWS_256x64_W8, TILE_ROWS_128x64_W8, TILE_ROWS_K64_256x64_W8, TILE_ROWS_K64_128x128_W8, TILE_PT_128x128_S2, TILE_K64_128x128_S2_W8, TILE_K64_256x128_S2_W8})
+        for (int t : {TILE_ROWS_256x64_W8, TILE_ROWS_128x64_W8, TILE_PP_256x128, TILE_PT_128x128_S2, TILE_K64_128x128_S2_W8})
             if (run_energy(t, 3, 128, 128, 40, 32, secs)) return 1;                      // 6.m / 12.m / 18.m
         return 0;
     }
     if (argc > 1 && !strcmp(argv[1], "rows")) {                                  // 3x3 stride-1 convs on the tap-reuse kernel (stamps 0..6)
-        const int t6[] = {TILE_ROWS_256x64_W8, TILE_ROWS_128x64_W8, TILE_ROWS_K64_256x64_W8};
+        const int t6[] = {TILE_ROWS_256x64_W8, TILE_ROWS_128x64_W8, TILE_ROWS_PT_256x64};
         for (int t : t6) if (run_conv3(t, 128, 128, 1, 40, 32, 0)) return 1;      // 6.m / 12.m / 18.m
         for (int t : t6) if (run_conv3(t, 64, 64, 1, 80, 32, 0)) return 1;        // 4.m / 15.m
         for (int t : t6) if (run_conv3(t, 128, 64, 1, 80, 32, 0)) return 1;       // Detect cv2.0 at P3
         for (int t : t6) if (run_conv3(t, 256, 128, 1, 40, 32, 0)) return 1;      // Detect cv3.0 at P4
-        return 0;
-    }
-    if (argc > 1 && !strcmp(argv[1], "l1lines")) {
-        // Is layer 1 held back by its 64-byte (half-line) requests?  A surrogate with the SAME bytes and FLOPs whose pixels are whole
-        // 128-byte lines: the 320 x 320 x 32 input viewed as 320 x 160 pixel pairs of 64 channels, 3x3 / stride 2 -> 160 x 80 x 64.
-        if (run_conv3(TILE_128x64, 32, 64, 2, 320, 32, 0)) return 1;                       // layer 1 as it is (no tail)
-        for (int t : {TILE_K64_128x64_S3, TILE_K64_128x64_S3_W8, TILE_K64_64x64_S3, TILE_PT_128x64_S2, TILE_PT_128x64_S3})
-            if (run_conv3(t, 64, 64, 2, 320, 32, 0, 160)) return 1;
         return 0;
     }
     if (argc > 1 && !strcmp(argv[1], "l1")) {
@@ -375,32 +368,13 @@ int main(int argc, char **argv) {
     if (argc > 1 && !strcmp(argv[1], "pt")) {                                     // persistent tiles against the plain 8-wave tile kernel
         const int shapes[][3] = {{256, 256, 40}, {512, 256, 40}, {384, 128, 80}, {768, 512, 20}};
         for (auto &sh : shapes)
-            for (int t : {TILE_K64_128x128_S2_W8, TILE_PT_128x128_S2, TILE_PT_128x128_S3, TILE_PT_128x64_S3})
+            for (int t : {TILE_K64_128x128_S2_W8, TILE_PT_128x128_S2, TILE_PT_128x64_S2})
                 if (run_conv1x1(t, sh[0], sh[1], sh[2], 32)) return 1;
         return 0;
     }
     if (argc > 1 && !strcmp(argv[1], "ksteps")) {                                 // k-step time of the 64-deep tile kernels by tile shape (stamped build)
-        for (int t : {TILE_K64_128x128_S2, TILE_K64_PF_128x128_S2, TILE_K64_128x128_S2_W8, TILE_K64_128x128_S3_W8, TILE_K64_256x128_S2_W8, TILE_K64_256x128_S3_W8, TILE_K64_PF_256x128_S3_W8,
-                      TILE_K64_256x256_S2_W8, TILE_K64_128x64_S3_W8, TILE_K64_64x64_S3, TILE_K64_64x64_S4})
+        for (int t : {TILE_K64_128x128_S2_W8, TILE_K64_128x128_S3_W8, TILE_K64_256x64_S2_W8, TILE_K64_128x64_S3_W8, TILE_K64_64x64_S3})
             if (run_conv1x1(t, 768, 256, 40, 32)) return 1;
-        return 0;
-    }
-    if (argc > 1 && !strcmp(argv[1], "pf")) {                                     // the software-pipelined k-loop against the plain tile kernels
-        const int shapes[][3] = {{256, 256, 40}, {512, 256, 40}, {384, 128, 80}, {768, 256, 40}};
-        for (auto &sh : shapes)
-            for (int t : {TILE_K64_128x128_S2, TILE_K64_PF_128x128_S2, TILE_K64_128x128_S2_W8, TILE_PT_128x128_S2, TILE_K64_256x128_S3_W8, TILE_K64_PF_256x128_S3_W8})
-                if (run_conv1x1(t, sh[0], sh[1], sh[2], 32)) return 1;
-        for (int t : {TILE_K64_128x128_S2, TILE_K64_PF_128x128_S2, TILE_K64_128x128_S2_W8, TILE_PT_128x128_S2, TILE_K64_256x128_S3_W8, TILE_K64_PF_256x128_S3_W8, TILE_ROWS_K64_256x64_W8}) {
-            if (run_conv3(t, 128, 128, 1, 40, 32, 0)) return 1;                  // 6.m / 12.m / 18.m
-            if (run_conv3(t, 128, 256, 2, 80, 32, 0)) return 1;                  // layer 5
-        }
-        return 0;
-    }
-    if (argc > 1 && !strcmp(argv[1], "ws")) {
-        if (run_conv1x1(TILE_WS_128x128, 256, 128, 80, 32)) return 1;          // 4.cv2 at 32 frames
-        if (run_conv1x1(TILE_128x64, 256, 128, 80, 32)) return 1;
-        if (run_conv1x1(TILE_WS_128x128, 256, 256, 40, 32)) return 1;          // 6.cv1
-        if (run_conv1x1(TILE_K64_128x128_S2_W8, 256, 256, 40, 32)) return 1;
         return 0;
     }
     if (run_bneck(32, 160, 16, true)) return 1;
