@@ -221,10 +221,10 @@ def verify_outputs(pkg, det, frame_ptrs, size, max_det, weights, scale):
         if not np.allclose(pred, Y.decode(maps), rtol=2e-4, atol=2e-4):
             raise SystemExit(f"bench self-check FAILED: image {img}: decode differs from the oracle on the engine's own head logits")
     launches = [n for n, _, _ in det.profile(1)]
-    fam = {"conv_mfma64_pt": sum(" pt:" in n or ", pt:" in n or "[pt:" in n for n in launches), "conv3x3_rows(_grp)": sum("rows" in n for n in launches),
-           "conv3x3_rows_stream": sum("rows-pt:" in n or "rows64-pt:" in n for n in launches), "16-wave tiles": sum("/16w" in n for n in launches),
-           "bottleneck_fused": sum("bottleneck" in n for n in launches), "conv_mfma_tail": sum("tail:" in n for n in launches),
-           "8-wave tiles": sum("/8w" in n for n in launches), "head_final": sum("head_final" in n for n in launches)}
+    fam = {"conv3x3_pp": sum("pp:" in n and "ppt:" not in n for n in launches) + sum(n.count("pp:") - 1 for n in launches if n.count("pp:") > 1 and "ppt:" not in n),
+           "conv_tile_pp": sum("ppt:" in n for n in launches), "conv_mfma64_pt": sum("tile pt:" in n or ", pt:" in n or "[pt:" in n for n in launches),
+           "conv3x3_rows": sum("rows" in n for n in launches), "bottleneck_fused": sum("fused bottleneck" in n for n in launches),
+           "conv_mfma_tail": sum("tail:" in n for n in launches), "8-wave tiles": sum("/8w" in n for n in launches), "head_final": sum("head_final" in n for n in launches)}
     return {"ok": True, "images": n_img, "boxes": n_box,
             "what": "fetched detections == oracle non_max_suppression + scale_boxes on the engine's pre-NMS tensor (bit-exact), every image of one batch",
             "layers_ok": True, "layers_checked": checked, "layer_images": images,

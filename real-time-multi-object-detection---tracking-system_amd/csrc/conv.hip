@@ -762,161 +762,6 @@ __global__ __launch_bounds__(NW * 64) void conv_mfma64_pt(ConvArgs p, int groups
 }
 
 
-// ---------------------------------------------------------------------------------------
-// conv3x3_rows_stream: the tap-reuse kernel with PERSISTENT workgroups (TILE_ROWS_PT_*).  A workgroup walks over the
-// launch-linear tile ids id0, id0 + G, id0 + 2 G, ... of a (grouped) launch; the (tile, super-step) pairs form ONE stream of
-// steps through the two-stage ring, so the first strip and weights of the next tile are in flight while the last super-step
-// of this tile is multiplied and its epilogue runs (a plain workgroup starts with an empty ring: ~2 600 clk before its first
-// MFMA, then 3 - 12 super-steps of ~2 000 clk at K = 576 - 1152: kernel_probe stamps).  The epilogue stores straight from the
-// accumulators (store_tile), so it needs no LDS and cannot collide with the prefetch.  Ids ascend through the problems, which
-// are sorted deepest K first: every workgroup's first tiles are the long ones.  G is a multiple of 8, so a workgroup's tiles
-// stay on the ids of one XCD (xcd_tile).  Same arithmetic and k order as conv3x3_rows_body: bit-identical results.
-// ---------------------------------------------------------------------------------------
-template <int BM, int BN, int WM, int WN, bool K64>
-__global__ __launch_bounds__(512) void conv3x3_rows_stream(ConvGroupArgs g, int total_ids) {
-    constexpr int NW = WM * WN;
-    static_assert(NW == 8, "8 waves");
-    constexpr int RP = K64 ? 8 : 16, RB = K64 ? 128 : 64, BK = K64 ? 64 : 32;
-    constexpr int NAS = BM / RP + 1, NBT = BN / RP, NP = NAS + 3 * NBT, STAGE = NP * 1024;
-    constexpr int TM = BM / WM / 16, TN = BN / WN / 16, TILE_BYTES = 16 * RB;
-    constexpr int LA = (NAS + NW - 1) / NW, LB = (3 * NBT + NW - 1) / NW;
-    __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * STAGE];
-
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int r = lane & 15, q = lane >> 4;
-    const int wm = wave / WN, wn = wave % WN;
-    auto lds_off = [](int R, int c) -> int {
-        if (K64) return (R >> 3) * 1024 + (R & 7) * 128 + ((c ^ ((R >> 1) & 7)) << 4);
-        return (R >> 4) * 1024 + (R & 15) * 64 + ((c ^ swz16(R)) << 4);
-    };
-    const int ld_row = K64 ? lane >> 3 : lane >> 2, ld_slot = K64 ? lane & 7 : lane & 3;
-    int a_rd[3][K64 ? 2 : 1], b_rd[K64 ? 2 : 1];
-#pragma unroll
-    for (int kw = 0; kw < 3; ++kw)
-#pragma unroll
-        for (int kk = 0; kk < (K64 ? 2 : 1); ++kk) a_rd[kw][kk] = lds_off(r + kw, kk * 4 + q);
-#pragma unroll
-    for (int kk = 0; kk < (K64 ? 2 : 1); ++kk) b_rd[kk] = lds_off(r, kk * 4 + q);
-
-    // one tile of one problem: where it is, and the DMA sources of this lane's pieces; (kh, c0) = the next super-step to issue
-    struct Tile { int z, m0, n0, ns, kh, c0, a_off[LA], b_off[LB]; };
-    const int G = gridDim.x;
-    // launch-linear id -> (problem, tile); false for the alignment fillers between problems
-    auto locate = [&](int id, Tile &t) -> bool {
-        int z = 0;
-        while (z + 1 < g.n && id >= g.start[z + 1]) ++z;
-        id -= g.start[z];
-        const ConvArgs &p = g.p[z];
-        const int gx = g.gx[z], gy = (p.cout + BN - 1) / BN;
-        if (id >= gx * gy) return false;
-        const int by = id / gx, bx = id - by * gx;
-        int mt, nt;
-        xcd_tile(gx, gy, bx, by, mt, nt);
-        t.z = z; t.m0 = mt * BM; t.n0 = nt * BN; t.ns = 3 * (p.cin / BK); t.kh = 0; t.c0 = 0;
-#pragma unroll
-        for (int i = 0; i < LA; ++i) {
-            const int R = (wave + NW * i) * RP + ld_row;
-            const int chunk = K64 ? (ld_slot ^ ((R >> 1) & 7)) : (ld_slot ^ swz16(R));
-            t.a_off[i] = rows_pos(p, t.m0 + R) | (chunk << 28);
-        }
-#pragma unroll
-        for (int i = 0; i < LB; ++i) {
-            const int pc = wave + NW * i;
-            const int kw = pc / NBT, R = (pc - kw * NBT) * RP + ld_row;
-            const int chunk = K64 ? (ld_slot ^ ((R >> 1) & 7)) : (ld_slot ^ swz16(R));
-            t.b_off[i] = (t.n0 + R) * p.kp + kw * p.cin + chunk * 8;
-        }
-        return true;
-    };
-    auto next_valid = [&](int id, Tile &t) -> int {          // first id >= `id` on this workgroup's stride that is a tile; total_ids when none
-        for (; id < total_ids; id += G)
-            if (locate(id, t)) return id;
-        return total_ids;
-    };
-    auto issue = [&](Tile &t, int stage) {                    // the super-step (t.kh, t.c0) of tile t -> ring stage
-        const ConvArgs &p = g.p[t.z];
-        unsigned char *sbase = lds + stage * STAGE;
-        const int row_shift = t.kh * p.in_Wp, last_pix = p.last_pos;
-#pragma unroll
-        for (int i = 0; i < LA; ++i) {
-            if (wave + NW * i < NAS) {
-                const int pix = min((t.a_off[i] & 0x0FFFFFFF) + row_shift, last_pix);
-                glds16(p.in + ((long)pix * p.in_cs + t.c0 + (t.a_off[i] >> 28) * 8), sbase + (wave + NW * i) * 1024);
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < LB; ++i)
-            if (wave + NW * i < 3 * NBT) glds16(p.wt + (t.b_off[i] + t.kh * 3 * p.cin + t.c0), sbase + (NAS + wave + NW * i) * 1024);
-        t.c0 += BK;
-        if (t.c0 >= p.cin) { t.c0 = 0; ++t.kh; }
-    };
-
-    Tile cur, nxt;
-    int id = next_valid(blockIdx.x, cur);
-    if (id >= total_ids) return;
-    issue(cur, 0);
-    int stage = 0;
-    while (true) {
-        const int nid = next_valid(id + G, nxt);
-        const bool have_next = nid < total_ids;
-        const ConvArgs &p = g.p[cur.z];
-        floatx4 acc[TM][TN], bv[TN];
-#pragma unroll
-        for (int t = 0; t < TM; ++t)
-#pragma unroll
-            for (int u = 0; u < TN; ++u) acc[t][u] = floatx4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int u = 0; u < TN; ++u) bv[u] = *(const floatx4 *)(p.bias + cur.n0 + (wn * TN + u) * 16 + q * 4);
-        for (int st = 0; st < cur.ns; ++st) {
-            wait_vmcnt<0>();                                 // this step's stage has landed (and the previous tile's stores have left)
-            __builtin_amdgcn_s_barrier();                    // ... for every wave; everyone is done reading the other stage
-            asm volatile("" ::: "memory");
-            if (st + 1 < cur.ns) issue(cur, stage ^ 1);
-            else if (have_next) issue(nxt, stage ^ 1);       // the next tile's first operands fly under this tile's last step and epilogue
-            const unsigned char *sA = lds + stage * STAGE + wm * TM * TILE_BYTES;
-            const unsigned char *sB = lds + stage * STAGE + NAS * 1024 + wn * TN * TILE_BYTES;
-#pragma unroll
-            for (int kw = 0; kw < 3; ++kw)
-#pragma unroll
-                for (int kk = 0; kk < (K64 ? 2 : 1); ++kk) {
-                    half8 fa[TM], fb[TN];
-#pragma unroll
-                    for (int t = 0; t < TM; ++t) fa[t] = *(const half8 *)(sA + t * TILE_BYTES + a_rd[kw][kk]);
-#pragma unroll
-                    for (int u = 0; u < TN; ++u) fb[u] = *(const half8 *)(sB + kw * NBT * 1024 + u * TILE_BYTES + b_rd[kk]);
-#pragma unroll
-                    for (int t = 0; t < TM; ++t)
-#pragma unroll
-                        for (int u = 0; u < TN; ++u)
-                            acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[u], fa[t], acc[t][u], 0, 0, 0);
-                }
-            stage ^= 1;
-        }
-        // ---- epilogue: padded position -> (b, y, x); border rows / columns are junk (conv3x3_rows_body's direct-store path) ----
-        const int HW = p.Ho * p.rows_wq;
-#pragma unroll
-        for (int t = 0; t < TM; ++t) {
-            const int m = cur.m0 + (wm * TM + t) * 16 + r;
-            if (m >= p.M) continue;
-            const int b = fdiv(m, p.d_hwp), rem = m - b * HW;
-            const int oy = fdiv(rem, p.d_wp), ox = rem - oy * p.rows_wq;
-            if (oy >= p.Ho || ox >= p.Wo) continue;
-            const long opix = ((long)(b * p.out_Hp + oy + p.out_pad) * p.out_Wp + ox + p.out_pad) * p.out_cs;
-            const long rpix = p.res ? ((long)(b * p.res_Hp + oy + p.res_pad) * p.res_Wp + ox + p.res_pad) * p.res_cs : 0;
-            const long opix2 = upsampled_offset(p, b, oy, ox);
-#pragma unroll
-            for (int u = 0; u < TN; ++u) {
-                const int n = cur.n0 + (wn * TN + u) * 16 + q * 4;
-                if (n < p.cout) store_tile(p, acc[t][u], bv[u], opix, rpix, n, opix2);
-            }
-        }
-        if (!have_next) break;
-        cur = nxt;
-        id = nid;
-    }
-}
-
 template <int BM, int BN, int WM, int WN, int NSTAGE, bool GENERAL>
 __global__ __launch_bounds__(256) void conv_mfma(ConvArgs p) { conv_mfma_body<BM, BN, WM, WN, NSTAGE, GENERAL>(p, blockIdx.x, blockIdx.y); }
 template <int BM, int BN, int WM, int WN, int NSTAGE, bool GENERAL>
@@ -972,18 +817,17 @@ __global__ __launch_bounds__(256) void conv_mfma_wsk_grp(ConvGroupArgs g) {
 const char *tile_name(int tile) {
     static const char *names[TILE_COUNT] = {"128x128s3", "128x64s3", "64x64s3", "256x32s3", "64x128s3", "wsk64x64", "wsk32x64", "wsk64x32",
                                             "k64:64x64s3", "rows:128x32", "rows64:64x64", "tail:128x64", "tail:k64:128x128",
-                                            "k64:128x128s2/8w", "k64:128x128s3/8w", "k64:128x64s3/8w", "k64:256x64s2/8w", "rows:128x64/8w", "rows:256x64/8w",
-                                            "pt:128x128s2", "pt:128x64s2", "rows-pt:256x64", "pp:256x128", "pp:256x64", "pp:256x192", "pp:512x64", "ppt:256x128"};
+                                            "k64:128x128s2/8w", "k64:128x128s3/8w", "k64:128x64s3/8w", "k64:256x64s2/8w", "rows:256x64/8w",
+                                            "pt:128x128s2", "pt:128x64s2", "pp:256x128", "pp:256x64", "pp:256x192", "pp:512x64", "ppt:256x128"};
     return tile >= 0 && tile < TILE_COUNT ? names[tile] : "?";
 }
 
 bool tile_is_w8(int tile) { return tile >= TILE_K64_128x128_S2_W8 && tile <= TILE_K64_256x64_S2_W8; }
 bool tile_is_pt(int tile) { return tile == TILE_PT_128x128_S2 || tile == TILE_PT_128x64_S2; }
 bool tile_is_tail(int tile) { return tile == TILE_TAIL_128x64 || tile == TILE_TAIL_K64_128x128; }
-bool tile_is_rows_pt(int tile) { return tile == TILE_ROWS_PT_256x64; }
 bool tile_is_pp(int tile) { return tile >= TILE_PP_256x128 && tile <= TILE_PP_512x64; }
 bool tile_is_ppt(int tile) { return tile == TILE_PPT_256x128; }
-bool tile_is_rows(int tile) { return tile == TILE_ROWS_128x32 || tile == TILE_ROWS_K64_64x64 || tile == TILE_ROWS_128x64_W8 || tile == TILE_ROWS_256x64_W8 || tile_is_rows_pt(tile) || tile_is_pp(tile); }
+bool tile_is_rows(int tile) { return tile == TILE_ROWS_128x32 || tile == TILE_ROWS_K64_64x64 || tile == TILE_ROWS_256x64_W8 || tile_is_pp(tile); }
 bool tile_needs_cin64(int tile) {
     return tile == TILE_K64_64x64_S3 || tile == TILE_ROWS_K64_64x64 || tile == TILE_TAIL_K64_128x128 || tile_is_w8(tile) || tile_is_pt(tile) || tile_is_pp(tile) || tile_is_ppt(tile);
 }
@@ -1008,11 +852,9 @@ TileShape tile_shape(int tile) {
         case TILE_K64_128x128_S2_W8: case TILE_K64_128x128_S3_W8: return {128, 128};
         case TILE_K64_128x64_S3_W8: return {128, 64};
         case TILE_K64_256x64_S2_W8: return {256, 64};
-        case TILE_ROWS_128x64_W8: return {128, 64};
         case TILE_ROWS_256x64_W8: return {256, 64};
         case TILE_PT_128x128_S2: return {128, 128};
         case TILE_PT_128x64_S2: return {128, 64};
-        case TILE_ROWS_PT_256x64: return {256, 64};
         case TILE_PP_256x128: return {256, 128};
         case TILE_PP_256x64: return {256, 64};
         case TILE_PP_256x192: return {256, 192};
@@ -1085,18 +927,6 @@ static void launch_rows_w8(const LaunchPlan &l, hipStream_t s) {
         grid = l.group(g, BM, BN);
         hipLaunchKernelGGL((conv3x3_rows_w8_grp<BM, BN, WM, WN, K64>), grid, dim3(512), 0, s, g);
     }
-}
-
-// persistent tap-reuse kernel: two workgroups per CU walk over all the tiles of the (grouped) launch
-template <int BM, int BN, int WM, int WN, bool K64>
-static void launch_rows_pt(const LaunchPlan &l, hipStream_t s) {
-    ConvGroupArgs g;
-    const dim3 all = l.group(g, BM, BN);                   // launch-linear ids of every problem's tiles (with the alignment fillers)
-    constexpr int stage_kib = (BM / (K64 ? 8 : 16) + 1 + 3 * (BN / (K64 ? 8 : 16)));
-    const int per_cu = std::max(1, std::min(2, 160 / (2 * stage_kib)));
-    int G = std::min((int)all.x, per_cu * device_cus());
-    if (G >= 8) G &= ~7;                                   // a workgroup's ids keep their residue mod 8: one XCD's share of the tile order
-    hipLaunchKernelGGL((conv3x3_rows_stream<BM, BN, WM, WN, K64>), dim3(G), dim3(512), 0, s, g, (int)all.x);
 }
 
 template <int BM, int BN, int WM, int WN, int NSTAGE>
@@ -1265,13 +1095,11 @@ int launch_conv_group(const ConvLaunch *c, int n, int tile, hipStream_t s) {
         case TILE_K64_64x64_S3: launch_k64<64, 64, 2, 2, 3>(l, s); break;
         case TILE_ROWS_128x32: launch_rows<128, 32, 4, 1, false>(l, s); break;
         case TILE_ROWS_K64_64x64: launch_rows<64, 64, 2, 2, true>(l, s); break;
-        case TILE_ROWS_128x64_W8: launch_rows_w8<128, 64, 4, 2, false>(l, s); break;
         case TILE_ROWS_256x64_W8: launch_rows_w8<256, 64, 4, 2, false>(l, s); break;
         case TILE_K64_128x128_S2_W8: RT_TRY((launch_k64_w8<128, 128, 4, 2, 2>(l, s))); break;
         case TILE_K64_128x128_S3_W8: RT_TRY((launch_k64_w8<128, 128, 4, 2, 3>(l, s))); break;
         case TILE_K64_128x64_S3_W8: RT_TRY((launch_k64_w8<128, 64, 4, 2, 3>(l, s))); break;
         case TILE_K64_256x64_S2_W8: RT_TRY((launch_k64_w8<256, 64, 8, 1, 2>(l, s))); break;
-        case TILE_ROWS_PT_256x64: launch_rows_pt<256, 64, 4, 2, false>(l, s); break;
         case TILE_PP_256x128: RT_TRY(launch_conv3x3_pp(a, n, 128, s)); break;
         case TILE_PP_256x64: RT_TRY(launch_conv3x3_pp(a, n, 64, s)); break;
         case TILE_PP_256x192: RT_TRY(launch_conv3x3_pp(a, n, 192, s)); break;

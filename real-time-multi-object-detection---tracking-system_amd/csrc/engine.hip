@@ -167,7 +167,7 @@ struct Op {
 
 using namespace rtmodt;
 
-constexpr int N_EXEC = 4;       // executable instances per captured graph of the plain / chained engines (capture_chain)
+constexpr int N_EXEC = 2;       // executable instances per captured graph of the plain / chained engines, alternating between successive batches (capture_chain)
 
 struct rtmodt_detector {
     rtmodt_det_cfg cfg{};
@@ -1151,11 +1151,13 @@ static int capture_chain(rtmodt_detector *d, int c) {
     hipError_t e = hipStreamEndCapture(main, &d->graphs[c]);
     RT_TRY(rc);
     RT_HIP(e);
-    // N_EXEC executable instances per graph, used round-robin by successive batches, so that an instance is never launched again while an earlier
-    // launch of it can still be running (the caller keeps at most three batches in flight).  Relaunching a running instance makes the runtime wait
-    // for it before submitting -- and under rocprofv3 --kernel-trace it segfaults inside hipGraphLaunch, a race that depends on how far the host runs
-    // ahead: with two alternating instances the 100-step bench crashed at launch ~200-310 three times out of four, with ONE instance every time, and
-    // never with instances that were not in flight (eager launches, the staged engine, re-instantiated executables): profiles/r04/rocprof_plain100/
+    // N_EXEC executable instances per graph, alternating between successive batches: relaunching an instance whose previous launch is still
+    // running makes the runtime wait for it before submitting.
+    // (rocprofv3 --kernel-trace segfaulting inside hipGraphLaunch on this engine after 200-300 launches is NOT a property of the engine: a
+    // stand-alone program that launches one captured graph of 45 spinning kernels 1 000 times dies with the same stack, and with the HIP
+    // runtime's AQL packet capture for graphs switched off -- DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 -- the engine's 100-step trace completes:
+    // tools/probes/graph_trace_repro.hip, profiles/r04/graph_trace_repro/.  Round 4 first blamed in-flight relaunches and rotated four
+    // instances; the collection run crashed all the same.)
     for (int k = 0; k < N_EXEC; ++k) RT_HIP(hipGraphInstantiate(&d->graph_execs[N_EXEC * c + k], d->graphs[c], nullptr, nullptr, 0));
     return RTMODT_OK;
 }
@@ -1301,17 +1303,7 @@ static int capture_graph(rtmodt_detector *d) {
 
 // stem output -> dense per-anchor candidates of a single-chain detector, on the main stream
 static int forward_graphs(rtmodt_detector *d) {
-    const int inst = rt_diag("ONE_EXEC") ? 0 : (int)(d->batch_no % N_EXEC);   // successive batches, successive instances
-#ifdef RTMODT_DIAG
-    // diagnostic build (rocprofv3 --kernel-trace segfaults inside hipGraphLaunch on this engine after ~200 launches): which launch
-    // it is, and whether executables that are re-instantiated every N launches get past it (an accumulation per executable in the runtime / profiler)
-    static const int dbg_count = rt_diag("DEBUG_GRAPH_COUNT") ? 1 : 0, dbg_reinst = rt_diag("DEBUG_REINST") ? atoi(rt_diag("DEBUG_REINST")) : 0;
-    if (dbg_count && d->batch_no % 8 == 0) fprintf(stderr, "[graph] launch %lld\n", (long long)d->batch_no);
-    if (dbg_reinst > 0 && d->batch_no > 0 && d->batch_no % dbg_reinst == 0) {
-        RT_HIP(hipStreamSynchronize(d->stream));
-        for (int k = 0; k < N_EXEC; ++k) { RT_HIP(hipGraphExecDestroy(d->graph_execs[k])); RT_HIP(hipGraphInstantiate(&d->graph_execs[k], d->graphs[0], nullptr, nullptr, 0)); }
-    }
-#endif
+    const int inst = (int)(d->batch_no % N_EXEC);   // successive batches, successive instances
     RT_HIP(hipGraphLaunch(d->graph_execs[inst], d->stream));
     return run_decode(d);
 }
@@ -1324,7 +1316,7 @@ static int forward_graphs(rtmodt_detector *d) {
 // (needed when the next batch's whole-batch letterbox would overwrite an image tensor a lagging chain still reads).
 static int forward_chains(rtmodt_detector *d, rtmodt_detector::Slot &sl, bool host_frames, bool join_main) {
     const int C = d->n_chains, nb = d->B / C;
-    const int inst = rt_diag("ONE_EXEC") ? 0 : (int)(d->batch_no % N_EXEC);
+    const int inst = (int)(d->batch_no % N_EXEC);
     for (int c = 0; c < C; ++c) {
         hipStream_t st = d->chain_streams[c];
         if (c > 0) {

@@ -43,9 +43,9 @@ struct TensorView {
 };
 
 // Tile configurations of the conv kernels (conv.hip, conv_pp.hip).  Round 4 pruned the table to what the autotuner picks somewhere between 1 and 32
-// frames per launch on the n / s / m widths (profiles/r04/tuner_wins.txt) plus the tiles the general (cin % 32 != 0) path needs; the families that lost
+// frames per launch on the n / s / m widths (profiles/r04/tuner_wins_*.txt: 23 of the 25 win somewhere) plus the tiles the general (cin % 32 != 0) path needs; the families that lost
 // every A/B -- weight-stationary 1x1, software-pipelined k-loop, 16-wave and 144-KiB one-per-CU tiles, deeper 32-deep rings, the 4-wave 64-deep
-// variants -- are gone from the library (their measurements stay under profiles/r02, r03).
+// variants, the persistent and the 128-row 8-wave tap-reuse tiles -- are gone from the library (their measurements stay under profiles/r02, r03).
 enum ConvTile {
     TILE_128x128 = 0, TILE_128x64 = 1, TILE_64x64 = 2, TILE_256x32 = 3, TILE_64x128 = 4,   // 4 waves share one tile, 32-deep k-steps, three stages (any cin % 8 == 0)
     TILE_WSK_64x64 = 5, TILE_WSK_32x64 = 6, TILE_WSK_64x32 = 7,                           // 4 waves split K over one tile (small-M layers)
@@ -53,19 +53,17 @@ enum ConvTile {
     TILE_ROWS_128x32 = 9, TILE_ROWS_K64_64x64 = 10,                                       // 3x3/s1 tap-reuse kernel, 4 waves (32- / 64-deep chunks)
     TILE_TAIL_128x64 = 11, TILE_TAIL_K64_128x128 = 12,                                    // conv + fused 1x1 tail (BN == cout)
     TILE_K64_128x128_S2_W8 = 13, TILE_K64_128x128_S3_W8 = 14, TILE_K64_128x64_S3_W8 = 15, TILE_K64_256x64_S2_W8 = 16,   // 64-deep, 8 waves per workgroup
-    TILE_ROWS_128x64_W8 = 17, TILE_ROWS_256x64_W8 = 18,                                   // tap-reuse kernel, 8 waves
-    TILE_PT_128x128_S2 = 19, TILE_PT_128x64_S2 = 20,                                      // PERSISTENT 64-deep tile kernel: a workgroup walks over pixel tiles, the ring keeps prefetching across tile boundaries
-    TILE_ROWS_PT_256x64 = 21,                                                             // PERSISTENT tap-reuse kernel (8 waves, groups allowed)
+    TILE_ROWS_256x64_W8 = 17,                                                             // tap-reuse kernel, 8 waves
+    TILE_PT_128x128_S2 = 18, TILE_PT_128x64_S2 = 19,                                      // PERSISTENT 64-deep tile kernel: a workgroup walks over pixel tiles, the ring keeps prefetching across tile boundaries
     // 3x3 / stride-1 PING-PONG kernel (conv_pp.hip): one persistent 8-wave workgroup per CU, its two halves one barrier interval apart (one reads +
     // issues DMA while the other multiplies), tap reuse; 256 positions x BN couts, or 512 positions x 64 couts (the wide form for 64-cout convs)
-    TILE_PP_256x128 = 22, TILE_PP_256x64 = 23, TILE_PP_256x192 = 24, TILE_PP_512x64 = 25,
-    TILE_PPT_256x128 = 26,                                                                // the ping-pong schedule without tap reuse (1x1, 3x3 stride 2): one conv per launch, cin % 64 == 0, K >= 192
-    TILE_COUNT = 27
+    TILE_PP_256x128 = 20, TILE_PP_256x64 = 21, TILE_PP_256x192 = 22, TILE_PP_512x64 = 23,
+    TILE_PPT_256x128 = 24,                                                                // the ping-pong schedule without tap reuse (1x1, 3x3 stride 2): one conv per launch, cin % 64 == 0, K >= 192
+    TILE_COUNT = 25
 };
 const char *tile_name(int tile);
 bool tile_needs_cin64(int tile);
 bool tile_is_rows(int tile);      // 3x3 stride-1 only, bordered input
-bool tile_is_rows_pt(int tile);   // ... its persistent form (groups allowed)
 bool tile_is_pp(int tile);        // ping-pong 3x3 / stride-1 kernel (conv_pp.hip): cin % 64 == 0, groups allowed
 bool tile_is_ppt(int tile);       // ping-pong tile kernel without tap reuse (conv_pp.hip): one conv, cin % 64 == 0, K >= 192, no residual / second destination
 bool tile_is_tail(int tile);      // runs ConvLaunch::tail_* as well; needs cout == the tile's BN

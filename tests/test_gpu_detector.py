@@ -222,7 +222,7 @@ def test_forward_layers_other_scales(pkg, wdir, scale, size):
     det.close()
 
 
-@pytest.mark.parametrize("tile", [T["ROWS_128x32"], T["ROWS_K64_64x64"], T["ROWS_128x64_W8"], T["ROWS_256x64_W8"], T["ROWS_PT_256x64"]])      # 4 waves (32- / 64-deep), 8 waves, the persistent form
+@pytest.mark.parametrize("tile", [T["ROWS_128x32"], T["ROWS_K64_64x64"], T["ROWS_256x64_W8"]])      # 4 waves (32- / 64-deep), 8 waves
 def test_tap_reuse_conv_tiles(pkg, wdir, monkeypatch, tile):
     """conv3x3_rows (the 3x3/s1 tap-reuse kernel) in each of its tile shapes, forced onto every
     layer where it is legal; all layers are then checked one by one against the oracle."""
@@ -735,7 +735,7 @@ def test_epilogue_variants_store_identical_values(pkg, wdir, monkeypatch):
     forced here).  bias / SiLU / residual / nearest-2x copy happen in fp32 before the single rounding in all of them,
     so every layer must be bit-identical."""
     monkeypatch.setenv("RTMODT_BNECK", "0")
-    monkeypatch.setenv("RTMODT_TILE_3X3S1", str(T["ROWS_128x64_W8"]))
+    monkeypatch.setenv("RTMODT_TILE_3X3S1", str(T["ROWS_256x64_W8"]))
     frames = list(pkg.synth.frames(2, 320, 320, seed=61))
     names = [c.name for c in pkg.weights.spec("s")]
     outs = {}
@@ -1241,47 +1241,6 @@ def test_converted_checkpoint_through_the_engine(pkg, wdir, tmp_path):
     dets, anch = Y.non_max_suppression(pr, 0.35, 0.45, None, False, 300)
     assert len(d) > 5 and abs(len(d) - len(dets)) <= max(3, len(dets) // 10)
     det.close()
-
-
-@pytest.mark.parametrize("tile,size,batch,scale", [(T["ROWS_PT_256x64"], 320, 32, "s"), (T["ROWS_PT_256x64"], 288, 3, "s"), (T["ROWS_PT_256x64"], 640, 4, "s"), (T["ROWS_PT_256x64"], 320, 8, "m")])
-def test_persistent_tap_reuse_kernel(pkg, wdir, monkeypatch, tile, size, batch, scale):
-    """conv3x3_rows_stream (TILE_ROWS_PT_*): persistent workgroups walk over the tiles of a launch -- of ALL problems of a grouped
-    launch (Detect stage 0: three levels with K = 1152 / 2304 / 4608, stage 1: six convs) -- with the next tile's first strip and
-    weights in flight under the current tile's last super-step and epilogue.  Forced onto every 3x3 / stride-1 conv (Bottlenecks
-    with their shortcuts, Detect); batches large enough that a workgroup walks several tiles and crosses problem boundaries, and
-    288 x 288 (partial tiles, fewer tiles than workgroups).  All layers of the first and the last image against the oracle; the
-    same arithmetic and k order as the plain tap-reuse kernel: bit-identical to it."""
-    monkeypatch.setenv("RTMODT_BNECK", "0")
-    monkeypatch.setenv("RTMODT_TAIL", "0")
-    frames = list(pkg.synth.frames(batch, size, size, seed=23 + tile))
-    names = [c.name for c in pkg.weights.spec(scale)]
-    plain = T["ROWS_256x64_W8"]                                # the same tile shape on the plain 8-wave tap-reuse kernel
-    outs = {}
-    for t in (plain, tile):
-        monkeypatch.setenv("RTMODT_TILE_3X3S1", str(t))
-        det, w = make_detector(pkg, wdir, scale, size, autotune=False, batch=batch, confidence=0.05)
-        used = [n for n, _, _ in det.profile(1) if "rows" in n]
-        assert len(used) >= 6 and (("-pt:" in " ".join(used)) == (t == tile)), used
-        dets = det.detect_batch(frames)
-        layers = {}
-        for img in sorted({0, batch - 1}):
-            inp, _, _ = det.debug_fetch(img, want_heads=False, want_pred=False)
-            gpu = fetch_layers(pkg, det, names, img)
-            layers[img] = gpu
-            if t == tile:
-                taps = {}
-                Y.forward(inp.astype(np.float32), w, scale, taps=taps, force=gpu)
-                for n in gpu:
-                    tol = 2e-3 * np.abs(taps[n]).max() + 2e-3
-                    err = float(np.abs(taps[n] - gpu[n]).max())
-                    assert err <= tol, f"tile {tile} img {img} layer {n}: max err {err:.4g} > tol {tol:.4g}"
-        outs[t] = (dets, layers)
-        det.close()
-    for img in outs[tile][1]:
-        for n in outs[tile][1][img]:
-            assert np.array_equal(outs[plain][1][img][n].view(np.uint16), outs[tile][1][img][n].view(np.uint16)), (img, n)
-    for a, b in zip(outs[plain][0], outs[tile][0]):
-        assert np.array_equal(a.xyxy.view(np.int32), b.xyxy.view(np.int32)) and a.class_id.tolist() == b.class_id.tolist()
 
 
 

@@ -22,9 +22,11 @@ rm -f $O/stats/*/*_kernel_trace.csv
 # the same bench on the PLAIN engine (one stream, one graph): every forward-pass kernel alone on the device, so the per-kernel
 # averages of the trace can be set against the HIP-event times of tools/profile_layers.py and bench.py (in the staged default
 # the kernels of the two stages overlap and each one's duration in the trace includes the time it shared the CUs)
-# (100 steps again: round 3's segfault inside hipGraphLaunch came from launching a graph executable again while an earlier launch of it was still
-# running, which rocprofv3 --kernel-trace does not survive -- the plain engine now rotates four instances: profiles/r04/rocprof_plain100/)
-RTMODT_CHAINS=1 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_chains1 -- $B --steps 100 --warmup 10 > $O/stats_chains1_bench.json 2> $O/stats_chains1.log || exit 1
+# (100 steps.  rocprofv3 --kernel-trace segfaults inside hipGraphLaunch after 200-300 launches of ONE big captured graph -- the plain engine's, or
+# the 45-node graph of tools/probes/graph_trace_repro.hip, which holds no engine code -- when the HIP runtime submits the graph's pre-built AQL
+# packets; with that path off (DEBUG_CLR_GRAPH_PACKET_CAPTURE=0: the runtime enqueues the nodes one by one) the trace completes.  The variable
+# is set for THIS profiler pass only; profiles/r04/graph_trace_repro/ holds the five runs)
+DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 RTMODT_CHAINS=1 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_chains1 -- $B --steps 100 --warmup 10 > $O/stats_chains1_bench.json 2> $O/stats_chains1.log || exit 1
 python tools/trace_gaps.py $O/stats_chains1/*/*_kernel_trace.csv 50 > $O/step_gaps_chains1.txt 2>&1
 rm -f $O/stats_chains1/*/*_kernel_trace.csv
 echo "[collect] kernel trace done"

@@ -346,12 +346,12 @@ int main(int argc, char **argv) {
             if (run_energy(t, 1, 512, 256, 40, 32, secs)) return 1;                      // 6.cv2
         for (int t : {TILE_K64_128x128_S2_W8, TILE_PT_128x128_S2, TILE_128x64})
             if (run_energy(t, 1, 256, 128, 80, 32, secs)) return 1;                      // 4.cv2
-        for (int t : {TILE_ROWS_256x64_W8, TILE_ROWS_128x64_W8, TILE_PP_256x128, TILE_PT_128x128_S2, TILE_K64_128x128_S2_W8})
+        for (int t : {TILE_ROWS_256x64_W8, TILE_PP_256x128, TILE_PT_128x128_S2, TILE_K64_128x128_S2_W8})
             if (run_energy(t, 3, 128, 128, 40, 32, secs)) return 1;                      // 6.m / 12.m / 18.m
         return 0;
     }
     if (argc > 1 && !strcmp(argv[1], "rows")) {                                  // 3x3 stride-1 convs on the tap-reuse kernel (stamps 0..6)
-        const int t6[] = {TILE_ROWS_256x64_W8, TILE_ROWS_128x64_W8, TILE_ROWS_PT_256x64};
+        const int t6[] = {TILE_ROWS_256x64_W8, TILE_ROWS_K64_64x64, TILE_PP_256x128};
         for (int t : t6) if (run_conv3(t, 128, 128, 1, 40, 32, 0)) return 1;      // 6.m / 12.m / 18.m
         for (int t : t6) if (run_conv3(t, 64, 64, 1, 80, 32, 0)) return 1;        // 4.m / 15.m
         for (int t : t6) if (run_conv3(t, 128, 64, 1, 80, 32, 0)) return 1;       // Detect cv2.0 at P3

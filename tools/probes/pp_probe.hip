@@ -183,7 +183,7 @@ int main(int argc, char **argv) {
         {"1x1 small   192->72 @13 B=3", 192, 72, 13, 3, false, 1, 1},
         {"3x3s2 small 64->128 @7 B=5", 64, 128, 7, 5, false, 3, 2},
     };
-    const int tiles3[] = {TILE_ROWS_256x64_W8, TILE_ROWS_PT_256x64, TILE_PT_128x128_S2, TILE_PT_128x64_S2, TILE_K64_128x128_S2_W8, TILE_PP_256x128, TILE_PP_256x64, TILE_PP_256x192, TILE_PP_512x64};
+    const int tiles3[] = {TILE_ROWS_256x64_W8, TILE_PT_128x128_S2, TILE_PT_128x64_S2, TILE_K64_128x128_S2_W8, TILE_PP_256x128, TILE_PP_256x64, TILE_PP_256x192, TILE_PP_512x64};
     const int tilesg[] = {TILE_K64_128x128_S3_W8, TILE_K64_128x128_S2_W8, TILE_K64_256x64_S2_W8, TILE_PT_128x128_S2, TILE_PT_128x64_S2, TILE_PPT_256x128};
     for (const Shape &sh : shapes) {
         if (*filter && !strstr(sh.name, filter)) continue;
@@ -226,7 +226,7 @@ int main(int argc, char **argv) {
             {"22.stage1 cv3 (3 levels, 128->128)", {{"", 128, 128, 80, 32, false}, {"", 128, 128, 40, 32, false}, {"", 128, 128, 20, 32, false}}},
             {"22.stage1 cv2 (3 levels, 64->64)", {{"", 64, 64, 80, 32, false}, {"", 64, 64, 40, 32, false}, {"", 64, 64, 20, 32, false}}},
         };
-        const int gtiles[] = {TILE_ROWS_PT_256x64, TILE_ROWS_256x64_W8, TILE_PP_256x128, TILE_PP_256x64, TILE_PP_256x192, TILE_PP_512x64};
+        const int gtiles[] = {TILE_ROWS_256x64_W8, TILE_PP_256x128, TILE_PP_256x64, TILE_PP_256x192, TILE_PP_512x64};
         for (const G &gr : groups) {
             std::vector<Problem> ps(gr.s.size());
             double gflop = 0;
