@@ -266,7 +266,7 @@ __global__ __launch_bounds__(BN_THREADS) void bottleneck_fused(BneckArgs p) {
             for (int u = 0; u < NT; ++u) {
                 const int n = u * 16 + q * 4;
                 half4 h = {(f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f};
-                if (inside) h = half4{(f16)silu_b(acc[i][u][0]), (f16)silu_b(acc[i][u][1]), (f16)silu_b(acc[i][u][2]), (f16)silu_b(acc[i][u][3])};
+                if (inside) { floatx4 sv = acc[i][u]; silu4(sv); h = half4{(f16)sv[0], (f16)sv[1], (f16)sv[2], (f16)sv[3]}; }
                 const int plane = n / G::CW, cn = n - plane * G::CW;
                 *(half4 *)(tbuf + plane * (G::T_ROWS * CB) + plane_off<CB>(m, cn >> 3) + (cn & 7) * 2) = h;
             }
@@ -313,7 +313,7 @@ __global__ __launch_bounds__(BN_THREADS) void bottleneck_fused(BneckArgs p) {
             for (int u = 0; u < NT; ++u) {
                 const int n = u * 16 + q * 4;
                 floatx4 v = acc[i][u];
-                v[0] = silu_b(v[0]); v[1] = silu_b(v[1]); v[2] = silu_b(v[2]); v[3] = silu_b(v[3]);
+                silu4(v);
                 if (p.res && live) {
                     half4 rv = *(const half4 *)(p.res + rpix + n);
                     v[0] += (float)rv[0]; v[1] += (float)rv[1]; v[2] += (float)rv[2]; v[3] += (float)rv[3];
@@ -391,7 +391,7 @@ __global__ __launch_bounds__(BN_THREADS) void bottleneck_fused(BneckArgs p) {
 #pragma unroll
                 for (int u = 0; u < N2T; ++u) {
                     floatx4 v = acc2[i][u] + b2v[u];
-                    if (p.t_act) { v[0] = silu_b(v[0]); v[1] = silu_b(v[1]); v[2] = silu_b(v[2]); v[3] = silu_b(v[3]); }
+                    if (p.t_act) silu4(v);
                     *(half4 *)(lds + m * ROWO + (u * 16 + q * 4) * 2) = half4{(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
                 }
             }

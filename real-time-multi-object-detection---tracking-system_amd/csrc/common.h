@@ -103,6 +103,31 @@ __device__ __forceinline__ float silu(float x) {
     return a;
 #endif
 }
+// Four SiLUs (one MFMA accumulator quad) with the plain multiplies and the add of each PAIR issued as one packed instruction:
+// v_pk_mul_f32 (x * -log2 e), 2 x v_exp_f32, v_pk_add_f32 (1 + t), 2 x v_rcp_f32, v_pk_mul_f32 -- 22 issue cycles per value against
+// silu()'s 26 (transcendentals 8 each, everything else 4 per instruction, packed or not).  Same operations, same roundings: the
+// values are bit-identical to silu()'s (hipcc packs only the last multiply by itself: a 32-bit literal cannot be a packed operand).
+typedef float floatx2_t __attribute__((ext_vector_type(2)));
+typedef float floatx4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ floatx2_t silu2(floatx2_t x) {
+#if defined(RTMODT_ABLATE_SILU2)
+    return floatx2_t{silu(x[0]), silu(x[1])};
+#else
+    // (vector expressions, not inline asm: the hazard recognizer does not see inside an asm statement, and a VALU instruction that reads a
+    //  transcendental's result one issue later reads the old register -- 1.2 % wrong outputs in the first form of this function)
+    const floatx2_t k = {-1.4426950408889634f, -1.4426950408889634f}, one = {1.0f, 1.0f};
+    floatx2_t t = x * k;
+    t[0] = __builtin_amdgcn_exp2f(t[0]); t[1] = __builtin_amdgcn_exp2f(t[1]);
+    floatx2_t d = t + one;
+    d[0] = __builtin_amdgcn_rcpf(d[0]); d[1] = __builtin_amdgcn_rcpf(d[1]);
+    const floatx2_t y = x * d;
+    return y;
+#endif
+}
+__device__ __forceinline__ void silu4(floatx4_t &v) {
+    const floatx2_t a = silu2(floatx2_t{v[0], v[1]}), b = silu2(floatx2_t{v[2], v[3]});
+    v[0] = a[0]; v[1] = a[1]; v[2] = b[0]; v[3] = b[1];
+}
 #endif
 
 }  // namespace rtmodt

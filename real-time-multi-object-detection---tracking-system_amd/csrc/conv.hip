@@ -731,8 +731,8 @@ __global__ __launch_bounds__(NW * 64) void conv_mfma64_pt(ConvArgs p, int groups
                 for (int u = 0; u < TN; u += 2) {
                     floatx4 v0 = acc[t][u] + bv[u], v1 = acc[t][u + 1] + bv[u + 1];
                     if (p.act) {
-                        v0[0] = silu_f(v0[0]); v0[1] = silu_f(v0[1]); v0[2] = silu_f(v0[2]); v0[3] = silu_f(v0[3]);
-                        v1[0] = silu_f(v1[0]); v1[1] = silu_f(v1[1]); v1[2] = silu_f(v1[2]); v1[3] = silu_f(v1[3]);
+                        silu4(v0);
+                        silu4(v1);
                     }
                     if (p.res) {
                         const half4 r0 = rv[t][u], r1 = rv[t][u + 1];
@@ -1137,7 +1137,7 @@ __device__ __forceinline__ void stem_store(unsigned char *tile, const floatx4 *a
     const int p = lane & 15, q = lane >> 4;
 #pragma unroll
     for (int u = 0; u < NT; ++u) {
-        half4 h = {(f16)silu_f(acc[u][0]), (f16)silu_f(acc[u][1]), (f16)silu_f(acc[u][2]), (f16)silu_f(acc[u][3])};
+        floatx4 sv = acc[u]; silu4(sv); half4 h = {(f16)sv[0], (f16)sv[1], (f16)sv[2], (f16)sv[3]};
         *(half4 *)(tile + p * ROW + u * 32 + q * 8) = h;
     }
     __builtin_amdgcn_wave_barrier();
@@ -1191,7 +1191,7 @@ __global__ __launch_bounds__(256) void stem_mfma(const f16 *__restrict__ img, in
             f16 *o = out + ((long)(b * oHp + oy + opad) * oWp + ox + opad) * ocs + q * 4;
 #pragma unroll
             for (int u = 0; u < NT; ++u) {
-                half4 h = {(f16)silu_f(acc[u][0]), (f16)silu_f(acc[u][1]), (f16)silu_f(acc[u][2]), (f16)silu_f(acc[u][3])};
+                floatx4 sv = acc[u]; silu4(sv); half4 h = {(f16)sv[0], (f16)sv[1], (f16)sv[2], (f16)sv[3]};
                 *(half4 *)(o + u * 16) = h;
             }
         }
@@ -1351,7 +1351,7 @@ __global__ __launch_bounds__(256) void stem_fused(StemSrc src, const f16 *__rest
             f16 *o = out + ((long)(b * oHp + oy + opad) * oWp + ox + opad) * ocs + q * 4;
 #pragma unroll
             for (int u = 0; u < NT; ++u) {
-                half4 h = {(f16)silu_f(acc[u][0]), (f16)silu_f(acc[u][1]), (f16)silu_f(acc[u][2]), (f16)silu_f(acc[u][3])};
+                floatx4 sv = acc[u]; silu4(sv); half4 h = {(f16)sv[0], (f16)sv[1], (f16)sv[2], (f16)sv[3]};
                 *(half4 *)(o + u * 16) = h;
             }
         }

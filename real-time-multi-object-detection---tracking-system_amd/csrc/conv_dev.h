@@ -135,7 +135,7 @@ __device__ __forceinline__ void glds16(const f16 *src, unsigned char *dst) {
 // channels n .. n+3
 __device__ __forceinline__ void store_tile(const ConvArgs &p, const floatx4 &acc, const floatx4 &bias, long opix, long rpix, int n, long opix2 = -1) {
     floatx4 v = acc + bias;
-    if (p.act) { v[0] = silu_f(v[0]); v[1] = silu_f(v[1]); v[2] = silu_f(v[2]); v[3] = silu_f(v[3]); }
+    if (p.act) silu4(v);
     if (p.res) {
         half4 rv = *(const half4 *)(p.res + rpix + n);
         v[0] += (float)rv[0]; v[1] += (float)rv[1]; v[2] += (float)rv[2]; v[3] += (float)rv[3];
@@ -206,7 +206,7 @@ __device__ __forceinline__ void epilogue_lds(const ConvArgs &p, const int n0, co
         for (int u = 0; u < TN; ++u) {
             const int nl = (wn * TN + u) * 16 + q * 4;
             floatx4 v = acc[t][u] + bv[u];
-            if (p.act) { v[0] = silu_f(v[0]); v[1] = silu_f(v[1]); v[2] = silu_f(v[2]); v[3] = silu_f(v[3]); }
+            if (p.act) silu4(v);
             if (p.res && live && n0 + nl < p.cout) {
                 half4 rv = *(const half4 *)(p.res + rpix + n0 + nl);
                 v[0] += (float)rv[0]; v[1] += (float)rv[1]; v[2] += (float)rv[2]; v[3] += (float)rv[3];
@@ -275,7 +275,7 @@ __device__ __forceinline__ void epilogue_tail(const ConvArgs &p, const floatx4 (
         for (int u = 0; u < TN; ++u) {
             const int nl = (wn * TN + u) * 16 + q * 4;
             floatx4 v = acc[t][u] + bv[u];
-            if (p.act) { v[0] = silu_f(v[0]); v[1] = silu_f(v[1]); v[2] = silu_f(v[2]); v[3] = silu_f(v[3]); }
+            if (p.act) silu4(v);
             *(half4 *)(lds + pm * ROWB + nl * 2) = half4{(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
         }
     }
@@ -308,7 +308,7 @@ __device__ __forceinline__ void epilogue_tail(const ConvArgs &p, const floatx4 (
 #pragma unroll
         for (int u = 0; u < N2T; ++u) {
             floatx4 v = acc2[i][u] + b2[u];
-            if (p.t_act) { v[0] = silu_f(v[0]); v[1] = silu_f(v[1]); v[2] = silu_f(v[2]); v[3] = silu_f(v[3]); }
+            if (p.t_act) silu4(v);
             *(half4 *)(lds + pm * ROWB2 + (u * 16 + q * 4) * 2) = half4{(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
         }
     }

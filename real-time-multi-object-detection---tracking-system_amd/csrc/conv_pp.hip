@@ -365,7 +365,7 @@ __global__ __launch_bounds__(512) void conv3x3_pp(ConvGroupArgs g, int total_ids
 #pragma unroll
                         for (int tt = 0; tt < TR; ++tt)
 #pragma unroll
-                            for (int u = 0; u < TN; ++u) { floatx4 &v = acc[t0 + tt][u]; v[0] = silu_f(v[0]); v[1] = silu_f(v[1]); v[2] = silu_f(v[2]); v[3] = silu_f(v[3]); }
+                            for (int u = 0; u < TN; ++u) silu4(acc[t0 + tt][u]);
                     }
 #pragma unroll
                     for (int tt = 0; tt < TR; ++tt)
@@ -408,7 +408,7 @@ __global__ __launch_bounds__(512) void conv3x3_pp(ConvGroupArgs g, int total_ids
 #pragma unroll
                         for (int tt = 0; tt < TR; ++tt)
 #pragma unroll
-                            for (int u = 0; u < TN; ++u) { floatx4 &v = acc[t0 + tt][u]; v[0] = silu_f(v[0]); v[1] = silu_f(v[1]); v[2] = silu_f(v[2]); v[3] = silu_f(v[3]); }
+                            for (int u = 0; u < TN; ++u) silu4(acc[t0 + tt][u]);
                     }
 #pragma unroll
                     for (int tt = 0; tt < TR; ++tt)
@@ -615,7 +615,7 @@ __global__ __launch_bounds__(512) void conv_tile_pp(ConvArgs p, int n_tiles) {
 #pragma unroll
                     for (int tt = 0; tt < TR; ++tt)
 #pragma unroll
-                        for (int u = 0; u < TN; ++u) { floatx4 &v = acc[t0 + tt][u]; v[0] = silu_f(v[0]); v[1] = silu_f(v[1]); v[2] = silu_f(v[2]); v[3] = silu_f(v[3]); }
+                        for (int u = 0; u < TN; ++u) silu4(acc[t0 + tt][u]);
                 }
 #pragma unroll
                 for (int tt = 0; tt < TR; ++tt)
