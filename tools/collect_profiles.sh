@@ -55,3 +55,6 @@ python tools/run_pipeline_synth.py --source 1920x1080 > $O/pipeline_1080p.json 2
 python tests/perf/tracker_modes.py > $O/tracker_modes.json 2> /dev/null
 python tools/bw_probe.py > $O/bandwidth_probe.txt 2> /dev/null
 echo "[collect] all done"
+# soak: 3 000 steps of the default engine with the line's self-check (NMS bit-equal to the oracle, every stored layer of two images) at the end
+python3 bench.py --no-cpu-baseline --no-latency --no-compare --no-host-leg --long 0 --prewarm 0.2 --steps 3000 --warmup 30 > $O/bench_soak3000.json 2> /dev/null || exit 1
+echo "[collect] soak done"

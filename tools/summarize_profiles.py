@@ -22,7 +22,7 @@ def one(pattern):
 
 
 for name in ("bench_default.json", "bench_driver_cmd.json", "bench_frames2.json", "bench_frames8.json", "bench_host_frames_F2.json", "layers_chains1_F2.txt", "layers_chains1_F8.txt", "bench_host_frames.json", "bench_host_frames_pageable.json", "bench_streams16.json",
-             "bench_streams32.json", "bench_frames1.json", "bench_frames4.json", "bench_chains1.json", "bench_chains2.json", "bench_stages2.json", "stats_bench.json", "stats_chains1_bench.json", "layers_chains1.txt", "step_gaps_chains1.txt", "pipeline_640.json", "pipeline_1080p.json", "layers.txt", "step_gaps.txt",
+             "bench_streams32.json", "bench_soak3000.json", "bench_frames1.json", "bench_frames4.json", "bench_chains1.json", "bench_chains2.json", "bench_stages2.json", "stats_bench.json", "stats_chains1_bench.json", "layers_chains1.txt", "step_gaps_chains1.txt", "pipeline_640.json", "pipeline_1080p.json", "layers.txt", "step_gaps.txt",
              "bandwidth_probe.txt", "tracker_modes.json"):
     p = os.path.join(src, name)
     if os.path.exists(p):
