@@ -864,18 +864,6 @@ TileShape tile_shape(int tile) {
     return {0, 0};
 }
 
-// compute units of the current device (the persistent kernels size their grids by it), looked up once per device
-static int device_cus() {
-    static int cus[64] = {};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
-    if (!cus[dev]) {
-        hipDeviceProp_t prop;
-        cus[dev] = hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    }
-    return cus[dev];
-}
-
 struct LaunchPlan {
     const ConvArgs *a; int n; bool general;
     dim3 grid(int bm, int bn) const { return dim3(cdiv(a[0].M, bm), cdiv(a[0].cout, bn), 1); }      // single problem

@@ -365,6 +365,18 @@ __device__ __forceinline__ int group_pick(const ConvGroupArgs &g, int &bx, int &
 }
 
 // conv_pp.hip: n 3x3 / stride-1 problems (ConvArgs prepared for the tap-reuse enumeration) as one ping-pong launch with cout tile bn
+// compute units of the current device (the persistent kernels size their grids by it), looked up once per device
+static inline int device_cus() {
+    static int cus[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (!cus[dev]) {
+        hipDeviceProp_t prop;
+        cus[dev] = hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    return cus[dev];
+}
+
 int launch_conv3x3_pp(const ConvArgs *a, int n, int bn, hipStream_t s);
 // ... one conv of any kernel size / stride without tap reuse (1x1, 3x3 stride 2) on the ping-pong tile kernel
 int launch_conv_tile_pp(const ConvArgs &a, int bn, hipStream_t s);

@@ -657,15 +657,10 @@ static int launch_pp_bn(const ConvArgs *a, int n, hipStream_t s) {
     }
     for (int i = n; i < MAX_GROUP; ++i) { g.start[i + 1] = g.start[n]; g.gx[i] = 1; }
     const int total = g.start[n];
-    static int cus = 0;                               // one persistent workgroup per CU (its LDS leaves no room for a second)
-    if (!cus) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        RT_HIP(hipGetDevice(&dev));
-        RT_HIP(hipGetDeviceProperties(&prop, dev));
-        cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    }
-    int G = std::min(total, cus);
+    // one persistent workgroup per CU (its LDS and registers leave no room for a second).  Diagnostic builds: RTMODT_PP_RESERVE=n leaves n CUs to the
+    // launches of the engine's other stages for the whole life of this launch.
+    static const int reserve = rt_diag("PP_RESERVE") ? atoi(rt_diag("PP_RESERVE")) : 0;
+    int G = std::min(total, std::max(8, device_cus() - reserve));
     if (G >= 8) G &= ~7;                              // a workgroup's ids keep their residue mod 8: one XCD's share of the tile order
     // Balanced tile lists (pp_lpt_schedule) for launches whose workgroups run more than one tile of DIFFERENT problems: built once per launch shape and
     // device, kept for the life of the process (a few KiB each).  A shape first seen while its stream is being captured runs on the static stride.
@@ -712,15 +707,8 @@ static int launch_pp_bn(const ConvArgs *a, int n, hipStream_t s) {
 template <int BN>
 static int launch_tile_pp_bn(const ConvArgs &a, hipStream_t s) {
     const int n_tiles = cdiv(a.M, 256) * cdiv(a.cout, BN);
-    static int cus = 0;
-    if (!cus) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        RT_HIP(hipGetDevice(&dev));
-        RT_HIP(hipGetDeviceProperties(&prop, dev));
-        cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    }
-    int G = std::min(n_tiles, cus);
+    static const int reserve = rt_diag("PP_RESERVE") ? atoi(rt_diag("PP_RESERVE")) : 0;
+    int G = std::min(n_tiles, std::max(8, device_cus() - reserve));
     if (G >= 8) G &= ~7;
     hipLaunchKernelGGL((conv_tile_pp<BN>), dim3(G), dim3(512), 0, s, a, n_tiles);
     return RTMODT_OK;
