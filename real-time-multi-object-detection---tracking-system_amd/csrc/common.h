@@ -110,7 +110,7 @@ __device__ __forceinline__ float silu(float x) {
 typedef float floatx2_t __attribute__((ext_vector_type(2)));
 typedef float floatx4_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ floatx2_t silu2(floatx2_t x) {
-#if defined(RTMODT_ABLATE_SILU2)
+#if defined(RTMODT_ABLATE_SILU2) || defined(RTMODT_SILU_SCALAR)      // (SILU_SCALAR: check build -- tools/ab/r04_silu_bits.sh compares the stored bits of the two forms)
     return floatx2_t{silu(x[0]), silu(x[1])};
 #else
     // (vector expressions, not inline asm: the hazard recognizer does not see inside an asm statement, and a VALU instruction that reads a

@@ -210,8 +210,10 @@ int main(int argc, char **argv) {
             std::vector<f16> got = fetch(ps[0]);
             if (ref.empty()) ref = got;
             const Cmp c = compare(got, ref);
-            printf("   %-20s %8.2f us  %7.1f TFLOP/s   max|d| %.4g (max|ref| %.3g)  outside tol: %zu of %zu%s\n", tile_name(t), us, gflop / us * 1e3, c.max_abs, c.max_ref, c.bad, c.n,
-                   c.bad ? "   <-- MISMATCH" : "");
+            unsigned long long h = 1469598103934665603ull;      // FNV-1a of the output bytes: two builds of the library that print the same hash store the same bits
+            for (const f16 &v : got) { unsigned short u; memcpy(&u, &v, 2); h = (h ^ (u & 0xff)) * 1099511628211ull; h = (h ^ (u >> 8)) * 1099511628211ull; }
+            printf("   %-20s %8.2f us  %7.1f TFLOP/s   max|d| %.4g (max|ref| %.3g)  outside tol: %zu of %zu%s  bits %016llx\n", tile_name(t), us, gflop / us * 1e3, c.max_abs, c.max_ref, c.bad, c.n,
+                   c.bad ? "   <-- MISMATCH" : "", h);
 #ifdef RTMODT_STAMP
             print_stamps(256);
 #endif
