@@ -1244,7 +1244,7 @@ def test_converted_checkpoint_through_the_engine(pkg, wdir, tmp_path):
 
 
 
-@pytest.mark.parametrize("tile,size,batch,scale", [(T["PP_256x128"], 320, 32, "s"), (T["PP_256x64"], 320, 32, "s"), (T["PP_256x192"], 320, 32, "s"), (T["PP_512x64"], 320, 32, "s"), (T["PP_256x128"], 288, 3, "s"), (T["PP_256x64"], 640, 4, "s"), (T["PP_512x64"], 288, 3, "s"), (T["PP_512x64"], 640, 2, "s"), (T["PP_256x128"], 320, 8, "m"), (T["PP_256x64"], 320, 5, "n")])
+@pytest.mark.parametrize("tile,size,batch,scale", [(T["PP_256x128"], 320, 32, "s"), (T["PP_256x64"], 320, 32, "s"), (T["PP_256x192"], 320, 32, "s"), (T["PP_512x64"], 320, 32, "s"), (T["PP_256x128"], 288, 3, "s"), (T["PP_256x64"], 640, 4, "s"), (T["PP_512x64"], 288, 3, "s"), (T["PP_512x64"], 640, 2, "s"), (T["PP_256x128"], 320, 8, "m"), (T["PP_256x64"], 320, 5, "n"), (T["PP_256x192"], 288, 3, "s"), (T["PP_256x192"], 640, 2, "s"), (T["PP_256x192"], 320, 4, "m")])
 def test_ping_pong_3x3_kernel(pkg, wdir, monkeypatch, tile, size, batch, scale):
     """conv3x3_pp (TILE_PP_*, csrc/conv_pp.hip): the 3x3 / stride-1 kernel whose two wave halves run one barrier interval apart, forced onto
     every conv where it is legal -- Bottlenecks with their shortcuts (fp32 staging + 16-byte shortcut reads), the grouped Detect launches (a
