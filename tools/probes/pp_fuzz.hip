@@ -2,7 +2,7 @@
 // shapes YOLOv8 n / s / m produce: non-square maps, channel SLICES of wider tensors for input / output / shortcut, cout not a multiple of the tile,
 // tiny and ragged M, activation on / off, grouped launches of unequal problems.  Every output tensor sits between two guard zones that must come back
 // untouched (an out-of-range store shows up as a damaged guard, not as a fault somewhere else).
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -o /tmp/pp_fuzz tools/probes/pp_fuzz.hip && /tmp/pp_fuzz [cases] [seed]
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -o /tmp/pp_fuzz tools/probes/pp_fuzz.hip && /tmp/pp_fuzz [cases] [seed] [all]   ("all": every tile of the table)
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -101,6 +101,7 @@ static bool run(std::vector<Problem> &ps, int tile, std::vector<std::vector<f16>
 int main(int argc, char **argv) {
     const int cases = argc > 1 ? atoi(argv[1]) : 100;
     if (argc > 2) rng ^= (unsigned long long)atoll(argv[2]) * 0x9E3779B97F4A7C15ull;
+    const bool all_tiles = argc > 3 && !strcmp(argv[3], "all");      // every tile of the table (tails excepted: they need a second conv) instead of the ping-pong ones
     const int pp_tiles[] = {TILE_PP_256x128, TILE_PP_256x64, TILE_PP_256x192, TILE_PP_512x64}, ppt_tiles[] = {TILE_PPT_256x128};
     int failures = 0, ran = 0, refused = 0;
     for (int k = 0; k < cases; ++k) {
@@ -129,8 +130,10 @@ int main(int argc, char **argv) {
         std::vector<std::vector<f16>> ref, got;
         bool g_ok = true;
         if (!run(ps, TILE_64x64, ref, g_ok) || !g_ok) { printf("case %d %s: REFERENCE tile failed (%s)\n", k, desc.c_str(), last_error().c_str()); ++failures; for (auto &p : ps) drop(p); continue; }
-        const int *tiles = kind == 3 ? ppt_tiles : pp_tiles;
-        const int nt = kind == 3 ? 1 : 4;
+        int every[TILE_COUNT], ne = 0;
+        for (int t = 0; t < TILE_COUNT; ++t) if (!tile_is_tail(t) && t != TILE_64x64) every[ne++] = t;
+        const int *tiles = all_tiles ? every : (kind == 3 ? ppt_tiles : pp_tiles);
+        const int nt = all_tiles ? ne : (kind == 3 ? 1 : 4);
         for (int ti = 0; ti < nt; ++ti) {
             if (!run(ps, tiles[ti], got, g_ok)) { ++refused; continue; }
             ++ran;
