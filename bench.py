@@ -118,6 +118,7 @@ def parse():
                     help="synthetic frames: uniform-random bytes (default, the hardest case for the chip's power limit) or smooth blobs on a gradient")
     ap.add_argument("--no-host-leg", action="store_true", help="skip the extra PCIe-inclusive measurement")
     ap.add_argument("--no-verify", action="store_true", help="skip the untimed output self-check")
+    ap.add_argument("--no-tracker-stress", action="store_true", help="skip the 200- / 500-box association sequences (BASELINE configs 3 / 5)")
     ap.add_argument("--prewarm", type=float, default=1.0, help="seconds of untimed full-pipeline running before the timed region (besides --warmup steps)")
     ap.add_argument("--launch-check", action="store_true",
                     help="rendez-vous only: every rank joins the process group, rank 0 prints {n_gpus, ranks}, nobody touches a GPU (CPU test of the launcher path)")
@@ -163,6 +164,67 @@ def cpu_baseline(pkg, weights, args, budget_s=20.0):
             "sample": f"{len(t)} frames 640x640, YOLOv8{args.model} fp32 torch-CPU forward + NumPy decode/NMS + C tracker, "
                       f"p50 {float(np.median(t)) * 1e3:.1f} ms/frame",
             "p50_ms": round(float(np.median(t)) * 1e3, 2)}
+
+
+def workload_label(model: str, size: int, streams: int) -> str:
+    """Which BASELINE.json configuration (if any) the per-GPU workload is the shard of -- derived from the arguments, never assumed
+    (a --model m --size 1280 --streams 1 run used to label itself "config 4 shard")."""
+    if (model, size, streams) == ("s", 640, 8):
+        return "BASELINE config 4 shard: 64 streams over 8 GPUs = 8 per GPU"
+    if (model, size, streams) == ("m", 1280, 1):
+        return "BASELINE config 5 shard: 8 streams over 8 GPUs = 1 per GPU"
+    if (model, size, streams) == ("s", 640, 1):
+        return "BASELINE config 2/3 shape: one stream on one GPU"
+    return "not a BASELINE configuration"
+
+
+def live_stream_cost(F: int, fps_camera: float = 25.0) -> str:
+    """What batching F consecutive frames of a stream into one launch set costs a LIVE camera (the headline assumes frames that are already there)."""
+    if F <= 1:
+        return "no batching over time: every frame is submitted as it arrives"
+    return (f"a live {fps_camera:g} fps camera would wait {(F - 1) * 1e3 / fps_camera:.0f} ms to fill a launch set (F - 1 frame periods) -- "
+            f"offline / recorded streams pay nothing; value_no_temporal_batching is the F = 1 figure")
+
+
+def tracker_stress(pkg, dev):
+    """BASELINE configs 3 and 5's association load as part of the driver-run record: the 200-box @ 640 (120 frames) and
+    500-box @ 1280 (60 frames) sequences of SURVEY 8d through the single-launch tracker, frame by frame, every frame's state digest compared
+    with the fixture the REFERENCE's own tracker.py generated (tests/golden/tracker_g5_seq200.npz, tracker_g6_seq500.npz; the digest
+    function is the oracle's -- the checker, as in verify_outputs).  Time = wall clock around the synchronous C-ABI call (H2D of the frame's
+    detections + one launch + device sync); pairs = live tracks x detections offered to the IoU sweep."""
+    import hashlib
+    from importlib import import_module
+    from oracle import tracker_oracle as T
+    core_cls = import_module(pkg.__name__ + ".tracking.tracker")._ByteTrackCore
+    out = {}
+    for key, fname in (("config3_200_boxes_640", "tracker_g5_seq200.npz"), ("config5_500_boxes_1280", "tracker_g6_seq500.npz")):
+        z = np.load(os.path.join(ROOT, "tests", "golden", fname))
+        n, canvas, frames, seed = int(z["seq_n"]), int(z["seq_canvas"]), int(z["seq_frames"]), int(z["seq_seed"])
+        xy, cf, cl = pkg.synth.box_sequence(n, canvas, frames, seed)
+        sha = hashlib.sha256(xy.tobytes() + cf.tobytes() + cl.tobytes()).digest()
+        if not np.array_equal(np.frombuffer(sha, dtype=np.uint8), z["in_sha"]):
+            raise SystemExit(f"bench tracker_stress: the generated {key} sequence is not the fixture's")
+        core = core_cls(device=dev, n_streams=1, max_dets=max(512, n), max_tracks=2048)
+        ts, pairs = [], 0
+        for rep in range(3):
+            core.reset()
+            for f in range(frames):
+                live = len(core.snapshot(0)["ids"]) if rep == 0 else 0
+                t0 = time.perf_counter()
+                core.update(xy[f], cf, cl)
+                ts.append(time.perf_counter() - t0)
+                if rep == 0:
+                    pairs += live * n
+                    if not np.array_equal(T.state_digest(core.snapshot(0)), z["digest"][f]):
+                        raise SystemExit(f"bench tracker_stress FAILED: {key} frame {f}: tracker state differs from the reference-generated fixture")
+        p50 = float(np.median(ts))
+        out[key] = {"boxes_per_frame": n, "canvas": canvas, "frames": frames, "update_us_p50": round(p50 * 1e6, 1), "update_us_p95": round(float(np.percentile(ts, 95)) * 1e6, 1),
+                    "iou_pairs_per_frame_mean": int(pairs / frames), "iou_pairs_per_s": round(pairs / frames / p50, 0),
+                    "live_tracks_end": len(core.snapshot(0)["ids"]), "bit_exact_vs_reference_fixture": True, "fixture": "tests/golden/" + fname}
+        core.close()
+    out["what"] = ("one stream, one launch per frame, greedy assignment (the reference's executable branch); wall clock around the synchronous C-ABI update "
+                   "(H2D of the detections + launch + sync); every frame's state digest == the fixture generated by the reference's tracker.py")
+    return out
 
 
 def verify_outputs(pkg, det, frame_ptrs, size, max_det, weights, scale):
@@ -286,9 +348,25 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the line would not describe the run")
     if args.launch_check:
         ranks = sync.sum_stats([1])[0]
+        # the per-rank plumbing of a real run, without a GPU: the single-writer weight file (temporary name + rename, read by everybody
+        # after the barrier), one tune-cache file per rank, the per-rank frames/s gather
+        wcheck = os.path.join(tempfile.gettempdir(), f"rtmodt_launch_check_{os.environ.get('MASTER_PORT', '0')}.bin")
+        if rank == 0:
+            tmp = wcheck + f".{os.getpid()}"
+            with open(tmp, "wb") as f:
+                f.write(b"RTMODTW1" + bytes(range(256)) * 64)
+            os.replace(tmp, wcheck)
+        sync.barrier()
+        with open(wcheck, "rb") as f:
+            whole = len(f.read()) == 8 + 256 * 64
+        tune = os.path.join(tempfile.gettempdir(), f"rtmodt_bench_tune_{os.getpid()}.txt")
+        per_rank = sync.gather_floats(float(rank))
+        seen_whole = sync.sum_stats([1 if whole else 0])[0]
         sync.barrier()
         if rank == 0:
-            print(json.dumps({"launch_check": True, "n_gpus": world, "ranks_joined": ranks, "backend": args.backend}), flush=True)
+            os.unlink(wcheck)
+            print(json.dumps({"launch_check": True, "n_gpus": world, "ranks_joined": ranks, "backend": args.backend, "per_rank_frames_s": per_rank,
+                              "ranks_that_read_the_whole_weight_file": seen_whole, "tune_cache_of_rank_0": tune}), flush=True)
         sync.close()
         return
     if not args.one_device:
@@ -483,6 +561,7 @@ def main():
     m = measure(F, args.steps, args.warmup, long_s=args.long, host=args.host_frames)
     det, trk, elapsed, fwd_ms, tot_ms, n_det = m["det"], m["trk"], m["elapsed"], m["fwd_ms"], m["tot_ms"], m["n_det"]
     flops_step = det.model.conv_flops_per_frame * S * F
+    per_rank_fps = sync.gather_floats(S * F * args.steps / elapsed)      # every rank's own frames/s (stragglers show in a SCALE run)
     elapsed = sync.max_time(elapsed)                # MAX over ranks
     cold = sync.max_time(m["cold"])
     n_tracks = sum(len(trk.snapshot(s)["ids"]) for s in range(S))
@@ -509,10 +588,11 @@ def main():
         "value": round(fps, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f16", "data": "synthetic",
-        "config": {"workload": f"YOLOv8{args.model} {size}x{size} fp16, {S} synthetic streams per GPU (BASELINE config 4 shard), "
-                               f"{F} consecutive frame(s) of every stream per launch set, "
+        "config": {"workload": f"YOLOv8{args.model} {size}x{size} fp16, {S} synthetic stream(s) per GPU ({workload_label(args.model, size, S)}), "
+                               f"{F} consecutive frame(s) of every stream per launch set ({live_stream_cost(F)}), "
                                f"detect (letterbox+forward+decode+NMS, max_det {args.max_det}) + ByteTrack update (frame by frame, in order), "
                                f"frames from: {src}, detections copied to host every step",
+                   "baseline_config": workload_label(args.model, size, S),
                    "streams_per_gpu": S, "frames_per_stream_per_step": F, "frames_per_step": S * F * world,
                    "weights": "synthetic seed 0, LSUV-calibrated on noise frames",
                    "parallelism": f"streams sharded {world} ways, no data-path collective"},
@@ -531,6 +611,7 @@ def main():
                      "flops_per_step": int(flops_step), "forward_ms_per_step": round(fwd_ms_step, 4),
                      "batch_latency_ms": round(tot_ms / args.steps, 4),
                      "batch_latency_note": "HIP events, first launch of a batch -> its NMS done (pipeline latency of one batch, not a per-step time)"},
+        "per_rank_frames_s": [round(v, 1) for v in per_rank_fps],
         "detections_per_frame": round(n_det / frames_total, 2), "live_tracks_node": n_tracks_node,
         "frames_source": src,
     }
@@ -557,8 +638,14 @@ def main():
         # HBM bytes per step come from separate rocprofv3 PMC passes (tools/collect_profiles.sh), so this line can only carry them while they still
         # describe the kernels it ran: the JSON is stamped with a digest of csrc/, and a tree whose kernels changed since prints null and says why
         sys.path.insert(0, os.path.join(ROOT, "tools"))
-        from kernel_digest import csrc_digest, load_traffic
-        traffic, why = load_traffic(os.path.join(ROOT, "profiles", "traffic_current.json"), f"{args.model}-{size}-{S}x{F}", csrc_digest())
+        from kernel_digest import load_traffic
+        # ... of the LIBRARY that ran (compiled in by the Makefile: rtmodt_build_info), not of the working tree -- a stale or diagnostic .so never inherits the figure
+        binfo = dict(kv.split("=", 1) for kv in pkg._ffi.lib().rtmodt_build_info().decode().split())
+        if binfo.get("diag") != "0":
+            traffic, why = None, "this library is a diagnostic build (make DIAG=1): measured figures are not attached to it"
+        else:
+            traffic, why = load_traffic(os.path.join(ROOT, "profiles", "traffic_current.json"), f"{args.model}-{size}-{S}x{F}", binfo.get("csrc_sha256", "unknown"))
+        res["roofline"]["library_build"] = binfo
         res["roofline"]["traffic"] = traffic
         res["roofline"]["traffic_unit"] = "bytes per step (FETCH_SIZE x2 + WRITE_SIZE over the forward-pass launches)"
         res["roofline"]["traffic_source"] = why
@@ -607,8 +694,18 @@ def main():
                 "value": round(S * Fc * args.steps / m1["elapsed"], 1), "unit": "frames/s",
                 "ms_per_step": round(m1["elapsed"] / args.steps * 1e3, 4), "forward_ms_per_step": round(f1, 4),
                 "achieved_tflops": round(m1["det"].model.conv_flops_per_frame * S * Fc / (f1 * 1e-3) / 1e12, 2)}
+            if Fc == 1:        # first-class: the configuration exactly as BASELINE config 4 words it (one frame of every stream per step)
+                res["value_no_temporal_batching"] = res["one_frame_per_stream_per_step"]["value"]
+                res["frac_no_temporal_batching"] = round(res["one_frame_per_stream_per_step"]["achieved_tflops"] / MFMA_F16_DENSE_PEAK_TFLOPS, 4)
             m1["det"].close()
             m1["trk"].close()
+    elif F == 1:
+        res["value_no_temporal_batching"] = res["value"]
+        res["frac_no_temporal_batching"] = res["roofline"]["frac"]
+
+    # ---- BASELINE configs 3 / 5: the 200- and 500-box association sequences, bit-checked against the reference-generated fixtures ----
+    if world == 1 and not args.no_tracker_stress:
+        res["tracker_stress"] = tracker_stress(pkg, dev)
 
     # ---- single-stream latency (BASELINE config 1/2 shape: batch 1, sync per frame) ----
     if not args.no_latency:

@@ -44,6 +44,12 @@ typedef struct rtmodt_zones rtmodt_zones;
 /* ---- library / device ------------------------------------------------------------- */
 const char *rtmodt_last_error(void);
 const char *rtmodt_version(void);
+/* "csrc_sha256=<digest of the kernel sources this binary was built from> diag=<0|1>": bench.py attaches a measured
+ * roofline.traffic only to a library whose digest equals the one the counters were collected on */
+const char *rtmodt_build_info(void);
+/* The value of the run-time option RTMODT_<name> exactly as the library reads it (NULL when unset).  Options are read at
+ * detector-create / autotune time only, from ONE table (csrc/common.h); a name outside it is RTMODT_E_INVALID -- never an abort. */
+int rtmodt_option(const char *name, const char **value);
 int rtmodt_device_count(int *count);
 int rtmodt_synchronize(int device);                 /* replaces torch.cuda.synchronize() (latency_profiler.py:63,69) */
 int rtmodt_device_alloc(int device, size_t bytes, void **out);

@@ -61,6 +61,8 @@ def lib() -> C.CDLL:
     sig = {
         "rtmodt_last_error": (C.c_char_p, []),
         "rtmodt_version": (C.c_char_p, []),
+        "rtmodt_build_info": (C.c_char_p, []),
+        "rtmodt_option": (C.c_int, [C.c_char_p, C.POINTER(C.c_char_p)]),
         "rtmodt_device_count": (C.c_int, [C.POINTER(C.c_int)]),
         "rtmodt_synchronize": (C.c_int, [C.c_int]),
         "rtmodt_device_alloc": (C.c_int, [C.c_int, C.c_size_t, C.POINTER(vp)]),

@@ -57,11 +57,15 @@ static inline const char *rt_env(const char *name) {
     snprintf(buf, sizeof(buf), "RTMODT_%s", name);
     return getenv(buf);
 }
+// A name that is not in the table is a programming error of the LIBRARY; it must still not take the host process down: the
+// lookup answers "unset", the error text goes to rtmodt_last_error(), and a sticky flag makes the next rtmodt_detector_create /
+// rtmodt_option call return RTMODT_E_INVALID (engine.hip: note_bad_option / bad_option_pending).
+void note_bad_option(const char *name);
 static inline const char *rt_opt(const char *name) {
     for (const char *k : kOptions)
         if (strcmp(k, name) == 0) return rt_env(name);
-    fprintf(stderr, "rtmodt: option %s is not in common.h's table\n", name);
-    abort();
+    note_bad_option(name);
+    return nullptr;
 }
 #if defined(RTMODT_DIAG)
 static inline const char *rt_diag(const char *name) { return rt_env(name); }

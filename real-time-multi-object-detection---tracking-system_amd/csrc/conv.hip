@@ -1029,6 +1029,15 @@ static int make_args(const ConvLaunch &c, ConvArgs &a) {
     return RTMODT_OK;
 }
 
+// the ping-pong kernels' 24-bit index bound (tile_math.h: pp_index_fits) for a launch description -- the same quantities make_args / launch_conv_group
+// hand to conv_pp.hip's own check, without needing device pointers: M is the largest enumeration either kernel uses (tap reuse: Ho x (in_Wp - 1) positions)
+bool conv_pp_index_fits(const ConvLaunch &c) {
+    const long out_hwc = (long)(c.out.H + 2 * c.out.pad) * c.out.padded_w() * c.out.C;
+    const long res_hwc = c.res.base ? (long)(c.res.H + 2 * c.res.pad) * c.res.padded_w() * c.res.C : 0L;
+    const long in_wp = c.in.padded_w();
+    return pp_index_fits(out_hwc, res_hwc, (long)c.out.H * in_wp, (long)c.B * c.out.H * std::max(in_wp, (long)c.out.W));
+}
+
 // n independent convolutions in ONE launch with tile configuration `tile`
 int launch_conv_group(const ConvLaunch *c, int n, int tile, hipStream_t s) {
     RT_CHECK(n >= 1 && n <= MAX_GROUP, RTMODT_E_INVALID, "launch_conv_group: %d problems", n);

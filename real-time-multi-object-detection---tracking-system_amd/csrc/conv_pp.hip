@@ -111,8 +111,7 @@ __device__ __forceinline__ PpOut pp_out(const ConvArgs &p, int rows_wq, const Fa
 }
 // the host-side condition of PpOut's 24-bit multiplies
 static bool pp_out_fits(const ConvArgs &a) {
-    const long lim = 1L << 24;
-    return (long)a.out_Hp * a.out_Wp * a.out_cs < lim && (!a.res || (long)a.res_Hp * a.res_Wp * a.res_cs < lim) && (long)a.Ho * a.in_Wp < lim && a.M < (1 << 30);
+    return pp_index_fits((long)a.out_Hp * a.out_Wp * a.out_cs, a.res ? (long)a.res_Hp * a.res_Wp * a.res_cs : 0L, (long)a.Ho * a.in_Wp, a.M);
 }
 
 template <int N>

@@ -8,6 +8,7 @@
 //   letterbox -> [graph: stem, 60-odd MFMA convs, SPPF pools, upsamples, decode] -> NMS
 // on a private HIP stream.  No PyTorch, no BLAS/MIOpen: only the kernels in this directory.
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstring>
 #include <fstream>
@@ -43,6 +44,17 @@ static void install_debug_handlers() {
 std::string &last_error() {
     static thread_local std::string e;
     return e;
+}
+
+// rt_opt() met a name that common.h's table lacks: remembered (process-wide) until an entry point reports it
+static std::atomic<bool> g_bad_option{false};
+static char g_bad_option_name[64] = "";
+void note_bad_option(const char *name) {
+    if (!g_bad_option.exchange(true)) snprintf(g_bad_option_name, sizeof(g_bad_option_name), "%s", name ? name : "(null)");
+}
+static int bad_option_pending() {
+    if (!g_bad_option.exchange(false)) return RTMODT_OK;
+    return fail(RTMODT_E_INVALID, "option RTMODT_%s is not in csrc/common.h's table (a library bug: every option the library reads must be listed there)", g_bad_option_name);
 }
 
 int fail(int code, const char *fmt, ...) {
@@ -889,6 +901,9 @@ static bool tile_legal(const ConvLaunch *c, int n, int t) {
                           c[0].cout % tile_shape(t).bn != 0 || c[0].out.coff % 8 != 0 || c[0].out.C % 8 != 0)) return false;
     if (tile_is_ppt(t) && (n != 1 || c[0].out2.base || c[0].res.base || c[0].kp != c[0].ks * c[0].ks * c[0].cin || c[0].ks * c[0].ks * (c[0].cin / 64) < 3 ||
                            c[0].cout % 8 != 0 || c[0].out.coff % 8 != 0 || c[0].out.C % 8 != 0)) return false;
+    if (tile_is_pp(t) || tile_is_ppt(t))         // 24-bit index arithmetic in their epilogues: larger tensors keep the other tiles (YOLOv8l / x above ~900 pixels)
+        for (int i = 0; i < n; ++i)
+            if (!conv_pp_index_fits(c[i])) return false;
     // the ping-pong 3x3 kernel stores (and reads the shortcut) 16 bytes per lane, has no second destination, and its 192-wide form no shortcut
     if (tile_is_pp(t))
         for (int i = 0; i < n; ++i)
@@ -925,7 +940,14 @@ static int tune_conv(rtmodt_detector *d, hipEvent_t e0, hipEvent_t e1, const std
         static const std::string skip = rt_diag("TUNE_SKIP") ? std::string(",") + rt_diag("TUNE_SKIP") + "," : std::string();
         if (!skip.empty() && skip.find("," + std::to_string(t) + ",") != std::string::npos) continue;
         float ms;
-        RT_TRY(time_launch(d, e0, e1, [&]() { return launch_conv_group(c, n, t, d->stream); }, ms));
+        {   // a tile whose launch check refuses this shape is "not a candidate", not a failed create; anything else is an error
+            const int trc = time_launch(d, e0, e1, [&]() { return launch_conv_group(c, n, t, d->stream); }, ms);
+            if (trc == RTMODT_E_INVALID || trc == RTMODT_E_UNSUPPORTED) {
+                if (rt_opt("TUNE_LOG")) fprintf(stderr, "[tune] %-28s %-16s refused: %s\n", name.c_str(), tile_name(t), last_error().c_str());
+                continue;
+            }
+            RT_TRY(trc);
+        }
         if (rt_opt("TUNE_LOG")) fprintf(stderr, "[tune] %-28s %-16s %8.2f us  (%d KiB LDS)\n", name.c_str(), tile_name(t), ms * 1e3f, tile_lds_kib(t));
         // the launches are timed ALONE, but in the staged engine they share the CUs with the other stages' launches: a tile
         // whose workgroup takes more than half the LDS keeps every other workgroup off its CU (experiment hook)
@@ -1362,6 +1384,11 @@ extern "C" {
 
 const char *rtmodt_last_error(void) { return last_error().c_str(); }
 const char *rtmodt_version(void) { return "rtmodt-hip 0.1 (gfx950)"; }
+int rtmodt_option(const char *name, const char **value) {
+    RT_CHECK(name && value, RTMODT_E_INVALID, "null argument");
+    *value = rt_opt(name);
+    return bad_option_pending();
+}
 
 int rtmodt_device_count(int *count) {
     RT_CHECK(count, RTMODT_E_INVALID, "null argument");
@@ -1541,6 +1568,7 @@ int rtmodt_detector_create(const rtmodt_det_cfg *cfg, rtmodt_detector **out) {
     install_debug_handlers();
     rtmodt_detector *d = new rtmodt_detector();
     int rc = detector_create_impl(cfg, d);
+    if (rc == RTMODT_OK) rc = bad_option_pending();
     if (rc != RTMODT_OK) {
         std::string keep = last_error();
         rtmodt_detector_destroy(d);

@@ -91,6 +91,7 @@ struct ConvLaunch {
 };
 
 int launch_conv(const ConvLaunch &c, hipStream_t s);
+bool conv_pp_index_fits(const ConvLaunch &c);   // the ping-pong kernels' 24-bit index bound (tile_math.h: pp_index_fits); part of the tuner's candidate filter
 // n (<= 6) independent convolutions sharing one tile configuration, in ONE launch
 int launch_conv_group(const ConvLaunch *c, int n, int tile, hipStream_t s);
 

@@ -125,6 +125,15 @@ struct PpIssue { int nB, nA; };
 RT_HD PpIssue pp_issue(int kw, int lb, bool wave0, int la0 = 2, int la1 = 2) { return kw == 0 ? PpIssue{lb, la0 + (wave0 ? 1 : 0)} : (kw == 1 ? PpIssue{lb, la1} : PpIssue{lb, 0}); }
 constexpr int pp_wait_count(int kw, int lb, bool wave0, int la0 = 2, int la1 = 2) { return kw == 0 ? lb + la0 + (wave0 ? 1 : 0) : (kw == 1 ? la0 + (wave0 ? 1 : 0) + lb + la1 : lb); }
 
+// The ping-pong kernels' epilogue (conv_pp.hip: PpOut) forms element offsets with 24-bit multiplies: every factor -- the padded H x W x C of ONE image of
+// the output tensor and of the shortcut tensor, and Ho x (positions enumerated per input row) -- must stay below 2^24, the enumerated positions below 2^30.
+// Shared by the launch check (conv_pp.hip: pp_out_fits) and by the tuner's candidate filter (engine.hip: tile_legal), so that a tile the kernel would
+// refuse is never timed nor taken from a cache (YOLOv8l's layer-2 concat tensor, 258 x 258 x 320 at 1024 pixels, exceeds it).
+RT_HD bool pp_index_fits(long out_hwc, long res_hwc /* 0: no shortcut */, long ho_inwp, long m) {
+    const long lim = 1L << 24;
+    return out_hwc < lim && res_hwc < lim && ho_inwp < lim && m < (1L << 30);
+}
+
 // Which tiles each persistent workgroup of a (grouped) ping-pong launch runs: longest-processing-time-first inside each XCD's share.
 // A launch holds the tiles of up to 6 problems back to back (launch-linear ids, problem z = ids start[z] .. start[z] + tiles[z]), sorted deepest K
 // first; workgroup g of G (G % 8 == 0 or G < 8) sits, under round-robin placement, on XCD g & 7 and is given ids with the same residue mod 8 (the ids

@@ -237,4 +237,43 @@ static int check_pp_lpt() {
     return 0;
 }
 
-int main() { return check_fastdiv() || check_xcd_tile() || check_pt_run() || check_swizzle() || check_nms_math() || check_pp_schedule() || check_pp_lpt(); }
+// pp_index_fits: whenever it accepts a tensor, PpOut's 24-bit multiplies (conv_pp.hip) give the exact element offset of every corner position; and the
+// case ADVICE r04 names -- YOLOv8l's layer-2 concat tensor (5 x 64 channels) at 1024 / 1280 pixels -- is refused (so is every tensor above 2^24 elements per image).
+static unsigned umul24(unsigned a, unsigned b) { return (unsigned)(((unsigned long long)(a & 0xFFFFFFu) * (b & 0xFFFFFFu)) & 0xFFFFFFFFull); }
+static int check_pp_index() {
+    const double widths[5] = {0.25, 0.5, 0.75, 1.0, 1.25};
+    const int reps[5] = {1, 1, 2, 3, 3};                      // Bottlenecks of the layer-2 C2f
+    long accepted = 0, refused = 0;
+    for (int sc = 0; sc < 5; ++sc)
+        for (int size = 320; size <= 1280; size += 32)
+            for (int level = 0; level < 4; ++level) {          // the C2f concat tensors at strides 4, 8, 16, 32
+                const int H = size >> (2 + level), c = (int)(std::min(64 << (level + 1), sc >= 3 ? 512 : 1024) * widths[sc] / 8 + 0.999) * 8 / 2;
+                const int n = level == 0 || level == 3 ? reps[sc] : 2 * reps[sc], C = (2 + n) * c;
+                const int Hp = H + 2, Wp = H + 2, B = 32;
+                const long hwc = (long)Hp * Wp * C;
+                const bool fits = pp_index_fits(hwc, hwc, (long)H * Wp, (long)B * H * Wp);
+                if (hwc >= (1L << 24) && fits) { printf("pp_index_fits accepts %d x %d x %d\n", Hp, Wp, C); return 1; }
+                if (!fits) { ++refused; continue; }
+                ++accepted;
+                const int o2 = Wp * C, o1 = Hp * o2, o0 = o2 + C, wq = Wp - 1, HW = H * wq;
+                const FastDiv d_img = make_fastdiv(HW), d_row = make_fastdiv(wq);
+                const int ms[6] = {0, wq - 1, HW - 1, HW, (B - 1) * HW + (H - 1) * wq + H - 1, B * HW - 1};
+                for (int m : ms) {
+                    const int b = fdiv(m, d_img), rem = m - (int)umul24((unsigned)b, (unsigned)HW);
+                    const int oy = fdiv(rem, d_row), ox = rem - (int)umul24((unsigned)oy, (unsigned)wq);
+                    const int opix = o0 + (int)umul24((unsigned)b, (unsigned)o1) + (int)umul24((unsigned)oy, (unsigned)o2) + (int)umul24((unsigned)ox, (unsigned)C);
+                    const long eb = m / HW, er = m % HW, ey = er / wq, ex = er % wq;
+                    const long exact = (long)o0 + eb * o1 + ey * o2 + ex * C;
+                    if (exact < (1L << 31) && (long)opix != exact) { printf("PpOut index: m %d of %d x %d x %d: %d != %ld\n", m, Hp, Wp, C, opix, exact); return 1; }
+                }
+            }
+    const long l1024 = 258L * 258 * 320, l1280 = 322L * 322 * 320, s640 = 162L * 162 * 96;
+    if (pp_index_fits(l1024, 0, 256L * 258, 256L * 258) || pp_index_fits(l1280, 0, 320L * 322, 320L * 322) || !pp_index_fits(s640, s640, 160L * 162, 32L * 160 * 162)) {
+        printf("pp_index_fits: the YOLOv8l layer-2 tensors must be refused, YOLOv8s @ 640 accepted\n");
+        return 1;
+    }
+    printf("ok pp index bound (%ld tensors accepted and exact, %ld refused)\n", accepted, refused);
+    return 0;
+}
+
+int main() { return check_pp_index() || check_fastdiv() || check_xcd_tile() || check_pt_run() || check_swizzle() || check_nms_math() || check_pp_schedule() || check_pp_lpt(); }

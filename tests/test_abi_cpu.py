@@ -18,6 +18,27 @@ def test_library_exports_every_declared_symbol(pkg):
     assert b"gfx950" in L.rtmodt_version()
 
 
+def test_unknown_option_is_an_error_not_an_abort(pkg):
+    """csrc/common.h: rt_opt() on a name outside the option table used to abort() inside the shared library; it now reads
+    as unset, and the entry point that met it returns RTMODT_E_INVALID with the name in rtmodt_last_error().  Known names read the
+    environment exactly as the library does at create time."""
+    import ctypes as C
+    import os
+    L = pkg._ffi.lib()
+    v = C.c_char_p()
+    assert L.rtmodt_option(b"NOT_AN_OPTION", C.byref(v)) == pkg._ffi.E_INVALID
+    assert b"NOT_AN_OPTION" in L.rtmodt_last_error() and v.value is None
+    assert L.rtmodt_option(b"TUNE_LOG", C.byref(v)) == 0      # (the sticky flag was consumed by the failing call)
+    os.environ["RTMODT_STAGES"] = "2"
+    try:
+        assert L.rtmodt_option(b"STAGES", C.byref(v)) == 0 and v.value == b"2"
+    finally:
+        del os.environ["RTMODT_STAGES"]
+    assert L.rtmodt_option(b"STAGES", C.byref(v)) == 0 and v.value is None
+    info = L.rtmodt_build_info().decode()
+    assert info.startswith("csrc_sha256=") and info.endswith("diag=0"), info
+
+
 def test_detector_signature_matches_reference(pkg):
     """src/detection/detector.py:59-70 -- names, order and defaults of the constructor."""
     sig = inspect.signature(pkg.Detector.__init__)

@@ -1,6 +1,7 @@
 """CPU, world_size 2 over gloo: the N > 1 layout of the hot path -- streams sharded by
 ``stream_id % world``, no data-path collective, barrier + max-time + stats all-reduce -- with
 the pinned tracker oracle standing in for the per-rank GPU work."""
+import os
 import socket
 
 import numpy as np
@@ -101,3 +102,56 @@ def test_bench_starts_its_own_ranks_when_run_bare():
     bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--launch-check"],
                          env=env2, capture_output=True, text=True, timeout=120)
     assert bad.returncode != 0 and "WORLD_SIZE=1" in bad.stderr
+
+
+def test_eight_ranks_join_and_share_one_weight_file():
+    """what can be proven about the 8-GPU run without the node.  `bench.py --gpus 8` run bare starts 8 ranks (gloo here,
+    nobody touches a GPU), all of them join, the single-writer weight file (temporary name + rename by rank 0) is read WHOLE by all 8 after
+    the barrier, every rank contributes its own entry to `per_rank_frames_s`, and the one line printed says n_gpus = 8."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "1"
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--backend", "gloo", "--one-device", "--launch-check"],
+                         env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 8 and rec["ranks_joined"] == 8
+    assert rec["per_rank_frames_s"] == [float(r) for r in range(8)]
+    assert rec["ranks_that_read_the_whole_weight_file"] == 8
+
+
+def _tune_cache_writer(path, rank, q):
+    # what engine.hip's autotune_ops does with RTMODT_TUNE_CACHE: whole file to "<path>.tmp.<pid>", then rename()
+    body = "#rtmodt-tune tiles=25 table=0\n" + "".join(f"key{k}\t{rank} {rank} {rank}\n" for k in range(2000))
+    tmp = f"{path}.tmp.{os.getpid()}"
+    with open(tmp, "w") as f:
+        f.write(body)
+    os.replace(tmp, path)
+    q.put(len(body))
+
+
+def test_eight_concurrent_creators_never_leave_half_a_file(tmp_path):
+    """Eight processes rewriting ONE tune-cache / weight file at once through temporary name + rename (the engine's and bench.py's protocol):
+    a reader sees one writer's complete file, never a mixture, and no temporary is left behind."""
+    import multiprocessing as mp
+    path = str(tmp_path / "shared.txt")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_tune_cache_writer, args=(path, r, q)) for r in range(8)]
+    for p in procs:
+        p.start()
+    sizes = [q.get(timeout=60) for _ in procs]
+    for p in procs:
+        p.join(timeout=30)
+        assert p.exitcode == 0
+    txt = open(path).read()
+    assert len(txt) in sizes
+    owners = {line.split("\t")[1] for line in txt.splitlines()[1:]}
+    assert len(owners) == 1, "mixed writers in one file"
+    assert [f for f in os.listdir(tmp_path) if ".tmp." in f] == []

@@ -69,7 +69,9 @@ def check_nms(pkg, pred, **kw):
 
 @pytest.fixture(params=["1024", "256"], ids=["1024-threads", "256-threads"])
 def nms_threads(request, monkeypatch):
-    """nms_kernel's two workgroup sizes (1024 = the product's; 256 = rounds 1-2, an A/B hook): the env is read per launch"""
+    """nms_kernel's two workgroup sizes (1024 = the product's; 256 = rounds 1-2, an A/B hook).  RTMODT_NMS_THREADS is resolved into an NmsPlan once per
+    detector (at create) and once per rtmodt_nms_pred call (postprocess.hip: nms_plan_from_options) -- never per launch; check_nms goes through
+    rtmodt_nms_pred, so setting the variable before the call is enough."""
     monkeypatch.setenv("RTMODT_NMS_THREADS", request.param)
     return request.param
 

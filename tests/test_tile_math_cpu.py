@@ -15,4 +15,4 @@ def test_tile_math_exhaustive(tmp_path):
     out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     sys.stdout.write(out.stdout)
     assert out.returncode == 0, out.stdout + out.stderr
-    assert out.stdout.count("ok ") == 7
+    assert out.stdout.count("ok ") == 8
