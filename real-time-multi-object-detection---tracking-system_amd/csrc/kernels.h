@@ -122,6 +122,20 @@ struct LetterboxGeom { int src_h, src_w, new_w, new_h, top, left, resize; };
 struct FramePtrs { const uint8_t *p[64]; };
 int launch_stem_fused(const FramePtrs &frames, int frame0, int pitch, const LetterboxGeom &g, int in_h, int in_w, const f16 *lut,
                       const TensorView &out, const f16 *wm, const float *bias, int B, int cout, hipStream_t s);
+// The net's front end in ONE launch (front.hip): [letterbox +] stem (3 -> c0, 3x3 / s2) -> layer 1 (c0 -> c1, 3x3 / s2) -> C2f.cv1 of layer 2 (1x1, c1 -> c2);
+// only the last conv's output is stored.  Source: the frames' bytes (frames that need no resize) or the letterboxed RGB0 image tensor.
+struct FrontLaunch {
+    FramePtrs frames; int frame0 = 0, pitch = 0; LetterboxGeom g{};      // byte source
+    TensorView img4; bool from_tensor = false;                           // tensor source
+    const f16 *zeros = nullptr;                                          // >= 16 bytes of zeros in device memory
+    const f16 *w0 = nullptr, *w1 = nullptr, *w2 = nullptr;               // stem [c0][64] (k' = kh*16 + kw*4 + c), layer 1 [c1][kp1] (kh, kw, cin), 2.cv1 [c2][kp2]
+    const float *b0 = nullptr, *b1 = nullptr, *b2 = nullptr;
+    int kp1 = 0, kp2 = 0;
+    TensorView out;                                                      // 2.cv1's output view
+    int B = 1, c0 = 0, c1 = 0, c2 = 0, in_h = 0, in_w = 0;
+};
+bool front_supported(int c0, int c1, int c2, int in_h, int in_w);
+int launch_front(const FrontLaunch &l, hipStream_t s);
 // SPPF: y -> (max5(y), max5(max5(y)), max5^3(y)) written to three channel slices of the same tensor
 int launch_sppf_pool(const TensorView &y, const TensorView &p1, const TensorView &p2, const TensorView &p3, int B,
                      hipStream_t s);
