@@ -164,8 +164,13 @@ struct Op {
     // with their own tiles); the autotuner keeps whichever is faster on this device and batch
     BottleneckLaunch bneck;
     bool fused = true;
-    TensorView v[4];                 // STEM: in,out; POOL: y,p1,p2,p3; UP: in,out
+    TensorView v[4];                 // STEM: in,out [, 2.cv1's output when the front end can run fused]; POOL: y,p1,p2,p3; UP: in,out
     const f16 *stem_w = nullptr; const float *stem_b = nullptr;
+    // STEM: the front end as ONE launch (front.hip: stem -> layer 1 -> C2f.cv1 of layer 2; only v[2] is stored).  `front_ok`: the graph allows it;
+    // `front_on`: it runs (the ops of layer 1 and 2.cv1 are then skipped)
+    bool front_ok = false, front_on = false;
+    const f16 *front_w1 = nullptr, *front_w2 = nullptr; const float *front_b1 = nullptr, *front_b2 = nullptr;
+    int front_kp1 = 0, front_kp2 = 0, front_c1 = 0, front_c2 = 0;
     int64_t flops = 0;               // per frame
     int B = 1;                       // images this launch covers
     int head_level = -1;             // >= 0: belongs to the Detect branch of that level (independent of the other levels)
@@ -632,6 +637,23 @@ static int build_graph(rtmodt_detector *d, WeightFile &wf) {
                 b.skip = a.tail_on;
             }
         }
+    // The front end as one launch (front.hip): stem -> "1" -> "2.cv1", whose two intermediate tensors have no other reader
+    if (d->ops.size() >= 3 && !rt_diag("NO_FRONT")) {
+        Op &st = d->ops[0], &l1 = d->ops[1], &cv = d->ops[2];
+        if (st.kind == OP_STEM && l1.kind == OP_CONV && l1.name == "1" && cv.kind == OP_CONV && cv.name == "2.cv1" && l1.conv.ks == 3 && l1.conv.stride == 2 &&
+            l1.conv.act == 1 && cv.conv.act == 1 && cv.conv.ks == 1 && cv.conv.stride == 1 && !l1.conv.res.base && !cv.conv.res.base && !l1.conv.out2.base && !cv.conv.out2.base &&
+            l1.conv.in.base == st.v[1].base && l1.conv.cin == st.v[1].c && cv.conv.in.base == l1.conv.out.base && cv.conv.in.coff == l1.conv.out.coff && cv.conv.cin == l1.conv.cout &&
+            front_supported(st.v[1].c, l1.conv.cout, cv.conv.cout, d->in_h, d->in_w) && cv.conv.out.coff % 8 == 0 && cv.conv.out.C % 8 == 0) {
+            st.front_ok = true;
+            st.v[2] = cv.conv.out;
+            st.front_w1 = l1.conv.wt; st.front_b1 = l1.conv.bias; st.front_kp1 = l1.conv.kp; st.front_c1 = l1.conv.cout;
+            st.front_w2 = cv.conv.wt; st.front_b2 = cv.conv.bias; st.front_kp2 = cv.conv.kp; st.front_c2 = cv.conv.cout;
+            if (const char *e = rt_opt("FRONT")) {         // test hook (no autotune): force the fused front end on / off
+                st.front_on = atoi(e) != 0;
+                l1.skip = cv.skip = st.front_on;
+            }
+        }
+    }
     // Detect head: the two first 3x3 convs of a level share their input -> one conv, cout = cbox + ccls
     const int cbox = std::max(16, std::max(c3 / 4, 64)), ccls = std::max(c3, std::min(d->nc, 100));
     const int nc4 = (int)align_up(d->nc, 4), no = 64 + (int)align_up(d->nc, 8);
@@ -835,9 +857,19 @@ static int run_decode(rtmodt_detector *d) { return run_decode_sub(d, 0, d->B, d-
 // The net's first launch for one op list (whole batch, a sub-batch chain, or an arena copy): the stem -- straight from the
 // frames' bytes (`from_bytes`: letterbox folded in) or from the letterboxed image tensor.  frame0: first frame of d->fptrs
 // this op list covers.
+static int front_launch(rtmodt_detector *d, const Op &op, int frame0, bool from_bytes, hipStream_t st) {
+    FrontLaunch f;
+    f.zeros = d->d_zeros;
+    f.w0 = op.stem_w; f.b0 = op.stem_b; f.w1 = op.front_w1; f.b1 = op.front_b1; f.kp1 = op.front_kp1; f.w2 = op.front_w2; f.b2 = op.front_b2; f.kp2 = op.front_kp2;
+    f.out = op.v[2]; f.B = op.B; f.c0 = op.v[1].c; f.c1 = op.front_c1; f.c2 = op.front_c2; f.in_h = d->in_h; f.in_w = d->in_w;
+    if (from_bytes) { f.frames = d->fptrs; f.frame0 = frame0; f.pitch = d->last_pitch; f.g = d->last_lg; }
+    else { f.from_tensor = true; f.img4 = op.v[0]; }
+    return launch_front(f, st);
+}
 static int run_first(rtmodt_detector *d, const std::vector<Op> &ops, int frame0, bool from_bytes, hipStream_t st) {
     const Op &op = ops[0];
     RT_CHECK(op.kind == OP_STEM, RTMODT_E_INVALID, "op 0 is not the stem");
+    if (op.front_on) return front_launch(d, op, frame0, from_bytes, st);
     if (from_bytes) return launch_stem_fused(d->fptrs, frame0, d->last_pitch, d->last_lg, d->in_h, d->in_w, d->lut255, op.v[1], op.stem_w,
                                              op.stem_b, op.B, op.v[1].c, st);
     return run_op_on(op, st);
@@ -1097,6 +1129,30 @@ static int autotune_ops(rtmodt_detector *d, std::vector<Op> &ops) {
         op.tail_on = op.tail_on && op.fused;
         nx.skip = op.tail_on;
     }
+    // the fused front end (stem -> layer 1 -> 2.cv1 in one launch) against the launches it replaces, both reading the letterboxed image tensor (what
+    // the tuner's eager passes run on; the byte source differs by the same letterbox work on either side)
+    if (ops.size() >= 3 && ops[0].kind == OP_STEM && ops[0].front_ok) {
+        Op &st = ops[0], &l1 = ops[1], &cv = ops[2];
+        const std::string key = "front|" + tune_key(d, l1);
+        auto hit = cache.find(key);
+        if (hit != cache.end()) st.front_on = hit->second.fused != 0;
+        else {
+            float ms_old, ms_new;
+            const bool keep1 = l1.skip, keep2 = cv.skip;
+            l1.skip = false; cv.skip = l1.tail_on;         // (the pair as the tuner just left it)
+            RT_TRY(time_launch(d, e0, e1, [&]() { RT_TRY(launch_stem(st.v[0], st.v[1], st.stem_w, st.stem_b, st.B, st.v[1].c, d->stream)); RT_TRY(run_op_on(l1, d->stream)); return run_op_on(cv, d->stream); }, ms_old));
+            RT_TRY(time_launch(d, e0, e1, [&]() { return front_launch(d, st, 0, false, d->stream); }, ms_new));
+            l1.skip = keep1; cv.skip = keep2;
+            st.front_on = ms_new < ms_old;
+            if (rt_opt("TUNE_LOG")) fprintf(stderr, "[tune] %-28s fused front end %8.2f us vs stem + layer 1 (+ 2.cv1) %8.2f us\n", "0 + 1 + 2.cv1", ms_new * 1e3f, ms_old * 1e3f);
+            TuneRec r; r.fused = st.front_on;
+            cache[key] = r;
+            dirty = true;
+        }
+        if (const char *e = rt_opt("FRONT")) st.front_on = atoi(e) != 0;      // A/B and test hook
+        if (st.front_on) l1.skip = cv.skip = true;
+        else { l1.skip = false; cv.skip = l1.tail_on; }
+    }
     hipEventDestroy(e0); hipEventDestroy(e1);
     if (cache_path && dirty) {                            // whole file rewritten through a rename: readers never see half a file
         const std::string tmp = std::string(cache_path) + ".tmp." + std::to_string((long)getpid());
@@ -1117,7 +1173,7 @@ static int autotune_tiles(rtmodt_detector *d) {
         dst.conv.tile = src.conv.tile;
         dst.group_tile = src.group_tile;
         dst.fused = src.fused;
-        dst.tail_on = src.tail_on; dst.tail_tile = src.tail_tile; dst.skip = src.skip;
+        dst.tail_on = src.tail_on; dst.tail_tile = src.tail_tile; dst.skip = src.skip; dst.front_on = src.front_on;
         for (size_t g = 0; g < dst.group.size(); ++g) dst.group[g].tile = src.group[g].tile;
     };
     if (d->n_chains > 1) {
@@ -1923,8 +1979,10 @@ int rtmodt_detector_debug_layer(rtmodt_detector *d, const char *name, int img, u
         if (d->newest >= 0) d->cur_dense = d->newest;
         RT_TRY(materialize_heads(d));                      // Detect's last convs live inside head_final
     }
+    if (!ops.empty() && ops[0].kind == OP_STEM && ops[0].front_on && (strcmp(name, "0") == 0 || strcmp(name, "1") == 0))
+        return fail(RTMODT_E_UNSUPPORTED, "%s lives in LDS only: the front end (stem, layer 1, 2.cv1) runs as one launch", name);
     for (auto &op : ops)                               // a conv whose 1x1 tail runs in the same launch stores only the tail's output
-        if (op.kind == OP_CONV && op.tail_on && op.name == name)
+        if (op.kind == OP_CONV && op.tail_on && !op.skip && op.name == name)
             return fail(RTMODT_E_UNSUPPORTED, "%s is consumed in LDS by the 1x1 conv fused into its launch", name);
     for (auto &op : ops)                               // ... and so does a fused Bottleneck whose C2f.cv2 runs as its tail
         if (op.kind == OP_BNECK && op.fused && op.tail_on && op.name == std::string(name).substr(0, std::string(name).rfind('.')) + " (cv1+cv2)")
@@ -1973,7 +2031,11 @@ int rtmodt_detector_profile(rtmodt_detector *d, int iters, int max_entries, cons
     d->prof_names.clear();
     for (auto &op : ops) {
         char buf[160];
-        if (op.kind == OP_CONV && op.skip) {
+        if (op.kind == OP_CONV && op.skip && ops[0].kind == OP_STEM && ops[0].front_on && (&op == &ops[1] || &op == &ops[2])) {
+            snprintf(buf, sizeof(buf), "%s [runs inside the front-end launch]", op.name.c_str());
+        } else if (op.kind == OP_STEM && op.front_on) {
+            snprintf(buf, sizeof(buf), "%s [front end fused: %sstem + layer 1 + 2.cv1, one launch]", op.name.c_str(), d->last_fused ? "letterbox + " : "");
+        } else if (op.kind == OP_CONV && op.skip) {
             snprintf(buf, sizeof(buf), "%s [runs as the tail of the previous launch]", op.name.c_str());
         } else if (op.kind == OP_CONV) {
             snprintf(buf, sizeof(buf), "%s [M=%d N=%d K=%d k%d s%d tile %s]", op.name.c_str(), PB * op.conv.out.H * op.conv.out.W,

@@ -24,6 +24,8 @@
 //
 // Second source (`img`): the letterboxed RGB0 fp16 image tensor (frames that needed a resize went through preprocess.hip): its pixels are DMA'd
 // straight into the pixel tile, T1 disappears.
+#include <type_traits>
+
 #include "conv_dev.h"
 
 namespace rtmodt {
@@ -35,15 +37,20 @@ constexpr int F_SH = 2 * F_TH + 1, F_SW = 2 * F_TW + 1; // 17 x 33 stem position
 constexpr int F_PH = 2 * F_SH + 1, F_PW = 2 * F_SW + 2; // 35 rows x 68 columns of source pixels (the last column only meets the stem's zero 4th tap)
 constexpr int F_PIXROW = F_PW * 8;                      // bytes per pixel row (RGB0 fp16)
 constexpr int F_RAWCH = 14, F_RAWROW = F_RAWCH * 16;    // raw bytes per row: 3 * 68 = 204 + up to 15 of misalignment -> 14 chunks
-constexpr int F_NE = (F_SW + 1) / 2, F_NO = F_SW / 2;   // even / odd stem columns of a row: 17 / 16
-constexpr int F_EVEN = F_SH * F_NE, F_ODD = F_SH * F_NO;                       // 289 / 272 positions
-constexpr int F_EG = (F_EVEN + 15) / 16, F_OG = (F_ODD + 15) / 16;             // 19 / 17 groups of 16
+// Stem outputs live in two planes of 64-byte rows: EVEN columns 0, 2, ..., 32 (17 per stem row, row pitch 24) and ODD columns 1, ..., 31 (16 per row,
+// pitch 16).  Layer 1's taps kw = 0 / 1 / 2 of output columns p = 0..15 then read rows (pitch * stem row) + p of the even / odd / even (+ 1) plane:
+// sixteen CONSECUTIVE rows -- and with pitches that are multiples of 8 the swizzle term of a row depends on the lane only, so every address in this
+// kernel is (one per-lane base register) + (compile-time offset): without that the hoisted address registers alone spill the kernel.
+constexpr int F_EP = 24, F_OP = 16;
 constexpr int RAW_OFF = 0, RAW_BYTES = 8 * 1024;                               // 35 x 14 = 490 chunks -> 8 wave instructions
 constexpr int PIX_OFF = RAW_OFF + RAW_BYTES, PIX_BYTES = 19 * 1024;            // 35 x 544 = 19 040 -> 19 wave instructions (tensor source)
-constexpr int SE_OFF = PIX_OFF + PIX_BYTES, SO_OFF = SE_OFF + F_EG * 16 * 64;  // stem planes, 64 B per position
-constexpr int F_LDS = SO_OFF + F_OG * 16 * 64;
-constexpr int Y1_OFF = PIX_OFF, Y2_OFF = SE_OFF;                               // layer 1's tile reuses the pixel tile, 2.cv1's the stem planes
-static_assert(F_PH * F_RAWROW <= RAW_BYTES && F_PH * F_PIXROW <= PIX_BYTES && F_TH * F_TW * 128 <= PIX_BYTES && F_TH * F_TW * 128 <= F_EG * 16 * 64, "LDS map");
+constexpr int SE_OFF = PIX_OFF + PIX_BYTES, SE_BYTES = F_SH * F_EP * 64;
+constexpr int SO_OFF = SE_OFF + SE_BYTES, SO_BYTES = F_SH * F_OP * 64;
+constexpr int W2_OFF = SO_OFF + SO_BYTES, W2_BYTES = 8 * 1024;                 // 2.cv1's weights as MFMA fragments [cout tile][k half][lane]
+constexpr int B2_OFF = W2_OFF + W2_BYTES, B2_BYTES = 256;                      // its bias [cout tile][q]
+constexpr int F_LDS = B2_OFF + B2_BYTES;
+constexpr int Y1_OFF = PIX_OFF, Y2_OFF = SE_OFF;                               // layer 1's tile reuses the pixel tile, 2.cv1's the even stem plane
+static_assert(F_PH * F_RAWROW <= RAW_BYTES && F_PH * F_PIXROW <= PIX_BYTES && F_TH * F_TW * 128 <= PIX_BYTES && F_TH * F_TW * 128 <= SE_BYTES, "LDS map");
 static_assert(F_LDS <= 80 * 1024, "two workgroups per CU");
 
 struct FrontArgs {
@@ -60,19 +67,25 @@ struct FrontArgs {
 __device__ __forceinline__ int s_off(int R, int c) { return R * 64 + (swz_slot<64>(R, c) << 4); }
 __device__ __forceinline__ int y_off(int R, int c) { return R * 128 + (swz_slot<128>(R, c) << 4); }
 
+// diagnostic build only (-DRTMODT_STAMP, tools/probes/front_probe.hip): phase stamps of a workgroup's SECOND tile (steady state)
+#if defined(RTMODT_STAMP)
+#define FST(k) do { if (t == (int)(blockIdx.x + gridDim.x)) STAMP(k); } while (0)
+#else
+#define FST(k)
+#endif
+
 template <bool TENSOR>
 __global__ __launch_bounds__(256, 2) void front_fused(FrontArgs a) {
     __shared__ __attribute__((aligned(1024))) unsigned char lds[F_LDS];
-    unsigned char *const raw = lds + RAW_OFF, *const pix = lds + PIX_OFF, *const sE = lds + SE_OFF, *const sO = lds + SO_OFF;
-    unsigned char *const y1 = lds + Y1_OFF, *const y2 = lds + Y2_OFF;
+    unsigned char *const raw = lds + RAW_OFF, *const pix = lds + PIX_OFF;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int p = lane & 15, q = lane >> 4;
     const int ch = wave & 1, ph = wave >> 1;               // layer 1 / 2.cv1: this wave's cout half (32 couts) and pixel half (4 rows)
 
-    // ---- weights and biases of the three convs -> registers, once per workgroup ----
-    half8 w0f[2][2], w1f[2][9], w2f[2][2];
-    floatx4 b0v[2], b1v[2], b2v[2];
+    // ---- weights and biases: stem and layer 1 -> registers, 2.cv1 -> LDS (as fragments), once per workgroup ----
+    half8 w0f[2][2], w1f[2][9];
+    floatx4 b0v[2], b1v[2];
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
 #pragma unroll
@@ -82,10 +95,32 @@ __global__ __launch_bounds__(256, 2) void front_fused(FrontArgs a) {
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) w1f[u][tap] = *(const half8 *)(a.w1 + (size_t)(n + p) * a.kp1 + tap * 32 + q * 8);
         b1v[u] = *(const floatx4 *)(a.b1 + n + q * 4);
-#pragma unroll
-        for (int kc = 0; kc < 2; ++kc) w2f[u][kc] = *(const half8 *)(a.w2 + (size_t)(n + p) * a.kp2 + kc * 32 + q * 8);
-        b2v[u] = *(const floatx4 *)(a.b2 + n + q * 4);
     }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {                          // fragment (cout tile ug, k half kc) = 2 * wave + i of 2.cv1's weights
+        const int fr = 2 * wave + i, ug = fr >> 1, kc = fr & 1;
+        *(half8 *)(lds + W2_OFF + fr * 1024 + lane * 16) = *(const half8 *)(a.w2 + (size_t)(ug * 16 + p) * a.kp2 + kc * 32 + q * 8);
+    }
+    if (tid < 16) *(floatx4 *)(lds + B2_OFF + tid * 16) = *(const floatx4 *)(a.b2 + (tid >> 2) * 16 + (tid & 3) * 4);
+
+    // ---- per-lane LDS addresses (bytes from `lds`), tile-independent; everything else is a compile-time offset from one of these ----
+    const int sw = ((p >> 2) & 1) << 1;                                                    // swizzle term of rows (multiple of 8) + p
+    const int st_src = PIX_OFF + (4 * p + 2 * (q & 1)) * 8 + (q >> 1) * F_PIXROW;           // stem fragment of even column 2 p, kernel rows 0 / 1, stem row 0
+    const int st_src2 = PIX_OFF + (4 * p + 2 * (q & 1)) * 8 + 2 * F_PIXROW;                 // ... kernel row 2
+    const int st_dst = p * 64 + (((q >> 1) ^ sw) << 4) + (q & 1) * 8;                       // where (row pitch * g + p, cout tile 0) goes inside a plane; tile 1: ^ 32
+    const int l1_e0 = SE_OFF + (8 * ph * F_EP + p) * 64 + ((q ^ sw) << 4);                  // layer-1 fragment, kw = 0, stem row 8 ph
+    const int l1_e2 = SE_OFF + (8 * ph * F_EP + p + 1) * 64 + ((q ^ ((((p + 1) >> 2) & 1) << 1)) << 4);      // kw = 2
+    const int l1_o = SO_OFF + (8 * ph * F_OP + p) * 64 + ((q ^ sw) << 4);                   // kw = 1
+    const int rot = 2 * (p >> 1);                                                           // rotation of 128-byte rows (multiple of 16) + p
+    int y_wr[2], y_rd[2];                                                                   // tile [pixel][64 channels]: this wave's writes (cout tile u) and reads (k half kc), row 4 ph
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        y_wr[u] = (64 * ph + p) * 128 + ((((2 * ch + u) * 2 + (q >> 1) + rot) & 7) << 4) + (q & 1) * 8;
+        y_rd[u] = (64 * ph + p) * 128 + (((u * 4 + q + rot) & 7) << 4);
+    }
+    const int st_px = tid >> 3;                                                             // T6: pixel (+ 32 k) and chunk of this thread's stores
+    const int st_rd = Y2_OFF + st_px * 128 + ((((tid & 7) + 2 * (st_px >> 1)) & 7) << 4);
+    const int st_go = ((st_px >> 4) * a.out_Wp + (st_px & 15)) * a.out_cs + (tid & 7) * 8;
 
     const int per_img = a.tiles_x * a.tiles_y;
     auto decode = [&](int t, int &b, int &y0, int &x0) {
@@ -93,11 +128,15 @@ __global__ __launch_bounds__(256, 2) void front_fused(FrontArgs a) {
         const int r = t - b * per_img, ty = r / a.tiles_x;
         y0 = ty * F_TH; x0 = (r - ty * a.tiles_x) * F_TW;
     };
-    // byte source: where row r of tile (b, y0, x0) starts inside its frame (relative to the frame's 16-byte aligned base `flo`), floor-aligned to 16
-    auto raw_base = [&](const uint8_t *f, int sy, int cx0) -> long {
-        const long row0 = (long)((uintptr_t)f & 15) + (long)sy * a.pitch;
-        return (row0 + 3L * (cx0 - a.left)) & ~15L;
-    };
+    // ---- source DMA.  Which (row, chunk) of a tile's source a lane fetches does not depend on the tile: worked out once. ----
+    // byte source: 35 rows x 14 chunks = 490 chunks = 8 wave instructions (2 per wave); tensor source: 35 x 34 = 1 190 chunks = 19 (4 or 5 per wave)
+    constexpr int NSRC = TENSOR ? 5 : 2, SRC_CH = TENSOR ? F_PW / 2 : F_RAWCH, SRC_INSTR = TENSOR ? 19 : 8;
+    int src_rj[NSRC];
+#pragma unroll
+    for (int i = 0; i < NSRC; ++i) {
+        const int g = (wave + 4 * i) * 64 + lane;
+        src_rj[i] = min(g / SRC_CH, F_PH - 1) | ((g - (g / SRC_CH) * SRC_CH) << 8);
+    }
     auto issue_src = [&](int t) {
         int b, y0, x0;
         decode(t, b, y0, x0);
@@ -105,106 +144,150 @@ __global__ __launch_bounds__(256, 2) void front_fused(FrontArgs a) {
         if constexpr (TENSOR) {
             // pixel rows straight from the image tensor: chunk j of row r = canvas pixels (cx0 + 2 j, + 1) of canvas row cy0 + r; what lies outside the
             // bordered tensor (rows / columns -3, -2 of the first tiles) comes from the zero page
-#pragma unroll 1
-            for (int k = wave; k < 19; k += 4) {
-                const int g = k * 64 + lane, r = min(g / 34, F_PH - 1), j = g - (g / 34) * 34;
-                const int ty = cy0 + r + 1, tx = cx0 + 2 * j + 1;              // padded tensor coordinates
-                const bool ok = ty >= 0 && tx >= 0;
-                const f16 *src = ok ? a.img + ((size_t)(b * a.img_Hp + ty) * a.img_Wp + tx) * 4 : a.zeros;
-                glds16(src, pix + k * 1024);
+            const f16 *img_b = a.img + (size_t)b * a.img_Hp * a.img_Wp * 4;
+#pragma unroll
+            for (int i = 0; i < NSRC; ++i) {
+                if (wave + 4 * i >= SRC_INSTR) break;
+                const int ty = cy0 + (src_rj[i] & 255) + 1, tx = cx0 + 2 * (src_rj[i] >> 8) + 1;      // padded tensor coordinates
+                const f16 *src = ty >= 0 && tx >= 0 ? img_b + (ty * a.img_Wp + tx) * 4 : a.zeros;
+                glds16(src, pix + (wave + 4 * i) * 1024);
             }
         } else {
             const uint8_t *f = a.frames.p[a.frame0 + b];
-            const uint8_t *flo = f - ((uintptr_t)f & 15);
-            const long fspan = (long)(((uintptr_t)f & 15) + a.frame_bytes + 15) & ~15L;
-#pragma unroll 1
-            for (int k = wave; k < 8; k += 4) {
-                const int g = k * 64 + lane, r = min(g / F_RAWCH, F_PH - 1), j = g - (g / F_RAWCH) * F_RAWCH;
-                const int sy = min(max(cy0 + r - a.top, 0), a.new_h - 1);      // rows outside the image: any row of the frame (never read)
-                long off = raw_base(f, sy, cx0) + 16 * j;
-                off = off < 0 ? 0 : (off > fspan - 16 ? fspan - 16 : off);     // chunks that hold no byte of the frame: clamped into its pages (never read)
-                glds16((const f16 *)(flo + off), raw + k * 1024);
+            const int mis = (int)((uintptr_t)f & 15);
+            const uint8_t *flo = f - mis;
+            const int fspan = (mis + a.frame_bytes + 15) & ~15;                 // (frame_bytes < 2^31: checked at launch)
+            const int col0 = mis + 3 * (cx0 - a.left);
+#pragma unroll
+            for (int i = 0; i < NSRC; ++i) {
+                const int sy = min(max(cy0 + (src_rj[i] & 255) - a.top, 0), a.new_h - 1);     // rows outside the image: any row of the frame (never read)
+                int off = ((sy * a.pitch + col0) & ~15) + 16 * (src_rj[i] >> 8);              // the row's first needed byte, floor-aligned, + this lane's chunk
+                off = min(max(off, 0), fspan - 16);                                           // chunks that hold no byte of the frame: clamped into its pages (never read)
+                glds16((const f16 *)(flo + off), raw + (wave + 4 * i) * 1024);
             }
         }
+    };
+
+    // ---- one group of 16 stem positions x 32 couts per call pair: fragments, 2 x 2 MFMAs, SiLU, fp16 -> plane.  NB groups at a time: independent
+    // chains the scheduler interleaves.  src / src2: LDS byte addresses of the fragments; dst: of the lane's 8 bytes of cout tile 0 ----
+    auto stem_groups = [&](auto nb_c, const int (&src)[decltype(nb_c)::value], const int (&src2)[decltype(nb_c)::value], const int (&dst)[decltype(nb_c)::value],
+                           const bool (&zero)[decltype(nb_c)::value]) {
+        constexpr int NB = decltype(nb_c)::value;
+        half8 a0[NB], a1[NB];
+#pragma unroll
+        for (int k = 0; k < NB; ++k) { a0[k] = *(const half8 *)(lds + src[k]); a1[k] = *(const half8 *)(lds + src2[k]); }
+        floatx4 acc[NB][2];
+#pragma unroll
+        for (int k = 0; k < NB; ++k)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) acc[k][u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w0f[u][0], a0[k], b0v[u], 0, 0, 0);
+#pragma unroll
+        for (int k = 0; k < NB; ++k)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) acc[k][u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w0f[u][1], a1[k], acc[k][u], 0, 0, 0);
+#pragma unroll
+        for (int k = 0; k < NB; ++k)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                silu4(acc[k][u]);
+                half4 h = {(f16)acc[k][u][0], (f16)acc[k][u][1], (f16)acc[k][u][2], (f16)acc[k][u][3]};
+                if (zero[k]) h = half4{(f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f};
+                *(half4 *)(lds + (dst[k] ^ (u * 32))) = h;
+            }
     };
 
     int t = blockIdx.x;
     if (t >= a.n_tiles) return;
     issue_src(t);
+    bool first = true;
 
     for (; t < a.n_tiles; t += gridDim.x) {
         int b, y0, x0;
         decode(t, b, y0, x0);
         const int cy0 = 4 * y0 - 3, cx0 = 4 * x0 - 3;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        FST(0);
+        // this tile's source pieces are the OLDEST outstanding memory operations of the wave; the previous tile's four 16-byte stores were issued after
+        // them and may stay in flight (vmcnt retires in issue order)
+        if (first) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        first = false;
         __syncthreads();                                   // T0: this tile's source has landed; every wave has left the previous tile
+        FST(1);
         if constexpr (!TENSOR) {
             // ---- T1: bytes -> (R, G, B, 0) fp16; byte -> float -> * (1 / 255) -> half == the letterbox kernel's half(c / 255.f) for all 256 values ----
             const uint8_t *f = a.frames.p[a.frame0 + b];
-            for (int i = tid; i < F_PH * (F_PW / 4); i += 256) {
+            const int col0 = (int)((uintptr_t)f & 15) + 3 * (cx0 - a.left), pm = a.pitch & 15;
+            // Branch-free, so that the (up to) three items of a thread are independent instruction streams the scheduler interleaves (LDS latency of one under
+            // the conversions of another): the twelve bytes are always read (from inside the raw row, whatever they are), then every pixel picks its bytes,
+            // the letterbox fill 114 (canvas outside the image) or 0 (outside the canvas: the stem's zero padding).
+#pragma unroll
+            for (int it = 0; it < (F_PH * (F_PW / 4) + 255) / 256; ++it) {
+                if (it * 256 + wave * 64 >= F_PH * (F_PW / 4)) break;            // (wave-uniform: the last pass has work for waves 0 and 1 only)
+                const int i = min(it * 256 + tid, F_PH * (F_PW / 4) - 1);        // (surplus lanes of the last wave repeat the last item)
                 const int r = i / (F_PW / 4), gq = i - r * (F_PW / 4);
                 const int cy = cy0 + r, sy = cy - a.top, cx = cx0 + 4 * gq;
                 const bool row_canvas = cy >= 0 && cy < a.in_h, row_img = row_canvas && sy >= 0 && sy < a.new_h;
-                unsigned d0, d1, d2;
-                bool canvas[4];
+                // offset of canvas column cx inside the raw row: (first needed byte of the row) mod 16 + 12 bytes per group
+                const int o = (row_img ? (sy * pm + col0) & 15 : 0) + 12 * gq;
+                const unsigned *rp = (const unsigned *)(raw + r * F_RAWROW + (o & ~3));
+                const unsigned q0 = rp[0], q1 = rp[1], q2 = rp[2], q3 = rp[3];
+                const unsigned sh = (unsigned)(o & 3);
+                const unsigned d0 = __builtin_amdgcn_alignbyte(q1, q0, sh), d1 = __builtin_amdgcn_alignbyte(q2, q1, sh), d2 = __builtin_amdgcn_alignbyte(q3, q2, sh);
+                const unsigned px[4] = {d0, __builtin_amdgcn_alignbyte(d1, d0, 3), __builtin_amdgcn_alignbyte(d2, d1, 2), d2 >> 8};      // B | G << 8 | R << 16 (| junk << 24)
+                half4 h[4];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) canvas[k] = row_canvas && cx + k >= 0 && cx + k < a.in_w;
-                const unsigned char *rr = raw + r * F_RAWROW;
-                const int o = row_img ? (int)((long)((uintptr_t)f & 15) + (long)sy * a.pitch + 3L * (cx - a.left) - raw_base(f, sy, cx0)) : 0;
-                if (row_img && cx >= a.left && cx + 3 < a.left + a.new_w) {
-                    const unsigned *rp = (const unsigned *)(rr + (o & ~3));
-                    const unsigned q0 = rp[0], q1 = rp[1], q2 = rp[2], q3 = rp[3];
-                    const unsigned sh = (unsigned)(o & 3);
-                    d0 = __builtin_amdgcn_alignbyte(q1, q0, sh);
-                    d1 = __builtin_amdgcn_alignbyte(q2, q1, sh);
-                    d2 = __builtin_amdgcn_alignbyte(q3, q2, sh);
-                } else {                                   // the group straddles an edge of the image or lies outside it: byte by byte
-                    unsigned dd[3] = {0u, 0u, 0u};
-#pragma unroll
-                    for (int j = 0; j < 12; ++j) {
-                        const int x = cx + j / 3;
-                        const bool in_img = row_img && x >= a.left && x < a.left + a.new_w;
-                        const unsigned v = in_img ? rr[o + j] : 114u;
-                        dd[j >> 2] |= v << (8 * (j & 3));
-                    }
-                    d0 = dd[0]; d1 = dd[1]; d2 = dd[2];
+                for (int k = 0; k < 4; ++k) {
+                    const int x = cx + k;
+                    const bool in_img = row_img && x >= a.left && x < a.left + a.new_w, in_canvas = row_canvas && x >= 0 && x < a.in_w;
+                    const unsigned v = in_img ? px[k] : 0x727272u;
+                    const float sc = in_canvas ? 1.0f / 255.0f : 0.0f;
+                    h[k] = half4{(f16)((float)((v >> 16) & 255u) * sc), (f16)((float)((v >> 8) & 255u) * sc), (f16)((float)(v & 255u) * sc), (f16)0.f};
                 }
-                auto cv = [&](unsigned byte, bool in) -> f16 { return (f16)((float)byte * (in ? 1.0f / 255.0f : 0.0f)); };
-                half8 lo, hi;
-                lo[0] = cv((d0 >> 16) & 255u, canvas[0]); lo[1] = cv((d0 >> 8) & 255u, canvas[0]); lo[2] = cv(d0 & 255u, canvas[0]); lo[3] = (f16)0.f;
-                lo[4] = cv((d1 >> 8) & 255u, canvas[1]); lo[5] = cv(d1 & 255u, canvas[1]); lo[6] = cv(d0 >> 24, canvas[1]); lo[7] = (f16)0.f;
-                hi[0] = cv(d2 & 255u, canvas[2]); hi[1] = cv(d1 >> 24, canvas[2]); hi[2] = cv((d1 >> 16) & 255u, canvas[2]); hi[3] = (f16)0.f;
-                hi[4] = cv(d2 >> 24, canvas[3]); hi[5] = cv((d2 >> 16) & 255u, canvas[3]); hi[6] = cv((d2 >> 8) & 255u, canvas[3]); hi[7] = (f16)0.f;
-                *(half8 *)(pix + r * F_PIXROW + gq * 32) = lo;
-                *(half8 *)(pix + r * F_PIXROW + gq * 32 + 16) = hi;
+                unsigned char *dst = pix + r * F_PIXROW + gq * 32;
+                *(half8 *)dst = half8{h[0][0], h[0][1], h[0][2], h[0][3], h[1][0], h[1][1], h[1][2], h[1][3]};
+                *(half8 *)(dst + 16) = half8{h[2][0], h[2][1], h[2][2], h[2][3], h[3][0], h[3][1], h[3][2], h[3][3]};
             }
+            FST(2);
             __syncthreads();                               // the raw rows are free: the next tile's bytes travel under the rest of this tile
             if (t + (int)gridDim.x < a.n_tiles) issue_src(t + gridDim.x);
         }
+        FST(3);
 
-        // ---- T3: stem over the two planes of positions ----
-        for (int gi = wave; gi < F_EG + F_OG; gi += 4) {
-            const bool odd = gi >= F_EG;
-            const int ncol = odd ? F_NO : F_NE;
-            const int idx = min((odd ? gi - F_EG : gi) * 16 + p, (odd ? F_ODD : F_EVEN) - 1);      // the last even group: rows past the plane re-read its last position
-            const int syr = idx / ncol, sxr = 2 * (idx - syr * ncol) + (odd ? 1 : 0);
-            const unsigned char *src = pix + (2 * syr) * F_PIXROW + (2 * sxr + 2 * (q & 1)) * 8;
-            const half8 a0 = *(const half8 *)(src + (q >> 1) * F_PIXROW);      // kernel rows 0 / 1
-            const half8 a1 = *(const half8 *)(src + 2 * F_PIXROW);             // kernel row 2 (k' >= 48 meets zero weights)
-            const bool inside = 2 * y0 - 1 + syr >= 0 && 2 * x0 - 1 + sxr >= 0;   // row / column -1 of the stem's output = layer 1's zero padding
-            unsigned char *dst = (odd ? sO : sE);
-            const int R = (odd ? gi - F_EG : gi) * 16 + p;
+        // ---- T3: stem.  36 groups of 16 positions: stem row g's even columns 0 .. 30 (E g, 17 groups), its odd columns (O g, 17), and column 32 of
+        // all rows (X0: rows 0 .. 15, X1: row 16).  Wave w: E g for g = w mod 4, O g for g = 3 - w mod 4, X0 -> wave 1, X1 -> wave 2: nine each.
+        // Row / column -1 of the stem's output (first tiles only) is layer 1's zero padding. ----
+        {
+            const bool top = y0 == 0, lft = x0 == 0 && p == 0;
+            const int eb = wave, ob = 3 - wave;            // first even / odd row of this wave
+            {
+                int srcE[4], src2E[4], dstE[4], srcO[4], src2O[4], dstO[4];
+                bool zE[4], zO[4];
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                floatx4 acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(w0f[u][0], a0, b0v[u], 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(w0f[u][1], a1, acc, 0, 0, 0);
-                silu4(acc);
-                half4 h = {(f16)acc[0], (f16)acc[1], (f16)acc[2], (f16)acc[3]};
-                if (!inside) h = half4{(f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f};
-                *(half4 *)(dst + s_off(R, u * 2 + (q >> 1)) + (q & 1) * 8) = h;
+                for (int k = 0; k < 4; ++k) {
+                    srcE[k] = st_src + (eb + 4 * k) * 2 * F_PIXROW; src2E[k] = st_src2 + (eb + 4 * k) * 2 * F_PIXROW; dstE[k] = SE_OFF + st_dst + (eb + 4 * k) * F_EP * 64;
+                    zE[k] = (top && eb + 4 * k == 0) || lft;
+                    srcO[k] = st_src + 16 + (ob + 4 * k) * 2 * F_PIXROW; src2O[k] = st_src2 + 16 + (ob + 4 * k) * 2 * F_PIXROW; dstO[k] = SO_OFF + st_dst + (ob + 4 * k) * F_OP * 64;
+                    zO[k] = top && ob + 4 * k == 0;
+                }
+                stem_groups(std::integral_constant<int, 4>{}, srcE, src2E, dstE, zE);
+                stem_groups(std::integral_constant<int, 4>{}, srcO, src2O, dstO, zO);
             }
+            // the ninth group: E 16 (wave 0), O 16 (wave 3), X0 (wave 1: column 32 of stem rows p), X1 (wave 2: column 32 of row 16; lanes p > 0 repeat it)
+            int src9, src29, dst9;
+            if (wave == 0) { src9 = st_src + 16 * 2 * F_PIXROW; src29 = st_src2 + 16 * 2 * F_PIXROW; dst9 = SE_OFF + st_dst + 16 * F_EP * 64; }
+            else if (wave == 3) { src9 = st_src + 16 + 16 * 2 * F_PIXROW; src29 = st_src2 + 16 + 16 * 2 * F_PIXROW; dst9 = SO_OFF + st_dst + 16 * F_OP * 64; }
+            else {
+                const int row = wave == 1 ? p : 16;
+                src9 = PIX_OFF + (64 + 2 * (q & 1)) * 8 + (2 * row + (q >> 1)) * F_PIXROW;
+                src29 = PIX_OFF + (64 + 2 * (q & 1)) * 8 + (2 * row + 2) * F_PIXROW;
+                dst9 = SE_OFF + (row * F_EP + 16) * 64 + (((q >> 1) ^ 0) << 4) + (q & 1) * 8;      // row pitch * row + 16: bit 2 of the row index is 0 -> no swizzle term
+            }
+            const int s9[1] = {src9}, s29[1] = {src29}, d9[1] = {dst9};
+            const bool z9[1] = {(wave == 0 && lft) || (wave == 1 && top && p == 0)};
+            stem_groups(std::integral_constant<int, 1>{}, s9, s29, d9, z9);
         }
+        FST(4);
         __syncthreads();                                   // stem planes complete; the pixel tile is dead
+        FST(5);
 
         // ---- T4: layer 1.  Output row 4 ph + i, tap (kh, kw) reads stem row 2 (4 ph + i) + kh, columns 2 p + kw ----
         floatx4 acc[4][2];
@@ -214,11 +297,10 @@ __global__ __launch_bounds__(256, 2) void front_fused(FrontArgs a) {
             for (int u = 0; u < 2; ++u) acc[i][u] = floatx4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int s = 0; s < 9; ++s) {
-            const int syr = 8 * ph + s;
             half8 fr[3];
-            fr[0] = *(const half8 *)(sE + s_off(syr * F_NE + p, q));
-            fr[1] = *(const half8 *)(sO + s_off(syr * F_NO + p, q));
-            fr[2] = *(const half8 *)(sE + s_off(syr * F_NE + p + 1, q));
+            fr[0] = *(const half8 *)(lds + l1_e0 + s * F_EP * 64);
+            fr[1] = *(const half8 *)(lds + l1_o + s * F_OP * 64);
+            fr[2] = *(const half8 *)(lds + l1_e2 + s * F_EP * 64);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int kh = s - 2 * i;
@@ -229,57 +311,59 @@ __global__ __launch_bounds__(256, 2) void front_fused(FrontArgs a) {
                     for (int u = 0; u < 2; ++u) acc[i][u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1f[u][kh * 3 + kw], fr[kw], acc[i][u], 0, 0, 0);
             }
         }
-        // NOTE on order: an accumulator meets its taps as (kh, kw) = (0,0) (0,1) (0,2) (1,0) ... -- the k order of the launch this replaces
+        FST(6);
+        // (an accumulator meets its taps as (kh, kw) = (0,0) (0,1) (0,2) (1,0) ... -- the k order of the launch this replaces)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int px = (4 * ph + i) * 16 + p;
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 floatx4 v = acc[i][u] + b1v[u];
                 silu4(v);
-                *(half4 *)(y1 + y_off(px, (2 * ch + u) * 2 + (q >> 1)) + (q & 1) * 8) = half4{(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
+                *(half4 *)(lds + Y1_OFF + y_wr[u] + i * 2048) = half4{(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
             }
-        }
+        FST(7);
         __syncthreads();                                   // layer 1's tile complete (both cout halves); the stem planes are dead
+        FST(8);
 
-        // ---- T5: 2.cv1 (1x1) on the tile ----
+        // ---- T5: 2.cv1 (1x1) on the tile; weight fragments and bias from LDS ----
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int u = 0; u < 2; ++u) acc[i][u] = floatx4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kc = 0; kc < 2; ++kc) {
-            half8 fa[4];
+            half8 fa[4], fw[2];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) fa[i] = *(const half8 *)(y1 + y_off((4 * ph + i) * 16 + p, kc * 4 + q));
+            for (int u = 0; u < 2; ++u) fw[u] = *(const half8 *)(lds + W2_OFF + ((2 * ch + u) * 2 + kc) * 1024 + lane * 16);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) fa[i] = *(const half8 *)(lds + Y1_OFF + y_rd[kc] + i * 2048);
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int u = 0; u < 2; ++u) acc[i][u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2f[u][kc], fa[i], acc[i][u], 0, 0, 0);
+                for (int u = 0; u < 2; ++u) acc[i][u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[u], fa[i], acc[i][u], 0, 0, 0);
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int px = (4 * ph + i) * 16 + p;
+        for (int u = 0; u < 2; ++u) {
+            const floatx4 b2v = *(const floatx4 *)(lds + B2_OFF + ((2 * ch + u) * 4 + q) * 16);
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                floatx4 v = acc[i][u] + b2v[u];
+            for (int i = 0; i < 4; ++i) {
+                floatx4 v = acc[i][u] + b2v;
                 silu4(v);
-                *(half4 *)(y2 + y_off(px, (2 * ch + u) * 2 + (q >> 1)) + (q & 1) * 8) = half4{(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
+                *(half4 *)(lds + Y2_OFF + y_wr[u] + i * 2048) = half4{(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
             }
         }
+        FST(9);
         __syncthreads();                                   // 2.cv1's tile complete; nobody reads layer 1's tile (= the pixel tile's LDS) any more
         if constexpr (TENSOR) {                            // tensor source: the pixel tile doubled as layer 1's tile, so its next load starts only here
             if (t + (int)gridDim.x < a.n_tiles) issue_src(t + gridDim.x);
         }
 
         // ---- T6: 16-byte NHWC stores (8 chunks = one 128-byte line per pixel) ----
-        f16 *const orow = a.out + ((size_t)(b * a.out_Hp + y0 + a.out_pad) * a.out_Wp + x0 + a.out_pad) * a.out_cs;
+        f16 *const orow = a.out + ((size_t)(b * a.out_Hp + y0 + a.out_pad) * a.out_Wp + x0 + a.out_pad) * a.out_cs + st_go;
+        const int row2 = 2 * a.out_Wp * a.out_cs;          // thread's pixels: rows 2 k + (tid >> 7) of the tile
 #pragma unroll
-        for (int k = 0; k < (F_TH * F_TW * 8) / 256; ++k) {
-            const int e = k * 256 + tid, px = e >> 3, c = e & 7;
-            const half8 v = *(const half8 *)(y2 + y_off(px, c));
-            *(half8 *)(orow + ((size_t)(px >> 4) * a.out_Wp + (px & 15)) * a.out_cs + c * 8) = v;
-        }
+        for (int k = 0; k < (F_TH * F_TW * 8) / 256; ++k) *(half8 *)(orow + k * row2) = *(const half8 *)(lds + st_rd + k * 4096);
+        FST(10);
     }
 }
 

@@ -61,6 +61,11 @@ int main(int argc, char **argv) {
     Net net = make_net();
     hipStream_t st; CK(hipStreamCreate(&st));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+#ifdef RTMODT_STAMP
+    const int STAMP_ROWS = 1 << 15;                          // every kernel of this build stamps: rows for the largest grid (the stem: B x 320 workgroups)
+    unsigned long long *ds; CK(hipMalloc(&ds, (size_t)STAMP_ROWS * 16 * 8)); CK(hipMemset(ds, 0, (size_t)STAMP_ROWS * 16 * 8));
+    CK(hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), &ds, sizeof(ds)));
+#endif
     const Case cases[] = {
         {"640x640 aligned", 640, 640, 640, 640, 0, 0, 0, 0},
         {"640x640 misaligned base +1, pitch +5", 640, 640, 640, 640, 0, 0, 5, 1},
@@ -109,6 +114,28 @@ int main(int argc, char **argv) {
         }
         auto tm = [&](auto &&fn) { fn(); CK(hipEventRecord(e0, st)); for (int i = 0; i < iters; ++i) fn(); CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1)); float ms; CK(hipEventElapsedTime(&ms, e0, e1)); return ms * 1e3f / iters; };
         const float us_ref = tm(run_ref), us_new = tm(run_new);
+#ifdef RTMODT_STAMP
+        {                                                      // phase stamps of every workgroup's second tile: mean clocks between consecutive stamps
+            const int G = 2 * 256;
+            CK(hipStreamSynchronize(st));
+            CK(hipMemset(ds, 0, (size_t)G * 16 * 8));
+            run_new();
+            CK(hipStreamSynchronize(st));
+            std::vector<unsigned long long> hs((size_t)G * 16);
+            CK(hipMemcpy(hs.data(), ds, hs.size() * 8, hipMemcpyDeviceToHost));
+            double sum[11] = {0}; int cnt = 0; double ghz = 0;
+            for (int g = 0; g < G; ++g) {
+                const unsigned long long *r = &hs[(size_t)g * 16];
+                if (!r[10] || !r[0]) continue;
+                for (int k = 1; k <= 10; ++k) sum[k] += (double)(r[k] ? r[k] : r[k - 1]) - (double)(r[k - 1] ? r[k - 1] : r[k]);
+                if (r[15] > r[13]) ghz += (double)(r[14] - r[12]) / (double)(r[15] - r[13]) * 0.1;
+                ++cnt;
+            }
+            printf("    stamps (%d workgroups, ~%.2f GHz): wait+barrier %.0f | convert %.0f | barrier+issue %.0f | stem %.0f | barrier %.0f | L1 mfma %.0f | L1 epilogue %.0f | barrier %.0f | tail %.0f | barrier+stores %.0f  clk; tile total %.0f\n",
+                   cnt, cnt ? ghz / cnt : 0, sum[1] / cnt, sum[2] / cnt, sum[3] / cnt, sum[4] / cnt, sum[5] / cnt, sum[6] / cnt, sum[7] / cnt, sum[8] / cnt, sum[9] / cnt, sum[10] / cnt,
+                   (sum[1] + sum[2] + sum[3] + sum[4] + sum[5] + sum[6] + sum[7] + sum[8] + sum[9] + sum[10]) / cnt);
+        }
+#endif
         printf("%-56s B %2d  bytes source:  %zu / %zu halves differ (max |d| %.4g, first at %zu; %zu non-zero)   two launches %7.1f us   fused %7.1f us\n", c.name, B, diff, n2, maxd, first, nz, us_ref, us_new);
         bad += diff != 0 || nz == 0;
         if (diff) {
