@@ -462,6 +462,7 @@ int launch_bottleneck(const BottleneckLaunch &l, hipStream_t s) {
         a.t_k1 = 2 * l.c; a.t_cout = l.tail_cout; a.t_kp = l.tail_kp; a.t_act = l.tail_act;
         a.t_in_Hp = ti.H + 2; a.t_in_Wp = ti.W + 2; a.t_in_cs = ti.C;
         a.t_out_Hp = to.H + 2 * to.pad; a.t_out_Wp = to.W + 2 * to.pad; a.t_out_cs = to.C; a.t_out_pad = to.pad;
+        if (l.c == 32 && l.persistent32 && bottleneck32_tail_supported(l)) return launch_bottleneck32_tail(l, s);
         if (l.c == 32) return launch_one<32, 16, 16, 4>(a, in.H, in.W, l.B, s);
         return launch_one<64, 16, 16, 8>(a, in.H, in.W, l.B, s);
     }

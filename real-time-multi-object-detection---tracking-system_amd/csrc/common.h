@@ -46,12 +46,12 @@ int fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
 //   diagnostics         DEBUG (print the device / library banner once)
 //   FORCE hooks of the parity tests (tests/test_gpu_detector.py: every kernel variant is run against the oracle, whatever the tuner
 //   would pick on this box): TILE, TILE_K64, TILE_3X3S1, EPI16, TAIL, BNECK, BNECK_TAIL, UP_READ, STEM_FUSE, NO_HEAD_FINAL,
-//                       NMS_THREADS, PAD_STREAMS, FRONT
+//                       NMS_THREADS, PAD_STREAMS, FRONT, BNECK32
 // The A/B switches of finished experiments (profiles/r0N/README.md has their measurements) exist only in a diagnostic build
 // (`make DIAG=1`, -DRTMODT_DIAG): rt_diag() is a constant nullptr otherwise and the branches behind it fold away.
 static const char *const kOptions[] = {"CHAINS", "STAGES", "CHAIN_JOIN", "CHAIN_PROBE", "ZERO_COPY", "TUNE_CACHE", "TUNE_LOG", "DEBUG",
                                        "TILE", "TILE_K64", "TILE_3X3S1", "EPI16", "TAIL", "BNECK", "BNECK_TAIL", "UP_READ", "STEM_FUSE",
-                                       "NO_HEAD_FINAL", "NMS_THREADS", "PAD_STREAMS", "FRONT"};
+                                       "NO_HEAD_FINAL", "NMS_THREADS", "PAD_STREAMS", "FRONT", "BNECK32"};
 static inline const char *rt_env(const char *name) {
     char buf[64];
     snprintf(buf, sizeof(buf), "RTMODT_%s", name);

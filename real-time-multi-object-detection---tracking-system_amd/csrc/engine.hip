@@ -503,6 +503,7 @@ static int build_graph(rtmodt_detector *d, WeightFile &wf) {
                 b.w1 = pair[0].conv.wt; b.b1 = pair[0].conv.bias; b.w2 = pair[1].conv.wt; b.b2 = pair[1].conv.bias;
                 b.zeros = d->d_zeros; b.B = d->B; b.c = c; b.kp = pair[0].conv.kp;
                 if (const char *e = rt_opt("BNECK")) op.fused = atoi(e) != 0;
+                if (const char *e = rt_opt("BNECK32")) b.persistent32 = atoi(e) != 0;      // A/B and test hook: 0 = bottleneck_fused for the c = 32 C2f too
                 d->ops.push_back(op);
                 continue;
             }
@@ -1050,7 +1051,7 @@ static int autotune_ops(rtmodt_detector *d, std::vector<Op> &ops) {
             const TuneRec &r = hit->second;
             if (op.kind == OP_CONV) { op.conv.tile = r.t0; if (op.conv.tail_wt) { op.tail_tile = r.t1; op.tail_on = r.fused != 0; } }
             else if (op.kind == OP_GROUP) op.group_tile = r.t0;
-            else { op.group[0].tile = r.t0; op.group[1].tile = r.t1; op.fused = r.fused != 0; op.tail_on = r.fused == 2 && op.bneck.tail_wt; }
+            else { op.group[0].tile = r.t0; op.group[1].tile = r.t1; op.fused = r.fused != 0; op.tail_on = (r.fused == 2 || r.fused == 4) && op.bneck.tail_wt; }
             continue;
         }
         float ms;
@@ -1111,7 +1112,8 @@ static int autotune_ops(rtmodt_detector *d, std::vector<Op> &ops) {
         if (op.kind != OP_BNECK || !op.bneck.tail_wt) continue;
         const std::string key = tune_key(d, op);
         auto hit = cache.find(key);
-        const bool decided = hit != cache.end() && hit->second.fused >= 2;      // 2 = fused with tail, 3 = tail timed and rejected
+        const bool decided = hit != cache.end() && hit->second.fused >= 2;      // 2 / 4 = fused with tail, 3 = tail timed and rejected
+        if (decided && hit->second.fused == 4) op.bneck.persistent32 = 0;
         if (!decided && op.fused) {
             float ms_plain, ms_cv2, ms_tail;
             BottleneckLaunch plain = op.bneck;
@@ -1119,9 +1121,17 @@ static int autotune_ops(rtmodt_detector *d, std::vector<Op> &ops) {
             RT_TRY(time_launch(d, e0, e1, [&]() { return launch_bottleneck(plain, d->stream); }, ms_plain));
             RT_TRY(time_launch(d, e0, e1, [&]() { return launch_conv(nx.conv, d->stream); }, ms_cv2));
             RT_TRY(time_launch(d, e0, e1, [&]() { return launch_bottleneck(op.bneck, d->stream); }, ms_tail));
+            if (op.bneck.c == 32 && !rt_opt("BNECK32") && bottleneck32_tail_supported(op.bneck)) {      // two kernels for this shape: bneck32.hip's persistent form and bottleneck_fused
+                BottleneckLaunch other = op.bneck;
+                other.persistent32 = !op.bneck.persistent32;
+                float ms_other;
+                RT_TRY(time_launch(d, e0, e1, [&]() { return launch_bottleneck(other, d->stream); }, ms_other));
+                if (rt_opt("TUNE_LOG")) fprintf(stderr, "[tune] %-28s with cv2 tail: persistent %8.2f us vs bottleneck_fused %8.2f us\n", op.name.c_str(), (op.bneck.persistent32 ? ms_tail : ms_other) * 1e3f, (op.bneck.persistent32 ? ms_other : ms_tail) * 1e3f);
+                if (ms_other < ms_tail) { op.bneck.persistent32 = other.persistent32; ms_tail = ms_other; }
+            }
             op.tail_on = ms_tail < ms_plain + ms_cv2;
             if (rt_opt("TUNE_LOG")) fprintf(stderr, "[tune] %-28s with cv2 tail %8.2f us vs fused + cv2 %8.2f us\n", op.name.c_str(), ms_tail * 1e3f, (ms_plain + ms_cv2) * 1e3f);
-            TuneRec r; r.t0 = op.group[0].tile; r.t1 = op.group[1].tile; r.fused = op.tail_on ? 2 : 3;
+            TuneRec r; r.t0 = op.group[0].tile; r.t1 = op.group[1].tile; r.fused = op.tail_on ? (op.bneck.persistent32 ? 2 : 4) : 3;      // 2 / 4: with the tail on bneck32.hip's kernel / on bottleneck_fused
             cache[key] = r;
             dirty = true;
         }
@@ -1173,7 +1183,7 @@ static int autotune_tiles(rtmodt_detector *d) {
         dst.conv.tile = src.conv.tile;
         dst.group_tile = src.group_tile;
         dst.fused = src.fused;
-        dst.tail_on = src.tail_on; dst.tail_tile = src.tail_tile; dst.skip = src.skip; dst.front_on = src.front_on;
+        dst.tail_on = src.tail_on; dst.tail_tile = src.tail_tile; dst.skip = src.skip; dst.front_on = src.front_on; dst.bneck.persistent32 = src.bneck.persistent32;
         for (size_t g = 0; g < dst.group.size(); ++g) dst.group[g].tile = src.group[g].tile;
     };
     if (d->n_chains > 1) {

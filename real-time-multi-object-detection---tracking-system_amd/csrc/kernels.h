@@ -106,9 +106,13 @@ struct BottleneckLaunch {
     // optional C2f.cv2 tail (last Bottleneck of a C2f with n = 1, c in {32, 64}): out2 = act(W . [tail_in (2c channels) | this output] + b);
     // only tail_out is stored
     TensorView tail_in, tail_out; const f16 *tail_wt = nullptr; const float *tail_bias = nullptr; int tail_cout = 0, tail_kp = 0, tail_act = 1;
+    int persistent32 = 1;         // c = 32 with the tail: the persistent two-workgroups-per-CU kernel of bneck32.hip where it applies (0: bottleneck_fused, the A/B and test baseline)
 };
 bool bottleneck_supported(int c);
 int launch_bottleneck(const BottleneckLaunch &l, hipStream_t s);
+// bneck32.hip: the c = 32 Bottleneck + C2f.cv2 tail (YOLOv8s layer 2) as persistent workgroups with cross-tile prefetch; bit-identical to bottleneck_fused
+bool bottleneck32_tail_supported(const BottleneckLaunch &l);
+int launch_bottleneck32_tail(const BottleneckLaunch &l, hipStream_t s);
 
 // stem: 3x3 stride-2 conv on the 4-channel (RGB0) padded fp16 image, cout in {16,32,48,64,80};
 // wm = [cout][64] fp16 in the k' = kh*16 + kw*4 + c order (zero where kw == 3, c == 3 or k' >= 48)

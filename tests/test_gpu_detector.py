@@ -933,6 +933,36 @@ def test_bottleneck_with_c2f_cv2_tail(pkg, wdir, monkeypatch, size, batch):
             assert np.array_equal(outs["0"][img][n], outs["1"][img][n]), (img, n)
 
 
+@pytest.mark.parametrize("size,batch", [(640, 2), (320, 3), (64, 1)])
+def test_persistent_c2f32_kernel_is_bit_identical(pkg, wdir, monkeypatch, size, batch):
+    """csrc/bneck32.hip: YOLOv8s' layer-2 Bottleneck (c = 32) with C2f.cv2 as its tail on persistent 256-thread workgroups (8 x 16 tiles, weights of both 3x3
+    convs in registers, the next tile's patch prefetched by LDS-DMA) against bottleneck_fused<32, 16, 16, 4>: same arithmetic order, so 2.cv2 and
+    everything behind it must be BIT-identical; and within the layer tolerance of the fp32 oracle (two fp16 intermediates in LDS: the 4e-3 class)."""
+    monkeypatch.setenv("RTMODT_BNECK", "1")
+    monkeypatch.setenv("RTMODT_BNECK_TAIL", "1")
+    monkeypatch.setenv("RTMODT_TAIL", "0")
+    frames = list(pkg.synth.frames(batch, size, size, seed=303))
+    outs = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("RTMODT_BNECK32", mode)
+        det, w = make_detector(pkg, wdir, "s", size, autotune=False, batch=batch)
+        dets = det.detect_batch(frames)
+        outs[mode] = ([{n: det.debug_layer(n, i) for n in ("2.cv1", "2.cv2", "4.cv2", "21.cv2")} for i in range(batch)], dets)
+        if mode == "1":
+            inp, _, _ = det.debug_fetch(0, want_heads=False, want_pred=False)
+            lay = outs[mode][0][0]
+            taps = {}
+            Y.forward(inp.astype(np.float32), w, "s", taps=taps, force={n: lay[n].astype(np.float32) for n in ("2.cv1", "2.cv2")}, only={"2.m.0.cv1", "2.m.0.cv2", "2.cv2"})
+            err, tol = float(np.abs(taps["2.cv2"] - lay["2.cv2"].astype(np.float32)).max()), 4e-3 * float(np.abs(taps["2.cv2"]).max()) + 2e-3
+            print(f"persistent c2f32 @ {size}: 2.cv2 err/tol {err / tol:.3f}")
+            assert err <= tol, (err, tol)
+        det.close()
+    for i in range(batch):
+        for n in outs["0"][0][i]:
+            assert np.array_equal(outs["0"][0][i][n].view(np.uint16), outs["1"][0][i][n].view(np.uint16)), (n, i)
+        assert np.array_equal(outs["0"][1][i].xyxy, outs["1"][1][i].xyxy)
+
+
 @pytest.mark.parametrize("src_hw,host", [((320, 320), False), ((320, 320), True), ((240, 416), True)])
 def test_free_running_chains_match_one_chain(pkg, wdir, monkeypatch, src_hw, host):
     """A 16-frame launch set runs as two sub-batch chains on their own streams (stem -> graph -> Detect's tail per chain,
