@@ -120,6 +120,9 @@ def parse():
     ap.add_argument("--no-verify", action="store_true", help="skip the untimed output self-check")
     ap.add_argument("--no-tracker-stress", action="store_true", help="skip the 200- / 500-box association sequences (BASELINE configs 3 / 5)")
     ap.add_argument("--prewarm", type=float, default=1.0, help="seconds of untimed full-pipeline running before the timed region (besides --warmup steps)")
+    ap.add_argument("--cpu-baseline-only", action="store_true",
+                    help="run ONLY the cpu_baseline leg (no GPU is touched) and print its object; tests/perf/cpu_baseline_node.py starts several of these side by side for a whole-box figure")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the cpu_baseline leg (0: min(os.cpu_count(), 16))")
     ap.add_argument("--launch-check", action="store_true",
                     help="rendez-vous only: every rank joins the process group, rank 0 prints {n_gpus, ranks}, nobody touches a GPU (CPU test of the launcher path)")
     ap.add_argument("--long", type=float, default=1.0, help="seconds of the additional long steady-state window reported beside the K timed steps (0: off)")
@@ -133,7 +136,7 @@ def cpu_baseline(pkg, weights, args, budget_s=20.0):
     import torch
     from oracle import yolo_oracle as Y
     from oracle import tracker_oracle_c as TC
-    cores = min(os.cpu_count() or 1, 16)          # a 1-GPU box's CPU share; more threads only oversubscribe these small convs
+    cores = args.cpu_threads if getattr(args, "cpu_threads", 0) > 0 else min(os.cpu_count() or 1, 16)          # a 1-GPU box's CPU share; more threads only oversubscribe these small convs
     torch.set_num_threads(cores)
     frames = pkg.synth.frames(4, args.size, args.size, seed=1234)
     trk = TC.TrackerOracleC()
@@ -342,6 +345,10 @@ def main():
         raise SystemExit(launch_ranks(args))
     import rtmodt_amd  # noqa: F401
     pkg = sys.modules["rtmodt_amd"]
+    if args.cpu_baseline_only:                           # the reference's CPU path restated, alone (no GPU, no process group)
+        weights = pkg.weights.synthetic(args.model, input_size=args.size)
+        print(json.dumps(cpu_baseline(pkg, weights, args)), flush=True)
+        return
     sync = pkg.streams.NodeSync(backend=args.backend)    # RCCL; no process group when WORLD_SIZE == 1
     rank, local_rank, world = sync.rank, sync.local_rank, sync.world
     if args.gpus != world:
