@@ -235,8 +235,8 @@ def verify_outputs(pkg, det, frame_ptrs, size, max_det, weights, scale):
       (1) for every image the fetched detections must equal oracle NMS + scale_boxes applied to the engine's own pre-NMS
           tensor, bit for bit;
       (2) the convs that were just timed: every stored layer of the first and the last image of the batch against the fp32
-          oracle fed the engine's own fp16 inputs (teacher forcing), tolerance 2e-3 * max|ref| + 2e-3 as in tests/ (4e-3 where
-          the tuner may keep an fp16 intermediate in LDS: fused Bottlenecks, conv -> 1x1 pairs) -- a wrong tile in
+          oracle fed the engine's own fp16 inputs (teacher forcing), tolerance 2e-3 * max|ref| + 2e-3 as in tests/ (also where
+          the tuner keeps an fp16 intermediate in LDS: fused Bottlenecks, conv -> 1x1 pairs, the fused front end) -- a wrong tile in
           conv_mfma64_pt, conv3x3_rows_grp, bottleneck_fused or a tail kernel cannot hide behind (1);
       (3) decode on the engine's own head logits, rtol = atol = 2e-4.
     The oracle is the checker; any mismatch aborts the bench."""
@@ -257,8 +257,8 @@ def verify_outputs(pkg, det, frame_ptrs, size, max_det, weights, scale):
         n_box += len(d)
     # (2) + (3)
     names = [c.name for c in pkg.weights.spec(scale)]
-    loose = {"2.cv1", "4.cv1", "6.cv1", "8.cv1", "2.cv2", "15.cv2"}
-    worst, checked = ("", 0.0), 0
+    fused_behind = {"2.cv1", "4.cv1", "6.cv1", "8.cv1", "2.cv2", "15.cv2"}      # consumers of an LDS-resident fp16 intermediate when the tuner fused the pair
+    worst, worst_fused, checked = ("", 0.0), ("", 0.0), 0
     images = sorted({0, len(got) - 1})
     for img in images:
         inp, heads, pred = det.debug_fetch(img)
@@ -272,13 +272,14 @@ def verify_outputs(pkg, det, frame_ptrs, size, max_det, weights, scale):
         taps = {}
         Y.forward(inp.astype(np.float32), weights, scale, taps=taps, force=gpu)
         for n, g in gpu.items():
-            k = 4e-3 if (n in loose or (".m." in n and n.endswith(".cv2"))) else 2e-3
-            tol = k * float(np.abs(taps[n]).max()) + 2e-3
+            tol = 2e-3 * float(np.abs(taps[n]).max()) + 2e-3      # ONE class since round 5 (the 4e-3 allowance behind fused pairs measured 0.23 of 2e-3)
             err = float(np.abs(taps[n] - g).max())
             if not np.isfinite(err) or err > tol:
                 raise SystemExit(f"bench self-check FAILED: image {img} layer {n}: max err {err:.4g} > tol {tol:.4g} vs the fp32 oracle (teacher-forced)")
             if err / tol > worst[1]:
                 worst = (n, err / tol)
+            if (n in fused_behind or (".m." in n and n.endswith(".cv2"))) and err / tol > worst_fused[1]:
+                worst_fused = (n, err / tol)
             checked += 1
         A, maps, off = det.model.n_anchors, [], 0
         for s_ in (size // 8, size // 16, size // 32):
@@ -293,9 +294,10 @@ def verify_outputs(pkg, det, frame_ptrs, size, max_det, weights, scale):
     return {"ok": True, "images": n_img, "boxes": n_box,
             "what": "fetched detections == oracle non_max_suppression + scale_boxes on the engine's pre-NMS tensor (bit-exact), every image of one batch",
             "layers_ok": True, "layers_checked": checked, "layer_images": images,
-            "layers_what": "every stored conv output of these images vs the fp32 oracle fed the engine's own inputs, |err| <= 2e-3 (4e-3 behind an LDS-resident "
-                           "fp16 intermediate) * max|ref| + 2e-3; decode on the engine's head logits rtol = atol = 2e-4",
-            "worst_layer": {"name": worst[0], "err_over_tol": round(worst[1], 3)}, "launches_by_kernel_family": fam}
+            "layers_what": "every stored conv output of these images vs the fp32 oracle fed the engine's own inputs, |err| <= 2e-3 * max|ref| + 2e-3 (one class: also behind "
+                           "an LDS-resident fp16 intermediate); decode on the engine's head logits rtol = atol = 2e-4",
+            "worst_layer": {"name": worst[0], "err_over_tol": round(worst[1], 3)},
+            "worst_layer_behind_a_fused_pair": {"name": worst_fused[0], "err_over_tol": round(worst_fused[1], 3)}, "launches_by_kernel_family": fam}
 
 
 def launch_ranks(args) -> int:

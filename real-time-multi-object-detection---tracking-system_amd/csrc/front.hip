@@ -168,32 +168,22 @@ __global__ __launch_bounds__(256, 2) void front_fused(FrontArgs a) {
         }
     };
 
-    // ---- one group of 16 stem positions x 32 couts per call pair: fragments, 2 x 2 MFMAs, SiLU, fp16 -> plane.  NB groups at a time: independent
-    // chains the scheduler interleaves.  src / src2: LDS byte addresses of the fragments; dst: of the lane's 8 bytes of cout tile 0 ----
-    auto stem_groups = [&](auto nb_c, const int (&src)[decltype(nb_c)::value], const int (&src2)[decltype(nb_c)::value], const int (&dst)[decltype(nb_c)::value],
-                           const bool (&zero)[decltype(nb_c)::value]) {
-        constexpr int NB = decltype(nb_c)::value;
-        half8 a0[NB], a1[NB];
+    // ---- stem building blocks for one group of 16 positions x 32 couts: fragments (two 16-byte reads), 2 x 2 MFMAs, SiLU + fp16 -> plane ----
+    auto st_load = [&](int src, int src2, half8 &a0, half8 &a1) { a0 = *(const half8 *)(lds + src); a1 = *(const half8 *)(lds + src2); };
+    auto st_mma = [&](const half8 &a0, const half8 &a1, floatx4 (&acc)[2]) {
 #pragma unroll
-        for (int k = 0; k < NB; ++k) { a0[k] = *(const half8 *)(lds + src[k]); a1[k] = *(const half8 *)(lds + src2[k]); }
-        floatx4 acc[NB][2];
+        for (int u = 0; u < 2; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w0f[u][0], a0, b0v[u], 0, 0, 0);
 #pragma unroll
-        for (int k = 0; k < NB; ++k)
+        for (int u = 0; u < 2; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w0f[u][1], a1, acc[u], 0, 0, 0);
+    };
+    auto st_store = [&](floatx4 (&acc)[2], int dst, bool zero) {
 #pragma unroll
-            for (int u = 0; u < 2; ++u) acc[k][u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w0f[u][0], a0[k], b0v[u], 0, 0, 0);
-#pragma unroll
-        for (int k = 0; k < NB; ++k)
-#pragma unroll
-            for (int u = 0; u < 2; ++u) acc[k][u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w0f[u][1], a1[k], acc[k][u], 0, 0, 0);
-#pragma unroll
-        for (int k = 0; k < NB; ++k)
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                silu4(acc[k][u]);
-                half4 h = {(f16)acc[k][u][0], (f16)acc[k][u][1], (f16)acc[k][u][2], (f16)acc[k][u][3]};
-                if (zero[k]) h = half4{(f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f};
-                *(half4 *)(lds + (dst[k] ^ (u * 32))) = h;
-            }
+        for (int u = 0; u < 2; ++u) {
+            silu4(acc[u]);
+            half4 h = {(f16)acc[u][0], (f16)acc[u][1], (f16)acc[u][2], (f16)acc[u][3]};
+            if (zero) h = half4{(f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f};
+            *(half4 *)(lds + (dst ^ (u * 32))) = h;
+        }
     };
 
     int t = blockIdx.x;
@@ -218,34 +208,41 @@ __global__ __launch_bounds__(256, 2) void front_fused(FrontArgs a) {
             const int col0 = (int)((uintptr_t)f & 15) + 3 * (cx0 - a.left), pm = a.pitch & 15;
             // Branch-free, so that the (up to) three items of a thread are independent instruction streams the scheduler interleaves (LDS latency of one under
             // the conversions of another): the twelve bytes are always read (from inside the raw row, whatever they are), then every pixel picks its bytes,
-            // the letterbox fill 114 (canvas outside the image) or 0 (outside the canvas: the stem's zero padding).
+            // the letterbox fill 114 (canvas outside the image) or 0 (outside the canvas: the stem's zero padding).  A tile whose 35 x 67 needed pixels all lie
+            // inside the image (85 % of the tiles of a 640 x 640 frame; column 67 only meets the stem's zero tap and may hold any bytes) skips the masks --
+            // 38 % of the masked form's instructions.
+            const bool interior = cy0 >= a.top && cy0 + F_PH <= a.top + a.new_h && cx0 >= a.left && cx0 + F_PW - 1 <= a.left + a.new_w;      // (wave-uniform)
+            auto convert = [&](auto masked_c) {
+                constexpr bool MASKED = decltype(masked_c)::value;
 #pragma unroll
-            for (int it = 0; it < (F_PH * (F_PW / 4) + 255) / 256; ++it) {
-                if (it * 256 + wave * 64 >= F_PH * (F_PW / 4)) break;            // (wave-uniform: the last pass has work for waves 0 and 1 only)
-                const int i = min(it * 256 + tid, F_PH * (F_PW / 4) - 1);        // (surplus lanes of the last wave repeat the last item)
-                const int r = i / (F_PW / 4), gq = i - r * (F_PW / 4);
-                const int cy = cy0 + r, sy = cy - a.top, cx = cx0 + 4 * gq;
-                const bool row_canvas = cy >= 0 && cy < a.in_h, row_img = row_canvas && sy >= 0 && sy < a.new_h;
-                // offset of canvas column cx inside the raw row: (first needed byte of the row) mod 16 + 12 bytes per group
-                const int o = (row_img ? (sy * pm + col0) & 15 : 0) + 12 * gq;
-                const unsigned *rp = (const unsigned *)(raw + r * F_RAWROW + (o & ~3));
-                const unsigned q0 = rp[0], q1 = rp[1], q2 = rp[2], q3 = rp[3];
-                const unsigned sh = (unsigned)(o & 3);
-                const unsigned d0 = __builtin_amdgcn_alignbyte(q1, q0, sh), d1 = __builtin_amdgcn_alignbyte(q2, q1, sh), d2 = __builtin_amdgcn_alignbyte(q3, q2, sh);
-                const unsigned px[4] = {d0, __builtin_amdgcn_alignbyte(d1, d0, 3), __builtin_amdgcn_alignbyte(d2, d1, 2), d2 >> 8};      // B | G << 8 | R << 16 (| junk << 24)
-                half4 h[4];
+                for (int it = 0; it < (F_PH * (F_PW / 4) + 255) / 256; ++it) {
+                    if (it * 256 + wave * 64 >= F_PH * (F_PW / 4)) break;            // (wave-uniform: the last pass has work for waves 0 and 1 only)
+                    const int i = min(it * 256 + tid, F_PH * (F_PW / 4) - 1);        // (surplus lanes of the last wave repeat the last item)
+                    const int r = i / (F_PW / 4), gq = i - r * (F_PW / 4);
+                    const int cy = cy0 + r, sy = cy - a.top, cx = cx0 + 4 * gq;
+                    const bool row_canvas = !MASKED || (cy >= 0 && cy < a.in_h), row_img = !MASKED || (row_canvas && sy >= 0 && sy < a.new_h);
+                    // offset of canvas column cx inside the raw row: (first needed byte of the row) mod 16 + 12 bytes per group
+                    const int o = (row_img ? (sy * pm + col0) & 15 : 0) + 12 * gq;
+                    const unsigned *rp = (const unsigned *)(raw + r * F_RAWROW + (o & ~3));
+                    const unsigned q0 = rp[0], q1 = rp[1], q2 = rp[2], q3 = rp[3];
+                    const unsigned sh = (unsigned)(o & 3);
+                    const unsigned d0 = __builtin_amdgcn_alignbyte(q1, q0, sh), d1 = __builtin_amdgcn_alignbyte(q2, q1, sh), d2 = __builtin_amdgcn_alignbyte(q3, q2, sh);
+                    const unsigned px[4] = {d0, __builtin_amdgcn_alignbyte(d1, d0, 3), __builtin_amdgcn_alignbyte(d2, d1, 2), d2 >> 8};      // B | G << 8 | R << 16 (| junk << 24)
+                    half4 h[4];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int x = cx + k;
-                    const bool in_img = row_img && x >= a.left && x < a.left + a.new_w, in_canvas = row_canvas && x >= 0 && x < a.in_w;
-                    const unsigned v = in_img ? px[k] : 0x727272u;
-                    const float sc = in_canvas ? 1.0f / 255.0f : 0.0f;
-                    h[k] = half4{(f16)((float)((v >> 16) & 255u) * sc), (f16)((float)((v >> 8) & 255u) * sc), (f16)((float)(v & 255u) * sc), (f16)0.f};
+                    for (int k = 0; k < 4; ++k) {
+                        const int x = cx + k;
+                        const bool in_img = !MASKED || (row_img && x >= a.left && x < a.left + a.new_w), in_canvas = !MASKED || (row_canvas && x >= 0 && x < a.in_w);
+                        const unsigned v = in_img ? px[k] : 0x727272u;
+                        const float sc = in_canvas ? 1.0f / 255.0f : 0.0f;
+                        h[k] = half4{(f16)((float)((v >> 16) & 255u) * sc), (f16)((float)((v >> 8) & 255u) * sc), (f16)((float)(v & 255u) * sc), (f16)0.f};
+                    }
+                    unsigned char *dst = pix + r * F_PIXROW + gq * 32;
+                    *(half8 *)dst = half8{h[0][0], h[0][1], h[0][2], h[0][3], h[1][0], h[1][1], h[1][2], h[1][3]};
+                    *(half8 *)(dst + 16) = half8{h[2][0], h[2][1], h[2][2], h[2][3], h[3][0], h[3][1], h[3][2], h[3][3]};
                 }
-                unsigned char *dst = pix + r * F_PIXROW + gq * 32;
-                *(half8 *)dst = half8{h[0][0], h[0][1], h[0][2], h[0][3], h[1][0], h[1][1], h[1][2], h[1][3]};
-                *(half8 *)(dst + 16) = half8{h[2][0], h[2][1], h[2][2], h[2][3], h[3][0], h[3][1], h[3][2], h[3][3]};
-            }
+            };
+            if (interior) convert(std::false_type{}); else convert(std::true_type{});
             FST(2);
             __syncthreads();                               // the raw rows are free: the next tile's bytes travel under the rest of this tile
             if (t + (int)gridDim.x < a.n_tiles) issue_src(t + gridDim.x);
@@ -258,19 +255,6 @@ __global__ __launch_bounds__(256, 2) void front_fused(FrontArgs a) {
         {
             const bool top = y0 == 0, lft = x0 == 0 && p == 0;
             const int eb = wave, ob = 3 - wave;            // first even / odd row of this wave
-            {
-                int srcE[4], src2E[4], dstE[4], srcO[4], src2O[4], dstO[4];
-                bool zE[4], zO[4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    srcE[k] = st_src + (eb + 4 * k) * 2 * F_PIXROW; src2E[k] = st_src2 + (eb + 4 * k) * 2 * F_PIXROW; dstE[k] = SE_OFF + st_dst + (eb + 4 * k) * F_EP * 64;
-                    zE[k] = (top && eb + 4 * k == 0) || lft;
-                    srcO[k] = st_src + 16 + (ob + 4 * k) * 2 * F_PIXROW; src2O[k] = st_src2 + 16 + (ob + 4 * k) * 2 * F_PIXROW; dstO[k] = SO_OFF + st_dst + (ob + 4 * k) * F_OP * 64;
-                    zO[k] = top && ob + 4 * k == 0;
-                }
-                stem_groups(std::integral_constant<int, 4>{}, srcE, src2E, dstE, zE);
-                stem_groups(std::integral_constant<int, 4>{}, srcO, src2O, dstO, zO);
-            }
             // the ninth group: E 16 (wave 0), O 16 (wave 3), X0 (wave 1: column 32 of stem rows p), X1 (wave 2: column 32 of row 16; lanes p > 0 repeat it)
             int src9, src29, dst9;
             if (wave == 0) { src9 = st_src + 16 * 2 * F_PIXROW; src29 = st_src2 + 16 * 2 * F_PIXROW; dst9 = SE_OFF + st_dst + 16 * F_EP * 64; }
@@ -279,11 +263,51 @@ __global__ __launch_bounds__(256, 2) void front_fused(FrontArgs a) {
                 const int row = wave == 1 ? p : 16;
                 src9 = PIX_OFF + (64 + 2 * (q & 1)) * 8 + (2 * row + (q >> 1)) * F_PIXROW;
                 src29 = PIX_OFF + (64 + 2 * (q & 1)) * 8 + (2 * row + 2) * F_PIXROW;
-                dst9 = SE_OFF + (row * F_EP + 16) * 64 + (((q >> 1) ^ 0) << 4) + (q & 1) * 8;      // row pitch * row + 16: bit 2 of the row index is 0 -> no swizzle term
+                dst9 = SE_OFF + (row * F_EP + 16) * 64 + ((q >> 1) << 4) + (q & 1) * 8;      // row pitch * row + 16: bit 2 of the row index is 0 -> no swizzle term
             }
-            const int s9[1] = {src9}, s29[1] = {src29}, d9[1] = {dst9};
-            const bool z9[1] = {(wave == 0 && lft) || (wave == 1 && top && p == 0)};
-            stem_groups(std::integral_constant<int, 1>{}, s9, s29, d9, z9);
+            const bool z9 = (wave == 0 && lft) || (wave == 1 && top && p == 0);
+            // Software pipeline over batches of two groups (E k = 0, 1 | E 2, 3 | O 0, 1 | O 2, 3 | the ninth): the MFMAs of batch b + 1 are issued BETWEEN the
+            // SiLU instructions of batch b (one MFMA, then a slice of VALU work: sched_group_barrier), so the matrix pipe runs in the shadow of the
+            // epilogue instead of in front of it -- stamped: the phase was its MFMA time + its VALU time, the waves of a SIMD taking turns.
+            half8 a0[2][2], a1[2][2];
+            floatx4 acc[2][2][2];
+            auto gsrc = [&](int b, int j, int &s1, int &s2, int &dd, bool &zz) {      // group j of batch b (b < 4)
+                const bool odd = b >= 2;
+                const int k = 2 * (b & 1) + j, row = (odd ? ob : eb) + 4 * k;
+                s1 = st_src + (odd ? 16 : 0) + row * 2 * F_PIXROW; s2 = st_src2 + (odd ? 16 : 0) + row * 2 * F_PIXROW;
+                dd = (odd ? SO_OFF + row * F_OP * 64 : SE_OFF + row * F_EP * 64) + st_dst;
+                zz = (top && row == 0) || (!odd && lft);
+            };
+            int s1, s2, dd[2][2]; bool zz[2][2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) { gsrc(0, j, s1, s2, dd[0][j], zz[0][j]); st_load(s1, s2, a0[0][j], a1[0][j]); }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) st_mma(a0[0][j], a1[0][j], acc[0][j]);
+#pragma unroll
+            for (int b = 1; b < 4; ++b) {
+                const int cur = b & 1, prev = cur ^ 1;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) { gsrc(b, j, s1, s2, dd[cur][j], zz[cur][j]); st_load(s1, s2, a0[cur][j], a1[cur][j]); }
+#pragma unroll
+                for (int j = 0; j < 2; ++j) st_mma(a0[cur][j], a1[cur][j], acc[cur][j]);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) st_store(acc[prev][j], dd[prev][j], zz[prev][j]);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {                  // 8 MFMAs of this batch among the ~80 VALU / transcendental instructions of the previous one
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x402, 9, 0);
+                }
+            }
+            st_load(src9, src29, a0[0][0], a1[0][0]);
+            st_mma(a0[0][0], a1[0][0], acc[0][0]);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) st_store(acc[1][j], dd[1][j], zz[1][j]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
+                __builtin_amdgcn_sched_group_barrier(0x402, 18, 1);
+            }
+            st_store(acc[0][0], dst9, z9);
         }
         FST(4);
         __syncthreads();                                   // stem planes complete; the pixel tile is dead

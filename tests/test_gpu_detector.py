@@ -642,7 +642,7 @@ def test_front_end_fused_is_bit_identical(pkg, wdir, monkeypatch, h, w, rect):
     replaces, forced on / off with the tuner out of the way.  Same MFMA instruction, same k order, fp16 at the same two places: 2.cv1's stored tensor,
     everything behind it and the detections must be BIT-identical.  Sources: the frames' bytes (no resize: 640x640; a smaller frame with letterbox pads
     on an odd pitch; 320x320) and the letterboxed image tensor (1080p resized; rect = its minimal 384x640 rectangle).  The fused-away tensors are
-    reported as such, and 2.cv1 stays within the layer tolerance of the fp32 oracle although TWO fp16 intermediates now stand behind it."""
+    reported as such, and 2.cv1 stays within the ordinary layer tolerance (2e-3) of the fp32 oracle although TWO fp16 intermediates now stand behind it."""
     size = 320 if h == 320 else 640
     pitch = 3 * w + (7 if h == 609 else 0)
     wide = pkg.synth.structured_frames(3, h, pitch // 3 + 1, seed=h + w).reshape(3, -1)[:, :h * pitch]
@@ -674,7 +674,7 @@ def test_front_end_fused_is_bit_identical(pkg, wdir, monkeypatch, h, w, rect):
             taps = {}
             Y.forward(inp.astype(np.float32), wts, "s", taps=taps, force={"2.cv1": layers[0]["2.cv1"].astype(np.float32)}, only={"0", "1", "2.cv1"})
             ref = taps["2.cv1"]
-            err, tol = float(np.abs(ref - layers[0]["2.cv1"].astype(np.float32)).max()), 4e-3 * float(np.abs(ref).max()) + 2e-3
+            err, tol = float(np.abs(ref - layers[0]["2.cv1"].astype(np.float32)).max()), 2e-3 * float(np.abs(ref).max()) + 2e-3
             print(f"front end fused, {h}x{w}: 2.cv1 err/tol {err / tol:.3f}")
             assert err <= tol, (err, tol)
         outs[mode] = (layers, preds, dets)
@@ -960,7 +960,7 @@ def test_bottleneck_with_c2f_cv2_tail(pkg, wdir, monkeypatch, size, batch):
                 taps = {}
                 Y.forward(inp.astype(np.float32), w, "s", taps=taps, force=gpu)
                 for n in gpu:
-                    tol = (4e-3 if n in ("2.cv2", "15.cv2") else 2e-3) * np.abs(taps[n]).max() + 2e-3      # two fp16 intermediates live in LDS
+                    tol = 2e-3 * np.abs(taps[n]).max() + 2e-3      # (also behind the two LDS-resident fp16 intermediates: measured 0.2 of it)
                     assert float(np.abs(taps[n] - gpu[n]).max()) <= tol, (img, n)
         det.close()
     for img in range(batch):
@@ -972,7 +972,7 @@ def test_bottleneck_with_c2f_cv2_tail(pkg, wdir, monkeypatch, size, batch):
 def test_persistent_c2f32_kernel_is_bit_identical(pkg, wdir, monkeypatch, size, batch):
     """csrc/bneck32.hip: YOLOv8s' layer-2 Bottleneck (c = 32) with C2f.cv2 as its tail on persistent 256-thread workgroups (8 x 16 tiles, weights of both 3x3
     convs in registers, the next tile's patch prefetched by LDS-DMA) against bottleneck_fused<32, 16, 16, 4>: same arithmetic order, so 2.cv2 and
-    everything behind it must be BIT-identical; and within the layer tolerance of the fp32 oracle (two fp16 intermediates in LDS: the 4e-3 class)."""
+    everything behind it must be BIT-identical; and within the ordinary layer tolerance (2e-3) of the fp32 oracle, two fp16 intermediates in LDS notwithstanding."""
     monkeypatch.setenv("RTMODT_BNECK", "1")
     monkeypatch.setenv("RTMODT_BNECK_TAIL", "1")
     monkeypatch.setenv("RTMODT_TAIL", "0")
@@ -988,7 +988,7 @@ def test_persistent_c2f32_kernel_is_bit_identical(pkg, wdir, monkeypatch, size, 
             lay = outs[mode][0][0]
             taps = {}
             Y.forward(inp.astype(np.float32), w, "s", taps=taps, force={n: lay[n].astype(np.float32) for n in ("2.cv1", "2.cv2")}, only={"2.m.0.cv1", "2.m.0.cv2", "2.cv2"})
-            err, tol = float(np.abs(taps["2.cv2"] - lay["2.cv2"].astype(np.float32)).max()), 4e-3 * float(np.abs(taps["2.cv2"]).max()) + 2e-3
+            err, tol = float(np.abs(taps["2.cv2"] - lay["2.cv2"].astype(np.float32)).max()), 2e-3 * float(np.abs(taps["2.cv2"]).max()) + 2e-3
             print(f"persistent c2f32 @ {size}: 2.cv2 err/tol {err / tol:.3f}")
             assert err <= tol, (err, tol)
         det.close()
@@ -1208,24 +1208,17 @@ def test_benchmarked_shape_parity(pkg, wdir):
         assert len(gpu) >= 50
         taps = {}
         Y.forward(inp.astype(np.float32), w, "s", taps=taps, force=gpu)
-        worst = {"2e-3": ("", 0.0), "4e-3 (behind an LDS-resident fp16 intermediate)": ("", 0.0), "4e-3 class measured against 2e-3": ("", 0.0)}
+        worst = {"plain": ("", 0.0), "behind an LDS-resident fp16 intermediate": ("", 0.0)}
         for n in gpu:
-            is_loose = n in loose or (".m." in n and n.endswith(".cv2"))
-            k = 4e-3 if is_loose else 2e-3
-            tol = k * np.abs(taps[n]).max() + 2e-3
+            tol = 2e-3 * np.abs(taps[n]).max() + 2e-3
             err = float(np.abs(taps[n] - gpu[n]).max())
             assert err <= tol, f"img {img} layer {n}: max err {err:.4g} > tol {tol:.4g}"
-            key = "4e-3 (behind an LDS-resident fp16 intermediate)" if is_loose else "2e-3"
+            key = "behind an LDS-resident fp16 intermediate" if (n in loose or (".m." in n and n.endswith(".cv2"))) else "plain"
             if err / tol > worst[key][1]:
                 worst[key] = (n, err / tol)
-            if is_loose:
-                r2 = err / (2e-3 * float(np.abs(taps[n]).max()) + 2e-3)
-                if r2 > worst["4e-3 class measured against 2e-3"][1]:
-                    worst["4e-3 class measured against 2e-3"] = (n, r2)
-        # the looser class is evidence, not allowance -- printed (-s) per class, and its members are asserted against 3e-3 as well:
-        # measured 0.16 - 0.45 of the 2e-3 bound on the round's boxes, i.e. the factor 2 is head room, not need
-        print(f"benchmarked shape, image {img}: worst err / tol per tolerance class: " + "; ".join(f"{k}: {v[1]:.3f} ({v[0]})" for k, v in worst.items()))
-        assert worst["4e-3 class measured against 2e-3"][1] <= 1.5, worst
+        # rounds 1-4 allowed 4e-3 * max|ref| behind a fused pair's LDS-resident fp16 intermediate.  Measured (round 5, printed with -s): those
+        # layers sit at 0.22 - 0.23 of the 2e-3 bound, the plain ones at 0.18 - 0.19 -- the factor 2 was never needed, so ONE tolerance class is left
+        print(f"benchmarked shape, image {img}: worst err / tol (2e-3 * max|ref| + 2e-3 everywhere): " + "; ".join(f"{k}: {v[1]:.3f} ({v[0]})" for k, v in worst.items()))
     # the same frames synchronously through the same engine
     sync = det.detect_batch([frames[steps - 1][f][s] for f in range(F) for s in range(S)])
     for i in range(B):
