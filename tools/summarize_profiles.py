@@ -21,7 +21,7 @@ def one(pattern):
     return g[-1] if g else None
 
 
-for name in ("bench_default.json", "bench_driver_cmd.json", "bench_frames2.json", "bench_frames8.json", "bench_host_frames_F2.json", "layers_chains1_F2.txt", "layers_chains1_F8.txt", "bench_host_frames.json", "bench_host_frames_pageable.json", "bench_streams16.json",
+for name in ("bench_cfg5_F1.json", "bench_cfg5_F4.json", "cpu_baseline_node.json", "bench_default.json", "bench_driver_cmd.json", "bench_frames2.json", "bench_frames8.json", "bench_host_frames_F2.json", "layers_chains1_F2.txt", "layers_chains1_F8.txt", "bench_host_frames.json", "bench_host_frames_pageable.json", "bench_streams16.json",
              "bench_streams32.json", "bench_soak3000.json", "bench_frames1.json", "bench_frames4.json", "bench_chains1.json", "bench_chains2.json", "bench_stages2.json", "stats_bench.json", "stats_chains1_bench.json", "layers_chains1.txt", "step_gaps_chains1.txt", "pipeline_640.json", "pipeline_1080p.json", "layers.txt", "step_gaps.txt",
              "bandwidth_probe.txt", "tracker_modes.json"):
     p = os.path.join(src, name)
@@ -51,7 +51,7 @@ def per_step(dirname, counters, steps=10):
         d[r["Counter_Name"]] = float(r["Counter_Value"])
         d["dur"] = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
     ids = sorted(per, key=int)
-    lb = [i for i in ids if "letterbox" in per[i]["name"] or "stem_fused" in per[i]["name"]]      # first launch of a chain's step
+    lb = [i for i in ids if "letterbox" in per[i]["name"] or "stem_fused" in per[i]["name"] or "front_fused" in per[i]["name"]]      # first launch of a chain's step
     a, b = int(lb[-steps * CHAINS - 1]), int(lb[-1])
     sel = [per[i] for i in ids if a <= int(i) < b]
     agg = collections.defaultdict(lambda: collections.defaultdict(float))
@@ -79,7 +79,9 @@ if fetch and write:
     key = f"s-640-{cfg['streams_per_gpu']}x{cfg.get('frames_per_stream_per_step', 1)}"
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     from kernel_digest import csrc_digest
-    json.dump({"workload_key": key, "csrc_sha256": csrc_digest(), "hbm_bytes_per_step": hbm, "fetch_size_kb_per_step": round(F, 1),
+    # the digest of the LIBRARY the counters were collected on (bench.py prints rtmodt_build_info as roofline.library_build); the tree's digest as a fallback
+    lib = json.loads(open(os.path.join(src, "stats_bench.json")).read().strip().splitlines()[-1])["roofline"].get("library_build", {})
+    json.dump({"workload_key": key, "csrc_sha256": lib.get("csrc_sha256") or csrc_digest(), "hbm_bytes_per_step": hbm, "fetch_size_kb_per_step": round(F, 1),
                "write_size_kb_per_step": round(W, 1),
                "source": dst + "/pmc_per_kernel.csv: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over "
                          "`bench.py --steps 20`; forward-pass launches of the last 10 steps; bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 "

@@ -16,9 +16,9 @@ rows = []
 for r in csv.DictReader(open(path)):
     rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r.get("Queue_Id", "")))
 rows.sort()
-is_stem = lambda name: "letterbox" in name or "stem_fused" in name      # first launch of a chain's step
+is_stem = lambda name: "letterbox" in name or "stem_fused" in name or "front_fused" in name      # first launch of a chain's step
 stem_q = sorted({r[3] for r in rows if is_stem(r[2])})
-queues = stem_q + sorted({r[3] for r in rows if "conv" in r[2] or "bottleneck" in r[2] or "head_final" in r[2]} - set(stem_q))   # (+ the later stages' queues of the staged engine)
+queues = stem_q + sorted({r[3] for r in rows if "conv" in r[2] or "bottleneck" in r[2] or "c2f32" in r[2] or "head_final" in r[2]} - set(stem_q))   # (+ the later stages' queues of the staged engine)
 first = [r for r in rows if is_stem(r[2]) and r[3] == queues[0]]
 assert len(first) > steps, "trace shorter than the requested number of steps"
 t0, t1 = first[-steps - 1][0], first[-1][0]
