@@ -149,7 +149,9 @@ __global__ __launch_bounds__(256, 2) void c2f32_fused(B32Args a) {
 
         // ---- P1: conv1 over the linearised patch, groups wave, wave + 4, wave + 8 (+ 12 for wave 0); positions outside the image are conv2's zero padding.
         // (A hand-pipelined form -- fragments of group i + 2 and MFMAs of group i + 1 in front of the SiLU epilogue of group i -- needs a second fragment
-        // set beside the 144 weight registers and spills 35 VGPRs: not kept.) ----
+        // set beside the 144 weight registers and spills 35 VGPRs: not kept.  Neither is the form with ONE cout tile's weights per wave (72 registers, the
+        // pipeline then fits): every position fragment is then read by two waves, conv1's phase went 5 450 -> 6 350 clk, the launch 113 -> 119 us:
+        // these 32-channel convs are bound by LDS fragment reads as soon as a fragment feeds fewer than two MFMAs -- gpurun_out/r05/bneck32_probe2.txt.) ----
         {
             const int ng = wave == 0 ? 4 : 3;
 #pragma unroll
