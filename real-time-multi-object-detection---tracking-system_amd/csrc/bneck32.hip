@@ -293,7 +293,8 @@ int launch_bottleneck32_tail(const BottleneckLaunch &l, hipStream_t s) {
     a.H = l.in.H; a.W = l.in.W; a.Hp = l.in.H + 2; a.Wp = l.in.W + 2; a.cs = l.in.C;
     a.tiles_x = a.W / B_TW; a.tiles_y = a.H / B_TH; a.n_tiles = l.B * a.tiles_x * a.tiles_y;
     a.shortcut = l.res.base != nullptr; a.act = l.tail_act;
-    const int G = std::min(a.n_tiles, 2 * device_cus());
+    static const int per_cu = rt_diag("FRONT_WGS") ? std::max(1, atoi(rt_diag("FRONT_WGS"))) : 2;      // (diagnostic builds: one workgroup per CU, as in front.hip)
+    const int G = std::min(a.n_tiles, per_cu * device_cus());
     hipLaunchKernelGGL(c2f32_fused, dim3(G), dim3(256), 0, s, a);
     RT_HIP(hipGetLastError());
     return RTMODT_OK;

@@ -411,7 +411,10 @@ int launch_front(const FrontLaunch &l, hipStream_t s) {
     a.out = o.base + o.coff; a.out_Hp = o.H + 2 * o.pad; a.out_Wp = o.padded_w(); a.out_cs = o.C; a.out_pad = o.pad;
     a.in_h = l.in_h; a.in_w = l.in_w;
     a.tiles_x = o.W / F_TW; a.tiles_y = o.H / F_TH; a.n_tiles = l.B * a.tiles_x * a.tiles_y;
-    const int G = std::min(a.n_tiles, 2 * device_cus());   // two workgroups per CU (LDS), persistent over the tiles
+    // two workgroups per CU (LDS), persistent over the tiles.  Diagnostic builds: RTMODT_FRONT_WGS=1 launches ONE per CU, leaving half of every CU's LDS and
+    // registers to the launches of the engine's other stages (same-box A/B: profiles/r05/README.md)
+    static const int per_cu = rt_diag("FRONT_WGS") ? std::max(1, atoi(rt_diag("FRONT_WGS"))) : 2;
+    const int G = std::min(a.n_tiles, per_cu * device_cus());
     if (l.from_tensor) {
         const TensorView &im = l.img4;
         RT_CHECK(im.base && im.C == 4 && im.pad == 1 && im.H == l.in_h && im.W == l.in_w && (uintptr_t)im.base % 16 == 0, RTMODT_E_INVALID, "launch_front: image tensor must be 4-channel with a border");
