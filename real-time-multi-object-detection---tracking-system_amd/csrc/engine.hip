@@ -212,7 +212,7 @@ struct rtmodt_detector {
     bool pipe = false;
     size_t arena_stride = 0;                          // bytes between the two arena copies
     static constexpr int MAX_STAGES = 3;
-    int n_stages = 1;                                 // 2: backbone | neck + Detect; 3: layers 0-6.m.0 | 6.m.1-15 | 16-22
+    int n_stages = 1;                                 // 2: backbone | neck + Detect; 3: layers 0-6.m.1 | 6.cv2-16 | 18-22
     int stage_lo[MAX_STAGES + 1] = {0, 0, 0, 0};      // stage s runs ops [stage_lo[s], stage_lo[s + 1])
     int run_par = 0, last_par = 0;                    // arena copy the launches being issued use / the newest batch used
     std::vector<Op> par_ops[MAX_STAGES];              // d->ops shifted into each arena copy (one copy per stage)
@@ -720,7 +720,9 @@ static int build_graph(rtmodt_detector *d, WeightFile &wf) {
     if (const char *e = rt_opt("STAGES")) stages = atoi(e);
     stages = d->cfg.use_graph ? std::max(1, std::min(stages, (int)rtmodt_detector::MAX_STAGES)) : 1;
     {   // stage boundaries by layer name: 2 stages cut after SPPF (52 % / 48 % of the kernel time), 3 stages at 35 % / 66 %
-        const char *cut2[] = {"12."}, *cut3[] = {"6.m.1", "16"};      // (sweeps of both sets of cuts on s @ 640: these, within 1 %)
+        // (sweeps of both sets of cuts on s @ 640.  Round 5: with the front end ~75 us shorter the three-stage cuts moved from {6.m.1, 16} to {6.cv2, 18.}: +3.2 ... 4.7 % on
+        //  two boxes, nine pairs of cuts tried twice each -- profiles/r05/split3/)
+        const char *cut2[] = {"12."}, *cut3[] = {"6.cv2", "18."};
         const char **cuts = stages == 3 ? cut3 : cut2;
         static std::string keep[2];                        // experiment hooks: RTMODT_SPLIT=<layer> (2 stages), RTMODT_SPLIT3=<layer>,<layer>
         if (const char *e = rt_diag("SPLIT")) { keep[0] = e; cut2[0] = keep[0].c_str(); }
