@@ -428,6 +428,10 @@ __global__ __launch_bounds__(512) void conv3x3_pp(ConvGroupArgs g, int total_ids
                         if (ok[cb][i]) *(half8 *)(e_out + op[cb][i]) = o;
                     }
                 }
+            } else {
+                // a shortcut with more than 64 couts per wave (the 192-wide tile): no epilogue exists for it.  launch_conv3x3_pp and tile_legal refuse the combination;
+                // a caller that gets past both (a probe including this file directly) must not leave the output tensor silently unwritten
+                __builtin_trap();
             }
         }
         if (have_next) __builtin_amdgcn_s_barrier();     // every wave is done with its staging area: the next tile's strips may land there
@@ -698,6 +702,7 @@ static int launch_pp_bn(const ConvArgs *a, int n, hipStream_t s) {
             }
         }
         if (it != plans.end()) { sched = it->second.first; sched_T = it->second.second; }
+        else if (rt_opt("TUNE_LOG")) fprintf(stderr, "[pp] grouped launch %s first seen while its stream is capturing: this capture keeps the static tile stride (no balanced schedule)\n", key.c_str());
     }
     hipLaunchKernelGGL((conv3x3_pp<BN, WIDE>), dim3(G), dim3(512), 0, s, g, total, sched, sched_T);
     return RTMODT_OK;

@@ -134,7 +134,7 @@ class FrameReader:
                              f"frame and the one being written: build it with >= {self.buffer_size + 2} slots")
         self._leases: Dict[int, int] = {}              # ring slot -> outstanding leases
         self.lease_misses = 0                          # read(copy=False) calls served by a copy because no slot could be leased
-        self._lease_slot: Dict[int, int] = {}          # frame id -> ring slot
+        self._lease_slot: Dict[int, list] = {}         # frame id -> [ring slot (-1: only copy-served holders so far), holders]
         self._latest_slot = -1
         self._cap = None
         self._latest: Optional[np.ndarray] = None
@@ -169,19 +169,43 @@ class FrameReader:
                 return True, self._latest.copy(), self._frame_id
             if self._ring is not None:                 # (without a ring every frame is a fresh array: nothing to protect)
                 slot = self._latest_slot
-                if slot not in self._leases and len(self._leases) >= self._ring.slots - 2:
-                    self.lease_misses += 1             # every leasable slot is out: hand a copy over, nothing to release for it
+                ent = self._lease_slot.get(self._frame_id)        # [slot or -1, holders]: every read(copy=False) of a frame id is one HOLDER, whatever it was handed
+                if (ent is None or ent[0] < 0) and slot not in self._leases and len(self._leases) >= self._ring.slots - 2:
+                    # every leasable slot is out: hand a copy over.  The holder is still counted under this frame id, so that its release() can
+                    # never be mistaken for the release of a REAL lease a later read of the same (still latest) id obtains
+                    self.lease_misses += 1
+                    if self.lease_misses == 1:
+                        log.warning("FrameReader: every leasable ring slot is on lease -- read(copy=False) now returns pageable copies "
+                                    "(release frames after their batch's fetch, or build a larger ring)")
+                    if ent is None:
+                        self._lease_slot[self._frame_id] = [-1, 1]
+                    else:
+                        ent[1] += 1
                     return True, self._latest.copy(), self._frame_id
-                if self._frame_id not in self._lease_slot:
+                if ent is None or ent[0] < 0:          # first real lease of this frame id: the slot goes on lease
                     self._leases[slot] = self._leases.get(slot, 0) + 1
-                    self._lease_slot[self._frame_id] = slot
+                    if ent is None:
+                        self._lease_slot[self._frame_id] = [slot, 1]
+                    else:
+                        ent[0] = slot; ent[1] += 1
+                else:
+                    ent[1] += 1
             return True, self._latest, self._frame_id
 
     def release(self, frame_id: int) -> None:
-        """Give back the slot leased by ``read(copy=False)`` for ``frame_id`` (no-op for ids that hold no lease)."""
+        """One holder of ``frame_id`` (a ``read(copy=False)`` of it) is done.  The frame's ring slot comes off lease when its LAST holder has
+        released -- copy-served holders included, so a slot is never rewritten under a holder that still uploads from it.  No-op for ids that
+        hold nothing."""
         with self._lock:
-            slot = self._lease_slot.pop(frame_id, None)
-            if slot is None:
+            ent = self._lease_slot.get(frame_id)
+            if ent is None:
+                return
+            ent[1] -= 1
+            if ent[1] > 0:
+                return
+            del self._lease_slot[frame_id]
+            slot = ent[0]
+            if slot < 0:
                 return
             left = self._leases.get(slot, 0) - 1
             if left > 0:

@@ -116,6 +116,41 @@ def test_leased_slots_are_never_rewritten():
     assert r.leased == 0                              # stop() (the context manager's exit) clears what was still on lease
 
 
+def test_holders_of_one_frame_id_are_counted():
+    """(1) two read(copy=False) of the SAME (still latest) frame id are two holders of one lease -- the first release() must not free the slot
+    under the second; (2) a copy-served read (no slot could be leased) is a holder of its frame id too, so its release() can never drop the real lease a
+    later read of that id obtained."""
+    frames = pkg.synth.frames(5, 48, 64, seed=3)
+    ring = HostRing(4, 48, 64)                     # 2 leasable slots
+    src = ing.FrameReader("ring", backend="synthetic", resolution=(64, 48), frames=frames, fps=1e-3, ring=ring, buffer_size=2)      # ~one frame, then nothing for minutes
+    with src as r:
+        assert wait_for(lambda: r.read()[0])
+        ok, a, fid = r.read(copy=False)
+        ok2, b, fid2 = r.read(copy=False)
+        assert ok and ok2 and fid == fid2 and np.shares_memory(a, b) and r.leased == 1
+        r.release(fid)
+        assert r.leased == 1                          # the second holder still has it
+        r.release(fid)
+        assert r.leased == 0
+        r.release(fid)                                # nobody left: a no-op
+        assert r.leased == 0
+        # (2) fill the leasable slots with OTHER frame ids by hand, so that this id can only be served by a copy
+        with r._lock:
+            other = [s for s in range(ring.slots) if s != r._latest_slot][:2]
+            for s in other:
+                r._leases[s] = 1
+        ok, c, fid3 = r.read(copy=False)
+        assert ok and fid3 == fid and r.lease_misses == 1 and not np.shares_memory(c, a)      # a pageable copy
+        with r._lock:
+            r._leases.pop(other[0])                   # a slot comes back ...
+        ok, d, fid4 = r.read(copy=False)              # ... and the same id now gets a real lease
+        assert ok and fid4 == fid and np.shares_memory(d, a) and r.leased == 2
+        r.release(fid)                                # the copy's holder is done: the real lease must survive
+        assert r.leased == 2 and r._latest_slot in r._leases
+        r.release(fid)
+        assert r._latest_slot not in r._leases
+
+
 def test_read_before_first_frame():
     class Never:
         opened = True

@@ -16,6 +16,7 @@
 namespace rtmodt {
 std::string &last_error() { static std::string e; return e; }
 int fail(int code, const char *fmt, ...) { char b[512]; va_list ap; va_start(ap, fmt); vsnprintf(b, sizeof(b), fmt, ap); va_end(ap); last_error() = b; return code; }
+void note_bad_option(const char *) {}
 }
 using namespace rtmodt;
 

@@ -19,6 +19,7 @@ __device__ unsigned long long *g_stamps;
 #endif
 std::string &last_error() { static std::string e; return e; }
 int fail(int code, const char *fmt, ...) { va_list ap; va_start(ap, fmt); vfprintf(stderr, fmt, ap); va_end(ap); fputc('\n', stderr); return code; }
+void note_bad_option(const char *) {}
 }
 using namespace rtmodt;
 
