@@ -688,6 +688,40 @@ def test_front_end_fused_is_bit_identical(pkg, wdir, monkeypatch, h, w, rect):
     buf.free()
 
 
+@pytest.mark.parametrize("chains", [1, 2, -1, -2], ids=["plain", "two-chains", "two-stages", "three-stages"])
+def test_front_end_fused_under_every_engine_shape(pkg, wdir, monkeypatch, chains):
+    """The fused front end is launched by enqueue_batch itself (its frame pointers change every batch), once per sub-batch chain or per arena copy of the
+    staged engine: forced on, batches of 4 pipelined through the plain engine, two sub-batch chains, two and three stages must give the detections of the
+    unfused plain engine, bit for bit (device frames that need no resize, and host frames that take the letterbox kernel + the tensor source)."""
+    frames = pkg.synth.structured_frames(12, 320, 320, seed=77).reshape(3, 4, 320, 320, 3)
+    small = pkg.synth.structured_frames(4, 240, 416, seed=78)                      # resized: letterbox kernel -> image tensor -> front_fused<TENSOR>
+    monkeypatch.setenv("RTMODT_FRONT", "0")
+    ref_det, _ = make_detector(pkg, wdir, "s", 320, autotune=False, batch=4, chains=1)
+    ref = [ref_det.detect_batch(list(frames[t])) for t in range(3)] + [ref_det.detect_batch(list(small))]
+    ref_det.close()
+    monkeypatch.setenv("RTMODT_FRONT", "1")
+    det, _ = make_detector(pkg, wdir, "s", 320, autotune=False, batch=4, chains=chains)
+    assert "front end fused" in det.profile(1)[0][0]
+    buf = pkg._ffi.DeviceBuffer(frames.nbytes)
+    buf.upload(frames)
+    per = 320 * 320 * 3
+    depth = (det.model.stages + 1) if getattr(det.model, "stages", 1) > 1 else 2
+    got = []
+    for t in range(3):
+        det.enqueue([buf.ptr + (t * 4 + i) * per for i in range(4)], height=320, width=320)
+        if t >= depth - 1:
+            got.append(det.fetch())
+    while len(got) < 3:
+        got.append(det.fetch())
+    got.append(det.detect_batch(list(small)))
+    for t in range(4):
+        for i in range(4):
+            assert np.array_equal(got[t][i].xyxy.view(np.int32), ref[t][i].xyxy.view(np.int32)) and got[t][i].class_id.tolist() == ref[t][i].class_id.tolist(), (chains, t, i)
+    assert sum(len(d) for b in got for d in b) > 0
+    buf.free()
+    det.close()
+
+
 @pytest.mark.parametrize("h,w", [(640, 640), (480, 640), (640, 512), (636, 640), (640, 634), (640, 630)])
 def test_letterbox_fused_into_stem_is_bit_identical(pkg, wdir, monkeypatch, h, w):
     """Frames that need no resize skip the letterbox kernel: the stem conv builds its MFMA fragments from the BGR
