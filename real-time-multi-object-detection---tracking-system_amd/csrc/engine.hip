@@ -661,7 +661,8 @@ static int build_graph(rtmodt_detector *d, WeightFile &wf) {
     const int src[3] = {t15, t18, t21};
     std::vector<Op> hops;                                   // 5 convs per level: A, B2, B3, C2, C3
     for (int l = 0; l < 3; ++l) {
-        const Tensor &s = d->tensors[src[l]];
+        const Tensor s = d->tensors[src[l]];               // BY VALUE: every T() below appends to d->tensors and may move it (a reference dangled as soon as the
+                                                           // vector grew at this point -- YOLOv8l, whose deeper C2f modules allocate more tensors, got garbage head shapes)
         std::string L = std::to_string(l);
         int hA = T(s.H, s.W, cbox + ccls, 1);
         RT_TRY(make_conv(d, wf, {"22.cv2." + L + ".0", "22.cv3." + L + ".0"}, "22.cv2+cv3." + L + ".0", V(src[l]), V(hA), nullptr, 0, &hops));
@@ -824,7 +825,12 @@ static int run_op_on(const Op &op, hipStream_t s) {
     }
     return RTMODT_OK;
 }
-static int run_op(rtmodt_detector *d, const Op &op) { return run_op_on(op, d->stream); }
+// (a failing launch check names the layer it belongs to: "launch_conv: ... [op 8.cv2]")
+static int run_op(rtmodt_detector *d, const Op &op) {
+    const int rc = run_op_on(op, d->stream);
+    if (rc != RTMODT_OK) last_error() += " [op " + op.name + "]";
+    return rc;
+}
 
 // Detect's tail for images [b0, b0 + nb) on stream `st`
 static int run_decode_sub(rtmodt_detector *d, int b0, int nb, hipStream_t st) {

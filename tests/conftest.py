@@ -24,7 +24,7 @@ _GPU_RANK = [
     (1, ("test_letterbox_bit_exact", "test_nms_", "test_decode_fast_path", "test_letterbox_fused_into_stem", "test_front_end_fused")),
     (2, ("test_benchmarked_shape_parity", "test_persistent_tile_kernel", "test_persistent_tap_reuse_kernel", "test_forward_layers", "test_tap_reuse_conv_tiles", "test_fused_bottleneck_kernel",
          "test_eight_wave_tiles", "test_weight_stationary_1x1_tiles", "test_conv_with_fused_1x1_tail", "test_bottleneck_with_c2f_cv2_tail", "test_persistent_c2f32",
-         "test_head_final_equals", "test_epilogue_variants", "test_neck_concat_read", "test_stem_and_layer1", "test_layer1_pixel_pair", "test_config5", "test_converted_checkpoint")),
+         "test_head_final_equals", "test_epilogue_variants", "test_neck_concat_read", "test_stem_and_layer1", "test_layer1_pixel_pair", "test_config5", "test_yolov8l_960", "test_converted_checkpoint")),
     (4, ("test_end_to_end_vs_fp32_oracle",)),
 ]
 

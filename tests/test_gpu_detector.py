@@ -539,6 +539,44 @@ def test_config5_yolov8m_1280_dense_scene(pkg, wdir):
     assert np.array_equal(T.state_digest(trk._core.snapshot()), T.state_digest(orc.snapshot()))
 
 
+def test_yolov8l_960_tuner_skips_tiles_that_do_not_fit(pkg, wdir):
+    """the ping-pong kernels index their output with 24-bit multiplies (padded H x W x C of ONE image < 2^24).  YOLOv8l's layer-2 concat
+    tensor has 5 x 64 = 320 channels: at 960 x 960 it is 242 x 242 x 320 = 18.7 M elements -- the tuner's candidate filter (and every cache hit) must skip those
+    tiles for the convs that write into it instead of failing `rtmodt_detector_create` (round 4: the launch check's E_INVALID aborted autotune).  Create with the
+    tuner ON, one frame, then: the tuner's launch list holds no ping-pong tile on layer 2's Bottleneck outputs, NMS is bit-exact on the engine's own tensor, and
+    layer 2 (every conv of it) is within tolerance of the fp32 oracle, teacher-forced."""
+    path = os.path.join(str(wdir), "yolov8l_960.rtw")
+    if not os.path.exists(path):
+        pkg.weights.save(path, pkg.weights.synthetic("l", input_size=160), "l")      # calibrated at 160 (cheap), run at 960
+    w, _, _, _ = pkg.weights.load(path)
+    det = pkg.Detector(path, input_size=(960, 960), max_det=300, warmup=False)         # autotune on (the default)
+    frame = pkg.synth.frames(1, 960, 960, seed=99)[0]
+    d = det.detect(frame)
+    prof = [n for n, _, _ in det.profile(1)]
+    l2 = [n for n in prof if n.startswith("2.m.")]
+    assert l2, prof[:12]
+    for n in l2:                                                                       # 2.m.j (cv1+cv2): its cv2 writes into the 320-channel tensor
+        if "two launches" in n:
+            tiles = n.split("two launches:")[1].strip(" ]").split(",")
+            assert "pp" not in tiles[1], (n, "a ping-pong tile was chosen for a tensor it cannot index")
+    inp, heads, pred = det.debug_fetch(0)
+    dets, _ = Y.non_max_suppression(pred, 0.35, 0.45, None, False, 300)
+    assert len(d) == len(dets) and np.array_equal(d.xyxy.view(np.int32), Y.scale_boxes(dets[:, :4], 960, 960, 960, 960).view(np.int32))
+    names = [cv.name for cv in pkg.weights.spec("l")]
+    stored = fetch_layers(pkg, det, names)
+    # layer 2's convs are all COMPUTED by the oracle (also the Bottlenecks' first convs, which a fused launch keeps in LDS), each from the engine's stored inputs;
+    # 2.cv1 only when its input (layer 1) was stored, i.e. when it did not run as layer 1's tail
+    only = {n for n in names if n.startswith("2.")} - (set() if "1" in stored else {"2.cv1"})
+    want = only & set(stored)
+    assert "2.cv2" in want and "2.m.2.cv2" in want and len(want) >= 4, sorted(want)
+    taps = {}
+    Y.forward(inp.astype(np.float32), w, "l", taps=taps, force=stored, only=only)
+    for n in sorted(want):
+        tol = 2e-3 * np.abs(taps[n]).max() + 2e-3
+        assert float(np.abs(taps[n] - stored[n]).max()) <= tol, f"l @ 960 layer {n}; launches: {prof[:12]}"
+    det.close()
+
+
 def test_reference_constructor_behaviour(pkg, wdir, tmp_path):
     path = os.path.join(str(wdir), "yolov8n_160.rtw")
     pkg.weights.save(path, pkg.weights.synthetic("n", input_size=160), "n")
