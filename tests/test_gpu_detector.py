@@ -539,18 +539,21 @@ def test_config5_yolov8m_1280_dense_scene(pkg, wdir):
     assert np.array_equal(T.state_digest(trk._core.snapshot()), T.state_digest(orc.snapshot()))
 
 
-def test_yolov8l_960_tuner_skips_tiles_that_do_not_fit(pkg, wdir):
-    """the ping-pong kernels index their output with 24-bit multiplies (padded H x W x C of ONE image < 2^24).  YOLOv8l's layer-2 concat
+@pytest.mark.parametrize("scale,size", [("l", 960), ("x", 320)])
+def test_yolov8l_960_tuner_skips_tiles_that_do_not_fit(pkg, wdir, scale, size):
+    """(YOLOv8x @ 320: the widest scale -- 80 / 160 / 320 / 640 channels, cin % 32 != 0 on layer 2: the general K-chunk path -- created and checked the same way;
+    before round 5 neither l nor x could be created at all: a reference into d->tensors dangled in the Detect head builder once the tensor list grew.)
+    ADVICE r04 (medium): the ping-pong kernels index their output with 24-bit multiplies (padded H x W x C of ONE image < 2^24).  YOLOv8l's layer-2 concat
     tensor has 5 x 64 = 320 channels: at 960 x 960 it is 242 x 242 x 320 = 18.7 M elements -- the tuner's candidate filter (and every cache hit) must skip those
     tiles for the convs that write into it instead of failing `rtmodt_detector_create` (round 4: the launch check's E_INVALID aborted autotune).  Create with the
     tuner ON, one frame, then: the tuner's launch list holds no ping-pong tile on layer 2's Bottleneck outputs, NMS is bit-exact on the engine's own tensor, and
     layer 2 (every conv of it) is within tolerance of the fp32 oracle, teacher-forced."""
-    path = os.path.join(str(wdir), "yolov8l_960.rtw")
+    path = os.path.join(str(wdir), f"yolov8{scale}_{size}_cal160.rtw")
     if not os.path.exists(path):
-        pkg.weights.save(path, pkg.weights.synthetic("l", input_size=160), "l")      # calibrated at 160 (cheap), run at 960
+        pkg.weights.save(path, pkg.weights.synthetic(scale, input_size=160), scale)      # calibrated at 160 (cheap), run at `size`
     w, _, _, _ = pkg.weights.load(path)
-    det = pkg.Detector(path, input_size=(960, 960), max_det=300, warmup=False)         # autotune on (the default)
-    frame = pkg.synth.frames(1, 960, 960, seed=99)[0]
+    det = pkg.Detector(path, input_size=(size, size), max_det=300, warmup=False)         # autotune on (the default)
+    frame = pkg.synth.frames(1, size, size, seed=99)[0]
     d = det.detect(frame)
     prof = [n for n, _, _ in det.profile(1)]
     l2 = [n for n in prof if n.startswith("2.m.")]
@@ -561,8 +564,8 @@ def test_yolov8l_960_tuner_skips_tiles_that_do_not_fit(pkg, wdir):
             assert "pp" not in tiles[1], (n, "a ping-pong tile was chosen for a tensor it cannot index")
     inp, heads, pred = det.debug_fetch(0)
     dets, _ = Y.non_max_suppression(pred, 0.35, 0.45, None, False, 300)
-    assert len(d) == len(dets) and np.array_equal(d.xyxy.view(np.int32), Y.scale_boxes(dets[:, :4], 960, 960, 960, 960).view(np.int32))
-    names = [cv.name for cv in pkg.weights.spec("l")]
+    assert len(d) == len(dets) and np.array_equal(d.xyxy.view(np.int32), Y.scale_boxes(dets[:, :4], size, size, size, size).view(np.int32))
+    names = [cv.name for cv in pkg.weights.spec(scale)]
     stored = fetch_layers(pkg, det, names)
     # layer 2's convs are all COMPUTED by the oracle (also the Bottlenecks' first convs, which a fused launch keeps in LDS), each from the engine's stored inputs;
     # 2.cv1 only when its input (layer 1) was stored, i.e. when it did not run as layer 1's tail
@@ -570,10 +573,10 @@ def test_yolov8l_960_tuner_skips_tiles_that_do_not_fit(pkg, wdir):
     want = only & set(stored)
     assert "2.cv2" in want and "2.m.2.cv2" in want and len(want) >= 4, sorted(want)
     taps = {}
-    Y.forward(inp.astype(np.float32), w, "l", taps=taps, force=stored, only=only)
+    Y.forward(inp.astype(np.float32), w, scale, taps=taps, force=stored, only=only)
     for n in sorted(want):
         tol = 2e-3 * np.abs(taps[n]).max() + 2e-3
-        assert float(np.abs(taps[n] - stored[n]).max()) <= tol, f"l @ 960 layer {n}; launches: {prof[:12]}"
+        assert float(np.abs(taps[n] - stored[n]).max()) <= tol, f"{scale} @ {size} layer {n}; launches: {prof[:12]}"
     det.close()
 
 
