@@ -57,7 +57,8 @@ static Net make_net() {
 struct Case { const char *name; int in_h, in_w, src_h, src_w, top, left, pitch_extra, ptr_off; };
 
 int main(int argc, char **argv) {
-    const int B = argc > 1 ? atoi(argv[1]) : 32, iters = argc > 2 ? atoi(argv[2]) : 20;
+    const int B0 = argc > 1 && std::string(argv[1]) != "fuzz" ? atoi(argv[1]) : 32, iters = argc > 2 && std::string(argv[1]) != "fuzz" ? atoi(argv[2]) : (argc > 1 && std::string(argv[1]) == "fuzz" ? 1 : 20);
+    const int B = B0;
     Net net = make_net();
     hipStream_t st; CK(hipStreamCreate(&st));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -75,7 +76,25 @@ int main(int argc, char **argv) {
         {"320x320", 320, 320, 320, 320, 0, 0, 0, 3},
     };
     int bad = 0;
-    for (const Case &c : cases) {
+    // `front_probe fuzz [n]`: n random geometries instead of the six named ones -- canvas sizes (multiples of 32 x 64 up to 704), frames smaller than the canvas at
+    // random letterbox offsets, odd pitches and misaligned bases, 1-3 images: every case bit-identical to the two launches, byte and tensor source
+    std::vector<Case> all(cases, cases + sizeof(cases) / sizeof(cases[0]));
+    static char names[512][96];
+    const bool fuzz = argc > 1 && std::string(argv[1]) == "fuzz";
+    if (fuzz) {
+        all.clear();
+        const int n = argc > 2 ? atoi(argv[2]) : 60;
+        for (int i = 0; i < n && i < 512; ++i) {
+            const int in_h = 32 * (1 + urand() % 22), in_w = 64 * (1 + urand() % 11);
+            const int src_h = std::max(1, in_h - (int)(urand() % 3 == 0 ? urand() % std::min(in_h, 70) : 0)), src_w = std::max(1, in_w - (int)(urand() % 3 == 0 ? urand() % std::min(in_w, 70) : 0));
+            const int top = (in_h - src_h) > 0 ? urand() % (in_h - src_h + 1) : 0, left = (in_w - src_w) > 0 ? urand() % (in_w - src_w + 1) : 0;
+            snprintf(names[i], sizeof(names[i]), "fuzz %3d: %dx%d frame in %dx%d at (%d, %d)", i, src_h, src_w, in_h, in_w, top, left);
+            all.push_back(Case{names[i], in_h, in_w, src_h, src_w, top, left, (int)(urand() % 9), (int)(urand() % 16)});
+        }
+    }
+    const int Bf = fuzz ? 1 + (int)(urand() % 3) : B;
+    for (const Case &c : all) {
+        const int B = Bf;
         const int H = c.in_h, W = c.in_w, H0 = H / 2, W0 = W / 2, H1 = H / 4, W1 = W / 4;
         const int pitch = 3 * c.src_w + c.pitch_extra;
         const size_t fbytes = (size_t)c.src_h * pitch + 64;
