@@ -1031,7 +1031,10 @@ static int make_args(const ConvLaunch &c, ConvArgs &a) {
 
 // the ping-pong kernels' 24-bit index bound (tile_math.h: pp_index_fits) for a launch description -- the same quantities make_args / launch_conv_group
 // hand to conv_pp.hip's own check, without needing device pointers: M is the largest enumeration either kernel uses (tap reuse: Ho x (in_Wp - 1) positions)
+// ... and the shortcut's geometry: the 3x3 ping-pong kernel reads the shortcut at the OUTPUT's element offsets (conv_pp.hip works a tile's store offsets out once, in front of the
+// k-loop): a channel slice of a tensor with the output's rows, pad and channel stride -- what a C2f block's concat buffer gives it -- is all it takes.
 bool conv_pp_index_fits(const ConvLaunch &c) {
+    if (c.res.base && (c.res.H != c.out.H || c.res.W != c.out.W || c.res.pad != c.out.pad || c.res.padded_w() != c.out.padded_w() || c.res.C != c.out.C)) return false;
     const long out_hwc = (long)(c.out.H + 2 * c.out.pad) * c.out.padded_w() * c.out.C;
     const long res_hwc = c.res.base ? (long)(c.res.H + 2 * c.res.pad) * c.res.padded_w() * c.res.C : 0L;
     const long in_wp = c.in.padded_w();

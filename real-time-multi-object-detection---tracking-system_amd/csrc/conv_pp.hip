@@ -255,6 +255,39 @@ __global__ __launch_bounds__(512) void conv3x3_pp(ConvGroupArgs g, int total_ids
         for (int t = 0; t < TM; ++t)
 #pragma unroll
             for (int u = 0; u < TN; ++u) acc[t][u] = bnext[u];
+        // WHERE this lane's 16-byte stores of the tile go is worked out HERE, in front of the k-loop, not inside the epilogue (round 5): the epilogue is the part of a tile's
+        // life in which the matrix pipe idles and the vector ALU is the bottleneck (SiLU), and PpOut::index per store was a third of its instructions; in front of the k-loop
+        // the same arithmetic runs while half 1 waits at the STAGGER barrier anyway / beside half 0's first DMA issue.  A lane's stores are positions m, m + KS, m + 2 KS, ...
+        // (KS = 64 / CPR) of one 16-byte chunk column: ONE decomposition (two multiply-high divisions), then steps of KS positions with a row / image carry.
+        // Element offsets in opx[], the store predicates as bits of okm; the shortcut tensor has the output tensor's geometry (checked at launch): same offsets.
+        constexpr int EP_CPR = C::HB / 8, EP_NST = EP_CPR, EP_KS = 64 / (EP_CPR > 0 ? EP_CPR : 1);
+        constexpr bool EP_AHEAD = C::HB == 64 || C::HB == 32;
+        int opx_tile[EP_AHEAD ? EP_NST : 1];
+        unsigned okm = 0;
+        if constexpr (EP_AHEAD) {
+            const PpOut po = pp_out(p, p.rows_wq, p.d_hwp, p.d_wp);
+            const int L = lane / EP_CPR, cc = lane - L * EP_CPR;
+            const int n = cur.n0 + col0 + cc * 8;
+            int m = cur.m0 + row0 + L;
+            int b = fdiv(m, po.d_img), rem = m - (int)__umul24((unsigned)b, (unsigned)po.HW);
+            int oy = fdiv(rem, po.d_row), x = rem - (int)__umul24((unsigned)oy, (unsigned)po.wq);
+            const bool nok = n < po.cout;
+            if (po.wq >= EP_KS) {
+#pragma unroll
+                for (int j = 0; j < EP_NST; ++j) {
+                    opx_tile[j] = po.o0 + (int)__umul24((unsigned)b, (unsigned)po.o1) + (int)__umul24((unsigned)oy, (unsigned)po.o2) + (int)__umul24((unsigned)x, (unsigned)po.ocs) + n;
+                    okm |= (unsigned)((m < po.M) & (x < po.Wo) & nok) << j;
+                    m += EP_KS; x += EP_KS;
+                    if (x >= po.wq) { x -= po.wq; oy += 1; if (oy >= po.Ho) { oy = 0; b += 1; } }
+                }
+            } else {                                      // rows shorter than the step (maps narrower than 8 / 16 pixels): the division per store
+#pragma unroll
+                for (int j = 0; j < EP_NST; ++j) {
+                    int rp;
+                    okm |= (unsigned)po.index(m + j * EP_KS, n, opx_tile[j], rp) << j;
+                }
+            }
+        }
         if (half == 1) __builtin_amdgcn_s_barrier();  // STAGGER: half 1 runs one interval behind half 0
         int kh = 0, c0 = 0;
         for (int s = 0; s < cur.ns; ++s) {
@@ -352,7 +385,9 @@ __global__ __launch_bounds__(512) void conv3x3_pp(ConvGroupArgs g, int total_ids
             // argument segment again for every store, a scalar-memory round trip each -- 5 800 of the 8 000 clk this epilogue took (profiles/r04/pp/run5.txt)
             f16 *const e_out = p.out; const f16 *const e_res = p.res;
             const int e_act = p.act;
-            const PpOut po = pp_out(p, p.rows_wq, p.d_hwp, p.d_wp);
+            const PpOut po = pp_out(p, p.rows_wq, p.d_hwp, p.d_wp);      // (only the 192-wide form still indexes inside the epilogue)
+            if constexpr (EP_AHEAD) asm volatile("" ::"s"(e_out), "s"(e_res), "s"(e_act));
+            else
             asm volatile("" ::"s"(e_out), "s"(e_res), "s"(e_act), "s"(po.M), "s"(po.HW), "s"(po.wq), "s"(po.Ho), "s"(po.Wo), "s"(po.cout), "s"(po.o0), "s"(po.o1), "s"(po.o2),
                          "s"(po.ocs), "s"(po.r0), "s"(po.r1), "s"(po.r2), "s"(po.rcs), "s"(po.d_img.mul), "s"(po.d_img.shift), "s"(po.d_row.mul), "s"(po.d_row.shift));
             if (!e_res) {
@@ -379,7 +414,9 @@ __global__ __launch_bounds__(512) void conv3x3_pp(ConvGroupArgs g, int total_ids
                         const int e = i * 64 + lane, pl = e / CPR, c = e - pl * CPR;
                         const half8 v = *(const half8 *)(stg + pl * RS + ((c ^ (pl & (CH - 1))) << 4));
                         int opix, rpix;
-                        const bool ok = po.index(cur.m0 + row0 + t0 * 16 + pl, cur.n0 + col0 + c * 8, opix, rpix) & !(ablate & 2);
+                        bool ok;
+                        if constexpr (EP_AHEAD) { const int sj = (t0 / TR) * (TR * 16 * CPR / 64) + i; opix = opx_tile[sj]; ok = ((okm >> sj) & 1u) & !(ablate & 2); }
+                        else ok = po.index(cur.m0 + row0 + t0 * 16 + pl, cur.n0 + col0 + c * 8, opix, rpix) & !(ablate & 2);
                         if (ok) *(half8 *)(e_out + opix) = v;
                     }
                 }
@@ -394,7 +431,8 @@ __global__ __launch_bounds__(512) void conv3x3_pp(ConvGroupArgs g, int total_ids
                     for (int i = 0; i < NI; ++i) {
                         const int e = i * 64 + lane, pl = e / CPR, c = e - pl * CPR;
                         int rpix;
-                        okx[i] = po.index(cur.m0 + row0 + t0 * 16 + pl, cur.n0 + col0 + c * 8, opx[i], rpix);
+                        if constexpr (EP_AHEAD) { const int sj = (t0 / TR) * NI + i; opx[i] = opx_tile[sj]; rpix = opx[i]; okx[i] = (okm >> sj) & 1u; }      // (shortcut geometry == output geometry: launch check)
+                        else okx[i] = po.index(cur.m0 + row0 + t0 * 16 + pl, cur.n0 + col0 + c * 8, opx[i], rpix);
                         rvx[i] = *(const half8 *)(e_res + (okx[i] ? rpix : 0));
                     }
                 };
@@ -568,6 +606,34 @@ __global__ __launch_bounds__(512) void conv_tile_pp(ConvArgs p, int n_tiles) {
         for (int t = 0; t < TM; ++t)
 #pragma unroll
             for (int u = 0; u < TN; ++u) acc[t][u] = bnext[u];
+        // the tile's store offsets, in front of the k-loop (as in conv3x3_pp; no pad columns among this kernel's positions, so a store is valid iff m < M and n < cout)
+        constexpr int EP_CPR = BN / 16, EP_KS = 64 / EP_CPR;
+        int opx_tile[EP_CPR];
+        unsigned okm = 0;
+        {
+            const PpOut po = pp_out(p, p.Wo, p.d_howo, p.d_wo);
+            const int L = lane / EP_CPR, cc = lane - L * EP_CPR;
+            const int n = cur_n0 + wn * (BN / 2) + cc * 8;
+            int m = cur_m0 + wm * TM * 16 + L;
+            int b = fdiv(m, po.d_img), rem = m - (int)__umul24((unsigned)b, (unsigned)po.HW);
+            int oy = fdiv(rem, po.d_row), x = rem - (int)__umul24((unsigned)oy, (unsigned)po.wq);
+            const bool nok = n < po.cout;
+            if (po.wq >= EP_KS) {
+#pragma unroll
+                for (int j = 0; j < EP_CPR; ++j) {
+                    opx_tile[j] = po.o0 + (int)__umul24((unsigned)b, (unsigned)po.o1) + (int)__umul24((unsigned)oy, (unsigned)po.o2) + (int)__umul24((unsigned)x, (unsigned)po.ocs) + n;
+                    okm |= (unsigned)((m < po.M) & nok) << j;
+                    m += EP_KS; x += EP_KS;
+                    if (x >= po.wq) { x -= po.wq; oy += 1; if (oy >= po.Ho) { oy = 0; b += 1; } }
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < EP_CPR; ++j) {
+                    int rp;
+                    okm |= (unsigned)po.index(m + j * EP_KS, n, opx_tile[j], rp) << j;
+                }
+            }
+        }
         if (half == 1) __builtin_amdgcn_s_barrier();  // STAGGER
         for (int j = 0; j < nph; ++j) {
             // ---------------- R ----------------
@@ -611,10 +677,12 @@ __global__ __launch_bounds__(512) void conv_tile_pp(ConvArgs p, int n_tiles) {
             constexpr int HB = BN / 2, CPR = HB / 8;
             constexpr int RS = HB <= 32 ? 64 : (HB <= 64 ? 128 : 256), CH = RS / 16, TR = 4096 / (16 * RS);
             static_assert(TM % TR == 0 && (TR * 16 * CPR) % 64 == 0, "staging rounds");
-            const PpOut po = pp_out(p, p.Wo, p.d_howo, p.d_wo);
+            f16 *const e_out = p.out;
+            const int e_act = p.act;
+            asm volatile("" ::"s"(e_out), "s"(e_act));
 #pragma unroll
             for (int t0 = 0; t0 < TM; t0 += TR) {
-                if (p.act) {
+                if (e_act) {
 #pragma unroll
                     for (int tt = 0; tt < TR; ++tt)
 #pragma unroll
@@ -632,8 +700,9 @@ __global__ __launch_bounds__(512) void conv_tile_pp(ConvArgs p, int n_tiles) {
                 for (int i = 0; i < TR * 16 * CPR / 64; ++i) {
                     const int e = i * 64 + lane, pl = e / CPR, c = e - pl * CPR;
                     const half8 v = *(const half8 *)(stg + pl * RS + ((c ^ (pl & (CH - 1))) << 4));
-                    int opix, rpix;
-                    if (po.index(cur_m0 + (wm * TM + t0) * 16 + pl, cur_n0 + wn * HB + c * 8, opix, rpix)) *(half8 *)(p.out + opix) = v;
+                    const int sj = (t0 / TR) * (TR * 16 * CPR / 64) + i;
+                    (void)pl; (void)c;
+                    if ((okm >> sj) & 1u) *(half8 *)(e_out + opx_tile[sj]) = v;
                 }
             }
         }
@@ -740,6 +809,8 @@ int launch_conv3x3_pp(const ConvArgs *a, int n, int bn, hipStream_t s) {
         RT_CHECK(a[i].cout % 8 == 0 && (uintptr_t)a[i].out % 16 == 0 && a[i].out_cs % 8 == 0 && (!a[i].res || ((uintptr_t)a[i].res % 16 == 0 && a[i].res_cs % 8 == 0)),
                  RTMODT_E_INVALID, "launch_conv: the ping-pong tile stores 16 bytes per lane (cout, channel offsets and strides %% 8 == 0)");
         RT_CHECK(!a[i].res || bn <= 128 || bn == 576, RTMODT_E_INVALID, "launch_conv: the 192-wide ping-pong tile takes no residual");
+        RT_CHECK(!a[i].res || (a[i].res_Hp == a[i].out_Hp && a[i].res_Wp == a[i].out_Wp && a[i].res_cs == a[i].out_cs && a[i].res_pad == a[i].out_pad), RTMODT_E_INVALID,
+                 "launch_conv: the ping-pong tile reads its shortcut at the output's element offsets (a channel slice of the same tensor geometry)");
         RT_CHECK(pp_out_fits(a[i]), RTMODT_E_INVALID, "launch_conv: the ping-pong tile indexes its output with 24-bit multiplies (padded H x W x C of a tensor < 2^24)");
     }
     switch (bn) {

@@ -122,6 +122,7 @@ int main(int argc, char **argv) {
             P.in_off = pick({0, 0, 8, 64}); P.in_C = P.in_off + P.cin + pick({0, 0, 8, 56});
             P.out_off = pick({0, 0, 8, 40}); P.out_C = P.out_off + P.cout + pick({0, 0, 8, 24});
             P.res_off = pick({0, 8}); P.res_C = P.res_off + P.cout + pick({0, 16});
+            if (rnd() % 3 != 0 && P.res_off + P.cout <= P.out_C) P.res_C = P.out_C;      // two in three: a slice of a tensor shaped like the output's (the only shortcut the ping-pong tiles take since round 5)
             make(P);
             char b[160];
             snprintf(b, sizeof(b), "[%d->%d %dx%d B%d k%ds%d act%d res%d in %d+%d/%d out %d+%d/%d] ", P.cin, P.cout, P.H, P.W, P.B, P.ks, P.stride, P.act, (int)P.res, P.in_off, P.cin, P.in_C,
