@@ -87,7 +87,9 @@ struct PpCfg {
 // Where output position m (of the launch's position enumeration: `wq` positions per image row, of which the first Wo hold outputs) and channel n go:
 // element offset into the output (and shortcut) tensor, and whether there is anything to store.  One multiply-high + shift per division (FastDiv),
 // 24-bit multiplies (full rate; every factor < 2^24: checked at launch) and ONE combined predicate -- the straightforward form (nested conditions, 32-bit
-// multiplies, 64-bit offsets) was half of the epilogue's 716 instructions per wave (profiles/r04/pp/README.md).
+// multiplies, 64-bit offsets) was half of the epilogue's 716 instructions per wave (profiles/r04/pp/README.md).  Since round 5 the 64- and 128-cout tiles call index()
+// ONCE per lane and tile, in front of the k-loop, and step from there (profiles/r05/pp_ahead); the 192-cout tile (12 chunks per pixel: a lane's stores are not one
+// chunk column) and maps narrower than a lane's step still call it per store.
 struct PpOut {
     int M, HW, wq, Ho, Wo, cout;
     int o0, o1, o2, ocs;          // output: offset of (b, y, x) = o0 + b * o1 + y * o2 + x * ocs
