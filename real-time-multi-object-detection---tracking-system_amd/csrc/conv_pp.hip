@@ -262,6 +262,7 @@ __global__ __launch_bounds__(512) void conv3x3_pp(ConvGroupArgs g, int total_ids
         // the same arithmetic runs while half 1 waits at the STAGGER barrier anyway / beside half 0's first DMA issue.  A lane's stores are positions m, m + KS, m + 2 KS, ...
         // (KS = 64 / CPR) of one 16-byte chunk column: ONE decomposition (two multiply-high divisions), then steps of KS positions with a row / image carry.
         // Element offsets in opx[], the store predicates as bits of okm; the shortcut tensor has the output tensor's geometry (checked at launch): same offsets.
+        // (Measured and dropped, profiles/r05/pp_ahead2: one step per phase inside the k-loop's R intervals, +7..17 %; half 0's share inside its first R interval, +3 %.)
         constexpr int EP_CPR = C::HB / 8, EP_NST = EP_CPR, EP_KS = 64 / (EP_CPR > 0 ? EP_CPR : 1);
         constexpr bool EP_AHEAD = C::HB == 64 || C::HB == 32;
         int opx_tile[EP_AHEAD ? EP_NST : 1];
@@ -275,12 +276,14 @@ __global__ __launch_bounds__(512) void conv3x3_pp(ConvGroupArgs g, int total_ids
             int oy = fdiv(rem, po.d_row), x = rem - (int)__umul24((unsigned)oy, (unsigned)po.wq);
             const bool nok = n < po.cout;
             if (po.wq >= EP_KS) {
+                int off = po.o0 + (int)__umul24((unsigned)b, (unsigned)po.o1) + (int)__umul24((unsigned)oy, (unsigned)po.o2) + (int)__umul24((unsigned)x, (unsigned)po.ocs) + n;
+                const int dx = EP_KS * po.ocs, drow = po.o2 - po.wq * po.ocs, dimg = po.o1 - po.Ho * po.o2;      // a step along the row; what a row carry / an image carry adds
 #pragma unroll
                 for (int j = 0; j < EP_NST; ++j) {
-                    opx_tile[j] = po.o0 + (int)__umul24((unsigned)b, (unsigned)po.o1) + (int)__umul24((unsigned)oy, (unsigned)po.o2) + (int)__umul24((unsigned)x, (unsigned)po.ocs) + n;
+                    opx_tile[j] = off;
                     okm |= (unsigned)((m < po.M) & (x < po.Wo) & nok) << j;
-                    m += EP_KS; x += EP_KS;
-                    if (x >= po.wq) { x -= po.wq; oy += 1; if (oy >= po.Ho) { oy = 0; b += 1; } }
+                    m += EP_KS; x += EP_KS; off += dx;
+                    if (x >= po.wq) { x -= po.wq; off += drow; oy += 1; if (oy >= po.Ho) { oy = 0; off += dimg; } }
                 }
             } else {                                      // rows shorter than the step (maps narrower than 8 / 16 pixels): the division per store
 #pragma unroll
@@ -621,12 +624,14 @@ __global__ __launch_bounds__(512) void conv_tile_pp(ConvArgs p, int n_tiles) {
             int oy = fdiv(rem, po.d_row), x = rem - (int)__umul24((unsigned)oy, (unsigned)po.wq);
             const bool nok = n < po.cout;
             if (po.wq >= EP_KS) {
+                int off = po.o0 + (int)__umul24((unsigned)b, (unsigned)po.o1) + (int)__umul24((unsigned)oy, (unsigned)po.o2) + (int)__umul24((unsigned)x, (unsigned)po.ocs) + n;
+                const int dx = EP_KS * po.ocs, drow = po.o2 - po.wq * po.ocs, dimg = po.o1 - po.Ho * po.o2;
 #pragma unroll
                 for (int j = 0; j < EP_CPR; ++j) {
-                    opx_tile[j] = po.o0 + (int)__umul24((unsigned)b, (unsigned)po.o1) + (int)__umul24((unsigned)oy, (unsigned)po.o2) + (int)__umul24((unsigned)x, (unsigned)po.ocs) + n;
+                    opx_tile[j] = off;
                     okm |= (unsigned)((m < po.M) & nok) << j;
-                    m += EP_KS; x += EP_KS;
-                    if (x >= po.wq) { x -= po.wq; oy += 1; if (oy >= po.Ho) { oy = 0; b += 1; } }
+                    m += EP_KS; x += EP_KS; off += dx;
+                    if (x >= po.wq) { x -= po.wq; off += drow; oy += 1; if (oy >= po.Ho) { oy = 0; off += dimg; } }
                 }
             } else {
 #pragma unroll
