@@ -425,6 +425,11 @@ int launch_front(const FrontLaunch &l, hipStream_t s) {
         RT_CHECK(!g.resize, RTMODT_E_INVALID, "launch_front: frames that need a resize go through the letterbox kernel (from_tensor)");
         RT_CHECK(l.frame0 >= 0 && l.frame0 + l.B <= 64, RTMODT_E_INVALID, "launch_front: frames %d..%d", l.frame0, l.frame0 + l.B);
         RT_CHECK((long)g.src_h * l.pitch < (1L << 31) && g.new_h >= 1 && g.new_w >= 1, RTMODT_E_INVALID, "launch_front: frame geometry");
+        // the kernel reads source pixel (y - top, x - left) for every canvas pixel inside [top, top + new_h) x [left, left + new_w): that window must be the frame, inside the canvas
+        RT_CHECK(g.new_h == g.src_h && g.new_w == g.src_w && g.top >= 0 && g.left >= 0 && g.top + g.new_h <= l.in_h && g.left + g.new_w <= l.in_w && l.pitch >= 3 * g.src_w,
+                 RTMODT_E_INVALID, "launch_front: a %dx%d frame (pitch %d) at (%d, %d) does not lie inside the %dx%d canvas unscaled", g.src_w, g.src_h, l.pitch, g.left, g.top, l.in_w, l.in_h);
+        for (int i = 0; i < l.B; ++i)
+            RT_CHECK((uintptr_t)l.frames.p[l.frame0 + i] >= (1ull << 32), RTMODT_E_INVALID, "launch_front: frame %d (%p) is not a device address", l.frame0 + i, (const void *)l.frames.p[l.frame0 + i]);
         a.frames = l.frames; a.frame0 = l.frame0; a.pitch = l.pitch; a.top = g.top; a.left = g.left; a.new_h = g.new_h; a.new_w = g.new_w;
         a.frame_bytes = (g.src_h - 1) * l.pitch + 3 * g.src_w;
         hipLaunchKernelGGL((front_fused<false>), dim3(G), dim3(256), 0, s, a);
