@@ -1387,10 +1387,16 @@ int launch_stem_fused(const FramePtrs &frames, int frame0, int pitch, const Lett
 }
 
 // ---------------------------------------------------------------------------------------
+// eight maxima as four packed instructions (v_pk_max_f16; the element-wise compare + select this replaces was 16 instructions and made the pooling kernel VALU-bound: 618 of its
+// 1 900 instructions).  maxnum semantics; the activations are finite, and a signed zero's sign has no effect downstream.
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ half8 hmax8(half8 a, half8 b) {
     half8 o;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) o[j] = a[j] > b[j] ? a[j] : b[j];
+    for (int j = 0; j < 8; j += 2) {
+        const half2v m = __builtin_elementwise_max(half2v{a[j], a[j + 1]}, half2v{b[j], b[j + 1]});
+        o[j] = m[0]; o[j + 1] = m[1];
+    }
     return o;
 }
 
@@ -1416,40 +1422,28 @@ __global__ __launch_bounds__(512) void sppf_pool(const f16 *__restrict__ y, int 
         tile[i] = *(const half8 *)(y + ((long)(b * Hp + yy + pad) * Wp + xx + pad) * cs + ch);
     }
     __syncthreads();
+    // max is idempotent: a neighbour outside the map is replaced by the nearest one inside (already in the window) -- no predicates
     for (int i = threadIdx.x; i < H * W; i += 512) {
-        int yy = i / W, xx = i - yy * W;
+        const int yy = i / W, xx = i - yy * W, lmax = xx, rmax = W - 1 - xx;
         half8 m = tile[i];
-        for (int d = 1; d <= 2; ++d) {
-            if (xx - d >= 0) m = hmax8(m, tile[i - d]);
-            if (xx + d < W) m = hmax8(m, tile[i + d]);
-        }
-        r5[i] = m;
-        for (int d = 3; d <= 4; ++d) {
-            if (xx - d >= 0) m = hmax8(m, tile[i - d]);
-            if (xx + d < W) m = hmax8(m, tile[i + d]);
-        }
-        r9[i] = m;
-        for (int d = 5; d <= 6; ++d) {
-            if (xx - d >= 0) m = hmax8(m, tile[i - d]);
-            if (xx + d < W) m = hmax8(m, tile[i + d]);
+#pragma unroll
+        for (int d = 1; d <= 6; ++d) {
+            m = hmax8(m, hmax8(tile[i - min(d, lmax)], tile[i + min(d, rmax)]));
+            if (d == 2) r5[i] = m;
+            if (d == 4) r9[i] = m;
         }
         r13[i] = m;
     }
     __syncthreads();
     for (int i = threadIdx.x; i < H * W; i += 512) {
-        int yy = i / W, xx = i - yy * W;
+        const int yy = i / W, xx = i - yy * W, umax = yy, dmax = H - 1 - yy;
         half8 a = r5[i], bq = r9[i], c = r13[i];
+#pragma unroll
         for (int d = 1; d <= 6; ++d) {
-            if (yy - d >= 0) {
-                if (d <= 2) a = hmax8(a, r5[i - d * W]);
-                if (d <= 4) bq = hmax8(bq, r9[i - d * W]);
-                c = hmax8(c, r13[i - d * W]);
-            }
-            if (yy + d < H) {
-                if (d <= 2) a = hmax8(a, r5[i + d * W]);
-                if (d <= 4) bq = hmax8(bq, r9[i + d * W]);
-                c = hmax8(c, r13[i + d * W]);
-            }
+            const int up = i - min(d, umax) * W, dn = i + min(d, dmax) * W;
+            if (d <= 2) a = hmax8(a, hmax8(r5[up], r5[dn]));
+            if (d <= 4) bq = hmax8(bq, hmax8(r9[up], r9[dn]));
+            c = hmax8(c, hmax8(r13[up], r13[dn]));
         }
         long opix = ((long)(b * Hp + yy + pad) * Wp + xx + pad) * ocs + ch;
         *(half8 *)(o1 + opix) = a;
